@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the HIP simulator on BASELINE.json's headline config.
+
+Workload (config.workload): Quadrotor2D trajectory tracking (the env of BASELINE configs[2];
+examples/rl/config_overrides/quadrotor_2D/quadrotor_2D_track.yaml), 65 536 envs per GPU, float32.
+One "step" = one control step of every env = ONE launch of the fused step kernel (action
+pre-processing, 20 engine substeps, observation / reward / done / info / 16 constraint rows,
+episode statistics, auto-reset), driven by synthetic actions ~U(-1,1) already resident in HBM
+(the reference's own README benchmark is the same open-loop random-action loop on one env).
+The K timed launches are replayed from a HIP graph so the measurement is not Python-bound.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank
+per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.  Env shards are independent
+(rank r owns global env ids [r*N, (r+1)*N)), there is no data-path collective: scaling = weak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# SURVEY.md §8d algorithmic bytes per env-step (fp32): read state 24 + action 8 + counter 4;
+# write state 24 + obs 48 + reward 4 + done 1 + flags 1 (trunc+violation+oob packed; survey counts 1+1)
+# + counter 4 + c_values 64 + mse 4  => 187 B with the survey's accounting.
+ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'quadrotor_3D_track': 363}
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20000)
+    ap.add_argument('--warmup', type=int, default=2000)
+    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
+    ap.add_argument('--task', default='quadrotor_2D_track')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
+    ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of a HIP graph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU oracle baseline')
+    ap.add_argument('--graph-len', type=int, default=1000, help='steps captured per HIP graph')
+    return ap.parse_args()
+
+
+def cpu_baseline(task, cfg, env_id, budget_s):
+    """The float64 NumPy oracle (port of the reference's per-env Python + Bullet step) timed on the host:
+    batched over 4096 envs on one core, random actions, for ~budget_s seconds."""
+    import numpy as np
+    from oracle.envs import make_oracle_env, make_rng
+    from oracle.vec import OracleVecEnv
+    n = 4096
+    env = OracleVecEnv(make_oracle_env(env_id, n, make_rng('philox', n, 42), **cfg))
+    env.reset()
+    rng = np.random.default_rng(0)
+    nu = env.env.action_dim
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        env.step(rng.uniform(-1, 1, size=(n, nu)))
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {'value': n * steps / el, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'oracle/ (float64 NumPy restatement, batched over {n} envs), {steps} control steps of {task} '
+                      f'with random actions in {el:.1f} s on 1 host core; reference README (1 env, PyBullet, '
+                      f'i7-1068NG7): 381-464 env-steps/s'}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f'[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    dtype = torch.float32 if args.dtype == 'f32' else torch.float64
+    env_id, cfg = load_task(args.task)
+    N = args.envs
+    env = HipVecEnv(env_id, N, seed=1337, dtype=dtype, env_id_offset=rank * N, return_numpy=False, **cfg)
+    nu = env.spec.nu
+    # synthetic actions resident in HBM: a ring of pre-generated batches
+    ring = 64
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    actions = (torch.rand(ring, N, nu, device=dev, dtype=dtype, generator=gen) * 2 - 1)
+    env.reset_tensors()
+
+    def run_steps(k0, k):
+        for t in range(k0, k0 + k):
+            env.step_tensors(actions[t % ring])
+
+    G = max(1, min(args.graph_len, args.steps))
+    graph = None
+    if not args.no_graph:
+        # warm up on a side stream, then capture G consecutive control steps
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run_steps(0, 8)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run_steps(0, G)
+
+    def do(k):
+        if graph is None:
+            run_steps(0, k)
+            return k
+        reps = (k + G - 1) // G
+        for _ in range(reps):
+            graph.replay()
+        return reps * G
+
+    do(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    done_steps = do(args.steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / done_steps          # avg launch-to-launch period of the step kernel
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    # sanity: the simulator really advanced (episodes finished, finite rewards)
+    ok = bool(torch.isfinite(env.out.reward).all().item())
+    total_env_steps = world * N * done_steps
+    value = total_env_steps / elapsed
+    if rank == 0:
+        algo = ALGO_BYTES_PER_ENV_STEP.get(args.task)
+        if dtype == torch.float64 and algo:
+            algo = None
+        achieved = (algo * N / (kernel_ms * 1e-3)) / 1e9 if algo else None
+        out = {
+            'metric': 'env-steps/sec (whole node), Quadrotor2D-track', 'value': value, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': done_steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / done_steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': f'{args.task}: {N} envs/GPU x {world} GPU, 1 launch of the fused step kernel per '
+                                   f'control step (20 engine substeps, obs/reward/done/info/constraints, auto-reset), '
+                                   f'synthetic U(-1,1) actions resident in HBM, '
+                                   f'{"HIP graph of %d steps" % G if graph is not None else "per-step Python launches"}',
+                       'envs_per_gpu': N, 'task_yaml': f'safe_control_gym_amd/configs/{args.task}.yaml',
+                       'parallelism': f'env-shard x{world}', 'finite_outputs': ok},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                         'kernel': 'step_kernel<QUAD_2D,float>', 'avg_launch_us': kernel_ms * 1e3,
+                         'algorithmic_bytes_per_env_step': algo},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.task, cfg, env_id, args.cpu_seconds)
+            out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

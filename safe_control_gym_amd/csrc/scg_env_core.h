@@ -1,0 +1,715 @@
+// scg_env_core.h — one environment instance per thread: the fused control step.
+//
+// Device-side statement of the reference's per-env Python hot path (paths relative to
+// /root/reference/safe_control_gym/envs), one launch per control step:
+//   before_step / _preprocess_control   benchmark_env.py:400-420, gym_pybullet_drones/quadrotor.py:722-775,
+//                                       gym_pybullet_drones/quadrotor_utils.py:16-60, gym_control/cartpole.py:479-530
+//   disturbances                        disturbances.py:54-259
+//   _advance_simulation (PYB_FREQ/CTRL_FREQ engine steps, semi-implicit Euler + Bullet's velocity clamp)
+//                                       gym_pybullet_drones/base_aviary.py:232-286,364-384, gym_control/cartpole.py:532-583
+//   _get_observation / extend_obs       quadrotor.py:777-817, cartpole.py:585-609, benchmark_env.py:422-445
+//   _get_reward / _get_done / _get_info quadrotor.py:819-923, cartpole.py:611-696
+//   after_step (constraints, penalty, time limit)   benchmark_env.py:447-502, constraints.py:97-131
+//   auto-reset (DummyVecEnv)            env_wrappers/vectorized_env/dummy_vec_env.py:29-41,
+//                                       quadrotor.py:328-392, cartpole.py:266-352, benchmark_env.py:237-268,320-359
+// Written from the semantics (see oracle/ for the float64 CPU restatement they are tested against),
+// not translated: state is SoA in HBM, everything between load and store lives in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scg_params.h"
+#include "scg_rng.h"
+
+namespace scg {
+
+// ------------------------------------------------------------------ math wrappers
+__device__ __forceinline__ float m_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double m_cos(double x) { return cos(x); }
+__device__ __forceinline__ void m_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ void m_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_log(float x) { return logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double m_pow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float m_asin(float x) { return asinf(x); }
+__device__ __forceinline__ double m_asin(double x) { return asin(x); }
+__device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_rint(float x) { return rintf(x); }
+__device__ __forceinline__ double m_rint(double x) { return rint(x); }
+__device__ __forceinline__ float m_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double m_floor(double x) { return floor(x); }
+template <typename T> __device__ __forceinline__ T m_clamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+template <typename T> __device__ __forceinline__ T m_max(T a, T b) { return a > b ? a : b; }
+
+template <typename T> struct Const {
+    static constexpr T PI = (T)3.14159265358979323846;
+    static constexpr T TWO_PI = (T)6.28318530717958647692;
+    static constexpr T HALF_PI = (T)1.57079632679489661923;
+};
+
+// math_and_models/normalization.py:8-10: ((x + pi) % (2 pi)) - pi with Python's floored modulo.
+template <typename T>
+__device__ __forceinline__ T normalize_angle(T x) {
+    T y = x + Const<T>::PI;
+    y = y - Const<T>::TWO_PI * m_floor(y / Const<T>::TWO_PI);
+    return y - Const<T>::PI;
+}
+
+// ------------------------------------------------------------------ per-system dimensions
+template <int SYS> struct Dims;
+template <> struct Dims<SCG_CARTPOLE> { enum { NX = 4, NU = 1, NS = 4, NP = 3, DYN = 2 }; };
+template <> struct Dims<SCG_QUAD_1D> { enum { NX = 2, NU = 1, NS = 2, NP = 4, DYN = 1 }; };
+template <> struct Dims<SCG_QUAD_2D> { enum { NX = 6, NU = 2, NS = 6, NP = 4, DYN = 2 }; };
+template <> struct Dims<SCG_QUAD_3D> { enum { NX = 12, NU = 4, NS = 13, NP = 4, DYN = 3 }; };
+
+// Device view of scg_step_out with typed pointers.
+template <typename T>
+struct StepOut {
+    T* obs; T* reward; uint8_t* done; uint8_t* flags; T* c_values; T* mse; T* terminal_obs; T* state;
+    T* noisy_action; T* ep_return; int32_t* ep_length; T* ep_violation; T* ep_mse;
+    T* fin_return; int32_t* fin_length; T* fin_violation; T* fin_mse;
+};
+
+enum : uint8_t { FLAG_TRUNCATED = 1, FLAG_VIOLATION = 2, FLAG_OOB = 4, FLAG_GOAL = 8 };
+
+template <int SYS, typename T>
+struct Env {
+    using D = Dims<SYS>;
+    T s[D::NS];        // raw simulator state
+    T par[D::NP];      // inertial parameters
+    int32_t step;      // ctrl_step_counter
+    uint32_t episode;
+    uint32_t gid;      // global env id (Philox counter word 0)
+};
+
+// ------------------------------------------------------------------ random helpers
+template <typename T>
+__device__ __forceinline__ T draw_rand(const DevRand<T>& r, RngKey key, uint32_t gid, uint32_t episode, uint32_t item) {
+    if (r.kind == SCG_RAND_NONE) return (T)0;
+    U4 w = rng_words(key, gid, episode, 0u, rng_tag(RNG_CH_RESET, item, 0));
+    if (r.kind == SCG_RAND_UNIFORM) return r.p0 + (r.p1 - r.p0) * u01<T>(w.x);
+    if (r.kind == SCG_RAND_NORMAL) {
+        T u1 = u01<T>(w.x), u2 = u01<T>(w.y);
+        return r.p0 + r.p1 * (m_sqrt((T)-2 * m_log(u1)) * m_cos(Const<T>::TWO_PI * u2));
+    }
+    uint32_t k = int_below(w.x, (uint32_t)r.n_choice);
+    T v = r.choices[0];
+#pragma unroll
+    for (int c = 1; c < SCG_MAX_CHOICE; ++c) v = (k == (uint32_t)c) ? r.choices[c] : v;
+    return v;
+}
+
+// DisturbanceList.apply (disturbances.py:54-62) for one channel; `vec` has `dim` entries.
+// rng_step: Philox step index (pre-increment counter for action/dynamics; observation index for obs).
+template <typename T, int MAXDIM>
+__device__ __forceinline__ void apply_disturbances(const DevParams<T>* __restrict__ P, int ch, T* vec, int dim,
+                                                   RngKey key, uint32_t gid, uint32_t episode, uint32_t rng_step,
+                                                   int32_t ctrl_step, int env_index) {
+    const int n = P->n_dist[ch];
+    for (int k = 0; k < n; ++k) {
+        const DevDist<T>& d = P->dist[ch][k];
+        const uint32_t rch = (uint32_t)(ch + 1);
+        if (d.kind == SCG_DIST_IMPULSE || d.kind == SCG_DIST_STEP) {
+            int32_t off = d.offset_slot >= 0 ? P->dist_offset[(size_t)d.offset_slot * P->num_envs + env_index] : d.step_offset;
+            T gain = (T)0;
+            if (ctrl_step >= off) {
+                if (d.kind == SCG_DIST_STEP) {
+                    gain = (T)1;
+                } else {
+                    int32_t peak = (int32_t)((T)off + d.half_duration);           // int(offset + duration/2)
+                    int32_t po = ctrl_step - peak; po = po < 0 ? -po : po;
+                    gain = ((T)po < d.half_duration) ? m_pow(d.decay_rate, (T)po) : (T)0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MAXDIM; ++j) if (j < dim) vec[j] += d.a[j] * gain;
+        } else if (d.kind == SCG_DIST_UNIFORM || d.kind == SCG_DIST_PERIODIC) {
+            U4 w{0, 0, 0, 0};
+            T tphase = (T)0;
+            if (d.kind == SCG_DIST_PERIODIC) tphase = d.two_pi_freq * ((T)(ctrl_step * P->substeps) * P->pyb_dt);
+#pragma unroll
+            for (int j = 0; j < MAXDIM; ++j) {
+                if (j < dim) {
+                    if ((j & 3) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 2)));
+                    T u = u01<T>(u4_get(w, j & 3));
+                    if (d.kind == SCG_DIST_UNIFORM) {
+                        vec[j] += (d.a[j] + (d.b[j] - d.a[j]) * u) * d.mask[j];
+                    } else {
+                        T phase = -Const<T>::PI + Const<T>::TWO_PI * u;
+                        vec[j] += d.a[j] * m_sin(tphase + phase);
+                    }
+                }
+            }
+        } else if (d.kind == SCG_DIST_WHITE) {
+            U4 w{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < MAXDIM; ++j) {
+                if (j < dim) {
+                    if ((j & 1) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 1)));
+                    T u1 = u01<T>((j & 1) ? w.z : w.x), u2 = u01<T>((j & 1) ? w.w : w.y);
+                    T z = m_sqrt((T)-2 * m_log(u1)) * m_cos(Const<T>::TWO_PI * u2);
+                    vec[j] += d.a[j] * z * d.mask[j];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ quaternion helpers (PyBullet conventions)
+template <typename T>
+__device__ __forceinline__ void quat_to_mat(const T* q, T R[3][3]) {
+    T x = q[0], y = q[1], z = q[2], w = q[3];
+    T d = x * x + y * y + z * z + w * w;
+    T s = (T)2 / d;
+    T xs = x * s, ys = y * s, zs = z * s;
+    T wx = w * xs, wy = w * ys, wz = w * zs;
+    T xx = x * xs, xy = x * ys, xz = x * zs;
+    T yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0][0] = (T)1 - (yy + zz); R[0][1] = xy - wz; R[0][2] = xz + wy;
+    R[1][0] = xy + wz; R[1][1] = (T)1 - (xx + zz); R[1][2] = yz - wx;
+    R[2][0] = xz - wy; R[2][1] = yz + wx; R[2][2] = (T)1 - (xx + yy);
+}
+
+// p.getEulerFromQuaternion incl. gimbal branches.
+template <typename T>
+__device__ __forceinline__ void quat_to_euler(const T* q, T* rpy) {
+    T x = q[0], y = q[1], z = q[2], w = q[3];
+    T sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+    T sarg = (T)-2 * (x * z - w * y);
+    if (sarg <= (T)-0.99999) {
+        rpy[0] = (T)0; rpy[1] = -Const<T>::HALF_PI; rpy[2] = (T)2 * m_atan2(x, -y);
+    } else if (sarg >= (T)0.99999) {
+        rpy[0] = (T)0; rpy[1] = Const<T>::HALF_PI; rpy[2] = (T)2 * m_atan2(-x, y);
+    } else {
+        rpy[0] = m_atan2((T)2 * (y * z + w * x), squ - sqx - sqy + sqz);
+        rpy[1] = m_asin(sarg);
+        rpy[2] = m_atan2((T)2 * (x * y + w * z), squ + sqx - sqy - sqz);
+    }
+}
+
+// p.getQuaternionFromEuler.
+template <typename T>
+__device__ __forceinline__ void euler_to_quat(T r, T p, T y, T* q) {
+    T sr, cr, sp, cp, sy, cy;
+    m_sincos((T)0.5 * r, &sr, &cr);
+    m_sincos((T)0.5 * p, &sp, &cp);
+    m_sincos((T)0.5 * y, &sy, &cy);
+    q[0] = sr * cp * cy - cr * sp * sy;
+    q[1] = cr * sp * cy + sr * cp * sy;
+    q[2] = cr * cp * sy - sr * sp * cy;
+    q[3] = cr * cp * cy + sr * sp * sy;
+}
+
+// The pitch PyBullet reports for a pure rotation by `th` about +y: asin(sin th) with the gimbal snap.
+template <typename T>
+__device__ __forceinline__ T planar_pitch(T th) {
+    if (m_abs(th) < (T)1.5663) return th;       // asin(0.99999) = 1.56632...
+    T sarg = m_sin(th);
+    if (sarg <= (T)-0.99999) return -Const<T>::HALF_PI;
+    if (sarg >= (T)0.99999) return Const<T>::HALF_PI;
+    return m_asin(sarg);
+}
+
+// ------------------------------------------------------------------ the environment
+template <int SYS, typename T>
+struct EnvOps {
+    using D = Dims<SYS>;
+    using E = Env<SYS, T>;
+    static constexpr bool IS_QUAD = (SYS != SCG_CARTPOLE);
+
+    __device__ static __forceinline__ void load(const DevParams<T>* __restrict__ P, int i, E& e) {
+        const size_t N = (size_t)P->num_envs;
+#pragma unroll
+        for (int k = 0; k < D::NS; ++k) e.s[k] = P->state[k * N + i];
+        if (P->per_env_params) {
+#pragma unroll
+            for (int k = 0; k < D::NP; ++k) e.par[k] = P->param[k * N + i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < D::NP; ++k) e.par[k] = P->base_param[k];
+        }
+        e.step = P->step[i];
+        e.episode = P->episode[i];
+        e.gid = (uint32_t)(P->env_id_offset + i);
+    }
+
+    __device__ static __forceinline__ void store(const DevParams<T>* __restrict__ P, int i, const E& e, bool params_dirty) {
+        const size_t N = (size_t)P->num_envs;
+#pragma unroll
+        for (int k = 0; k < D::NS; ++k) P->state[k * N + i] = e.s[k];
+        if (P->per_env_params && params_dirty) {
+#pragma unroll
+            for (int k = 0; k < D::NP; ++k) P->param[k * N + i] = e.par[k];
+        }
+        P->step[i] = e.step;
+        P->episode[i] = e.episode;
+    }
+
+    // env.state (the vector the reference exposes), from the raw simulator state.
+    __device__ static __forceinline__ void state_vector(const E& e, T* st) {
+        if constexpr (SYS == SCG_CARTPOLE || SYS == SCG_QUAD_1D) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) st[k] = e.s[k];
+        } else if constexpr (SYS == SCG_QUAD_2D) {
+            st[0] = e.s[0]; st[1] = e.s[1]; st[2] = e.s[2]; st[3] = e.s[3];
+            st[4] = planar_pitch(e.s[4]); st[5] = e.s[5];
+        } else {
+            // quadrotor.py:794-802: positions/velocities interleaved, rpy, BODY rates R^T w.
+            T R[3][3];
+            quat_to_mat(&e.s[3], R);
+            T rpy[3];
+            quat_to_euler(&e.s[3], rpy);
+            st[0] = e.s[0]; st[1] = e.s[7]; st[2] = e.s[1]; st[3] = e.s[8]; st[4] = e.s[2]; st[5] = e.s[9];
+            st[6] = rpy[0]; st[7] = rpy[1]; st[8] = rpy[2];
+            const T wx = e.s[10], wy = e.s[11], wz = e.s[12];
+            st[9] = R[0][0] * wx + R[1][0] * wy + R[2][0] * wz;
+            st[10] = R[0][1] * wx + R[1][1] * wy + R[2][1] * wz;
+            st[11] = R[0][2] * wx + R[1][2] * wy + R[2][2] * wz;
+        }
+    }
+
+    // Reset one env (Quadrotor.reset / CartPole.reset).  Increments the episode index, draws disturbance
+    // offsets, inertial parameters and the initial state (each addressed by its own Philox counter).
+    __device__ static __forceinline__ void reset(const DevParams<T>* __restrict__ P, int i, E& e, RngKey key) {
+        e.episode += 1u;
+        e.step = 0;
+        // disturbance offsets (ImpulseDisturbance.reset / StepDisturbance.reset)
+        for (int ch = 0; ch < 3; ++ch) {
+            for (int k = 0; k < P->n_dist[ch]; ++k) {
+                const DevDist<T>& d = P->dist[ch][k];
+                if (d.offset_slot >= 0) {
+                    U4 w = rng_words(key, e.gid, e.episode, 0u,
+                                     rng_tag(RNG_CH_RESET, RNG_ITEM_DISTURB0 + 8u * (uint32_t)ch + (uint32_t)k, 0));
+                    P->dist_offset[(size_t)d.offset_slot * P->num_envs + i] = (int32_t)int_below(w.x, (uint32_t)d.max_step);
+                }
+            }
+        }
+        if (P->per_env_params) {
+#pragma unroll
+            for (int k = 0; k < D::NP; ++k)
+                e.par[k] = P->base_param[k] + draw_rand(P->param_rand[k], key, e.gid, e.episode, RNG_ITEM_PARAM0 + (uint32_t)k);
+        }
+        T iv[D::NX];
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) {
+            iv[k] = P->init_state[k];
+            if (P->randomized_init) iv[k] += draw_rand(P->init_rand[k], key, e.gid, e.episode, RNG_ITEM_INIT0 + (uint32_t)k);
+        }
+        if constexpr (SYS == SCG_CARTPOLE || SYS == SCG_QUAD_2D) {
+#pragma unroll
+            for (int k = 0; k < D::NS; ++k) e.s[k] = iv[k];
+        } else if constexpr (SYS == SCG_QUAD_1D) {
+            // INIT_STATE_LABELS[ONE_D] = ['init_x', 'init_x_dot'] (quadrotor.py:210) while reset() reads
+            // init_z / init_z_dot with default 0 (:373-374): the 1D drone always starts at z = 0, z_dot = 0
+            // and the drawn init_x values only move x.  Replicated: the raw state is (z, z_dot) = 0.
+            e.s[0] = (T)0; e.s[1] = (T)0;
+            (void)iv;
+        } else {
+            e.s[0] = iv[0]; e.s[1] = iv[2]; e.s[2] = iv[4];         // pos
+            euler_to_quat(iv[6], iv[7], iv[8], &e.s[3]);             // quat from (phi, theta, psi)
+            e.s[7] = iv[1]; e.s[8] = iv[3]; e.s[9] = iv[5];         // vel
+            e.s[10] = iv[9]; e.s[11] = iv[10]; e.s[12] = iv[11];    // p,q,r applied as WORLD rates (:379-384)
+        }
+    }
+
+    // Observation row: state (+ observation-channel noise) (+ angle wrap) (+ goal rows).
+    //   next_index: first X_GOAL row appended (1 at reset, ctrl_step_counter + 2 after a step;
+    //               benchmark_env.py:433-437, quadrotor.py:813-816)
+    //   rng_step:   Philox step index of the observation (0 at reset, k after the k-th step)
+    //   ctrl_step:  ctrl_step_counter seen by impulse/step disturbances (pre-increment value)
+    __device__ static __forceinline__ void write_obs(const DevParams<T>* __restrict__ P, const T* goal_tab, const T* st,
+                                                     const E& e, RngKey key, int next_index, uint32_t rng_step,
+                                                     int32_t ctrl_step, int env_index, T* dst) {
+        T o[D::NX];
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) o[k] = st[k];
+        if (P->n_dist[SCG_CH_OBSERVATION] > 0)
+            apply_disturbances<T, D::NX>(P, SCG_CH_OBSERVATION, o, D::NX, key, e.gid, e.episode, rng_step, ctrl_step, env_index);
+        if constexpr (SYS == SCG_CARTPOLE) {
+            if (P->obs_wrap_angle) o[2] = normalize_angle(o[2]);
+        }
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
+        const int h = P->obs_goal_horizon;
+        if (h > 0 && P->cost == SCG_COST_RL_REWARD) {
+            if (P->task == SCG_TASK_TRAJ_TRACKING) {
+                const int last = P->goal_rows - 1;
+                for (int r = 0; r < h; ++r) {
+                    int row = next_index + r; row = row > last ? last : row;
+#pragma unroll
+                    for (int k = 0; k < D::NX; ++k) dst[D::NX * (1 + r) + k] = goal_tab[row * D::NX + k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) dst[D::NX + k] = goal_tab[k];
+            }
+        }
+    }
+
+    // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset.
+    __device__ static __forceinline__ bool constraints(const DevParams<T>* __restrict__ P, const T* st, const T* act,
+                                                       T* c_out, size_t stride, bool only_state) {
+        bool viol = false;
+        int out_row = 0;
+        for (int r = 0; r < P->n_con_rows; ++r) {
+            const DevRow<T>& row = P->con[r];
+            if (only_state && row.var != 0) continue;
+            T c;
+            if (row.kind == SCG_ROW_SPARSE || row.kind == SCG_ROW_ABS) {
+                T v = (T)0;
+                if (row.var == 0) {
+#pragma unroll
+                    for (int k = 0; k < D::NX; ++k) v = (row.index == k) ? st[k] : v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < D::NU; ++k) v = (row.index == k) ? act[k] : v;
+                }
+                c = (row.kind == SCG_ROW_ABS) ? (m_abs(v) - row.b) : (row.sign * v - row.b);
+            } else if (row.kind == SCG_ROW_DENSE) {
+                c = (T)0;
+                if (row.var == 0) {
+#pragma unroll
+                    for (int k = 0; k < D::NX; ++k) c += row.coef[k] * st[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < D::NU; ++k) c += row.coef[k] * act[k];
+                }
+                c -= row.b;
+            } else {   // quadratic: v' P v - b over the state (or input) vector
+                const T* Pm = P->quad_P[row.index];
+                c = (T)0;
+                if (row.var == 0) {
+                    for (int a = 0; a < D::NX; ++a) {
+                        T acc = (T)0;
+                        for (int b = 0; b < D::NX; ++b) acc += Pm[a * D::NX + b] * st[b];
+                        c += st[a] * acc;
+                    }
+                } else {
+                    for (int a = 0; a < D::NU; ++a) {
+                        T acc = (T)0;
+                        for (int b = 0; b < D::NU; ++b) acc += Pm[a * D::NU + b] * act[b];
+                        c += act[a] * acc;
+                    }
+                }
+                c -= row.b;
+            }
+            if (row.round_scale > (T)0) c = m_rint(c * row.round_scale) * row.inv_round_scale;
+            viol = viol || (row.strict ? (c >= (T)0) : (c > (T)0));
+            if (c_out) c_out[(size_t)out_row * stride] = c;
+            ++out_row;
+        }
+        return viol;
+    }
+
+    struct StepResult { T reward; T mse; bool done; uint8_t flags; };
+
+    // One control step, no auto-reset.  `act_in` = raw controller action; `adv` = adversary action or null.
+    // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
+    __device__ static __forceinline__ StepResult step(const DevParams<T>* __restrict__ P, const T* goal_tab, E& e,
+                                                      const T* act_in, const T* adv, RngKey key, int env_index,
+                                                      T* st, T* noisy_out, T* c_out, size_t c_stride) {
+        const int32_t c0 = e.step;      // ctrl_step_counter before the increment
+        // ---- _preprocess_control
+        T noisy[D::NU], clipped[D::NU];
+#pragma unroll
+        for (int j = 0; j < D::NU; ++j) {
+            T a = act_in[j];
+            if (P->normalized_action) {
+                if constexpr (IS_QUAD) a = ((T)1 + P->act_scale * a) * P->hover_thrust;
+                else a = P->act_scale * a;
+            }
+            noisy[j] = a;
+        }
+        if (P->n_dist[SCG_CH_ACTION] > 0)
+            apply_disturbances<T, D::NU>(P, SCG_CH_ACTION, noisy, D::NU, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
+        if (P->adversary_channel == SCG_CH_ACTION && adv) {
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) noisy[j] += adv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D::NU; ++j) {
+            clipped[j] = m_clamp(noisy[j], P->act_low[j], P->act_high[j]);
+            if (noisy_out) noisy_out[j] = noisy[j];
+        }
+        // ---- dynamics disturbance, sampled once per control step (quadrotor.py:413-435, cartpole.py:540-551)
+        T fd[D::DYN];
+#pragma unroll
+        for (int j = 0; j < D::DYN; ++j) fd[j] = (T)0;
+        const bool has_dyn = (P->n_dist[SCG_CH_DYNAMICS] > 0) || (P->adversary_channel == SCG_CH_DYNAMICS);
+        if (P->n_dist[SCG_CH_DYNAMICS] > 0)
+            apply_disturbances<T, D::DYN>(P, SCG_CH_DYNAMICS, fd, D::DYN, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
+        if (P->adversary_channel == SCG_CH_DYNAMICS && adv) {
+#pragma unroll
+            for (int j = 0; j < D::DYN; ++j) fd[j] += adv[j];
+        }
+        // ---- physics
+        const T h = P->pyb_dt;
+        const T vmax = P->vmax;
+        if constexpr (SYS == SCG_CARTPOLE) {
+            const T force = clipped[0];
+            const T l = e.par[0], M = e.par[1], m = e.par[2];
+            // Bullet recomputes the pole inertia from its collision box (see oracle/bullet.py::pole_inertia).
+            const T two_l = (T)2 * l;
+            const T ip = m * (P->pole_box_width * P->pole_box_width + two_l * two_l) * (T)(1.0 / 12.0);
+            const T a11 = M + m, a22 = ip + m * l * l, ml = m * l;
+            T x = e.s[0], xd = e.s[1], th = e.s[2], thd = e.s[3];
+            for (int k = 0; k < P->substeps; ++k) {
+                T sn, cs;
+                m_sincos(th, &sn, &cs);
+                const T a12 = ml * cs;
+                T b1 = force + ml * thd * thd * sn;
+                T b2 = m * P->gravity * l * sn;
+                if (has_dyn) { b1 += fd[0]; b2 += l * (fd[0] * cs - fd[1] * sn); }
+                const T det = a11 * a22 - a12 * a12;
+                const T xdd = (a22 * b1 - a12 * b2) / det;
+                const T thdd = (a11 * b2 - a12 * b1) / det;
+                xd = m_clamp(xd + h * xdd, -vmax, vmax);
+                thd = m_clamp(thd + h * thdd, -vmax, vmax);
+                x += h * xd;
+                th += h * thd;
+            }
+            e.s[0] = x; e.s[1] = xd; e.s[2] = th; e.s[3] = thd;
+        } else {
+            // cmd2pwm / pwm2rpm (quadrotor_utils.py:16-60) and per-motor forces (base_aviary.py:370-372)
+            T pwm[4];
+            constexpr int n_motor = 4 / D::NU;
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) {
+                T thr = m_max(clipped[j], (T)0);
+                pwm[j] = (m_sqrt(thr / (T)n_motor / P->kf) - P->pwm2rpm_const) / P->pwm2rpm_scale;
+            }
+            if constexpr (D::NU == 1) { pwm[1] = pwm[0]; pwm[2] = pwm[0]; pwm[3] = pwm[0]; }
+            if constexpr (D::NU == 2) { pwm[2] = pwm[1]; pwm[3] = pwm[0]; }
+            T f[4], tq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T p = m_clamp(pwm[j], P->pwm_min, P->pwm_max);
+                T rpm = P->pwm2rpm_scale * p + P->pwm2rpm_const;
+                f[j] = rpm * rpm * P->kf;
+                tq[j] = rpm * rpm * P->km;
+            }
+            const T thrust = f[0] + f[1] + f[2] + f[3];
+            const T mass = e.par[0];
+            const T g = P->gravity;
+            const T arm = P->arm;
+            if constexpr (SYS == SCG_QUAD_1D) {
+                T z = e.s[0], vz = e.s[1];
+                const T az = thrust / mass - g + (has_dyn ? fd[0] / mass : (T)0);
+                for (int k = 0; k < P->substeps; ++k) {
+                    vz = m_clamp(vz + h * az, -vmax, vmax);
+                    z += h * vz;
+                }
+                e.s[0] = z; e.s[1] = vz;
+            } else if constexpr (SYS == SCG_QUAD_2D) {
+                // planar reduction of the free-body step: y, roll, yaw stay 0 (motors [T1,T2,T2,T1]/2)
+                const T iyy = e.par[2];
+                const T tau_prop = arm * (-f[0] + f[1] + f[2] - f[3]);
+                const T tm = thrust / mass;
+                T x = e.s[0], vx = e.s[1], z = e.s[2], vz = e.s[3], th = e.s[4], w = e.s[5];
+                const T x0 = x, z0 = z;       // applyExternalForce point cached at the start of the control step
+                const T fx = has_dyn ? fd[0] : (T)0, fz = has_dyn ? fd[1] : (T)0;
+                for (int k = 0; k < P->substeps; ++k) {
+                    T sn, cs;
+                    m_sincos(th, &sn, &cs);
+                    T tau = tau_prop;
+                    if (has_dyn) tau += (z0 - z) * fx - (x0 - x) * fz;      // ((p0 - p) x F)_y, base_aviary.py:272
+                    const T wd = tau / iyy;
+                    const T ax = sn * tm + fx / mass;
+                    const T az = cs * tm - g + fz / mass;
+                    w = m_clamp(w + h * wd, -vmax, vmax);
+                    vx = m_clamp(vx + h * ax, -vmax, vmax);
+                    vz = m_clamp(vz + h * az, -vmax, vmax);
+                    x += h * vx;
+                    z += h * vz;
+                    th += h * w;
+                }
+                e.s[0] = x; e.s[1] = vx; e.s[2] = z; e.s[3] = vz; e.s[4] = th; e.s[5] = w;
+            } else {
+                const T J0 = e.par[1], J1 = e.par[2], J2 = e.par[3];
+                const T tb0 = arm * (f[0] + f[1] - f[2] - f[3]);
+                const T tb1 = arm * (-f[0] + f[1] + f[2] - f[3]);
+                const T tb2 = -tq[0] + tq[1] - tq[2] + tq[3];
+                T p[3] = {e.s[0], e.s[1], e.s[2]};
+                T q[4] = {e.s[3], e.s[4], e.s[5], e.s[6]};
+                T v[3] = {e.s[7], e.s[8], e.s[9]};
+                T w[3] = {e.s[10], e.s[11], e.s[12]};
+                const T p0[3] = {p[0], p[1], p[2]};
+                for (int k = 0; k < P->substeps; ++k) {
+                    T R[3][3];
+                    quat_to_mat(q, R);
+                    T t0 = tb0, t1 = tb1, t2 = tb2;
+                    if (has_dyn) {
+                        const T r0 = p0[0] - p[0], r1 = p0[1] - p[1], r2 = p0[2] - p[2];
+                        const T tw0 = r1 * fd[2] - r2 * fd[1], tw1 = r2 * fd[0] - r0 * fd[2], tw2 = r0 * fd[1] - r1 * fd[0];
+                        t0 += R[0][0] * tw0 + R[1][0] * tw1 + R[2][0] * tw2;
+                        t1 += R[0][1] * tw0 + R[1][1] * tw1 + R[2][1] * tw2;
+                        t2 += R[0][2] * tw0 + R[1][2] * tw1 + R[2][2] * tw2;
+                    }
+                    const T wb0 = R[0][0] * w[0] + R[1][0] * w[1] + R[2][0] * w[2];
+                    const T wb1 = R[0][1] * w[0] + R[1][1] * w[1] + R[2][1] * w[2];
+                    const T wb2 = R[0][2] * w[0] + R[1][2] * w[1] + R[2][2] * w[2];
+                    const T jw0 = J0 * wb0, jw1 = J1 * wb1, jw2 = J2 * wb2;
+                    const T wd0 = (t0 - (wb1 * jw2 - wb2 * jw1)) / J0;
+                    const T wd1 = (t1 - (wb2 * jw0 - wb0 * jw2)) / J1;
+                    const T wd2 = (t2 - (wb0 * jw1 - wb1 * jw0)) / J2;
+                    const T tm = thrust / mass;
+                    T a0 = R[0][2] * tm, a1 = R[1][2] * tm, a2 = R[2][2] * tm - g;
+                    if (has_dyn) { a0 += fd[0] / mass; a1 += fd[1] / mass; a2 += fd[2] / mass; }
+                    w[0] = m_clamp(w[0] + h * (R[0][0] * wd0 + R[0][1] * wd1 + R[0][2] * wd2), -vmax, vmax);
+                    w[1] = m_clamp(w[1] + h * (R[1][0] * wd0 + R[1][1] * wd1 + R[1][2] * wd2), -vmax, vmax);
+                    w[2] = m_clamp(w[2] + h * (R[2][0] * wd0 + R[2][1] * wd1 + R[2][2] * wd2), -vmax, vmax);
+                    v[0] = m_clamp(v[0] + h * a0, -vmax, vmax);
+                    v[1] = m_clamp(v[1] + h * a1, -vmax, vmax);
+                    v[2] = m_clamp(v[2] + h * a2, -vmax, vmax);
+                    p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
+                    // exponential-map orientation update (btMultiBody::stepPositionsMultiDof)
+                    T ang = m_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                    if (ang * h > (T)0.78539816339744830962) ang = (T)0.78539816339744830962 / h;
+                    T kk;
+                    if (ang < (T)0.001) kk = (T)0.5 * h - (h * h * h) * (T)0.020833333333 * ang * ang;
+                    else kk = m_sin((T)0.5 * ang * h) / ang;
+                    const T dx = w[0] * kk, dy = w[1] * kk, dz = w[2] * kk, dw = m_cos((T)0.5 * ang * h);
+                    const T qx = dw * q[0] + dx * q[3] + dy * q[2] - dz * q[1];
+                    const T qy = dw * q[1] - dx * q[2] + dy * q[3] + dz * q[0];
+                    const T qz = dw * q[2] + dx * q[1] - dy * q[0] + dz * q[3];
+                    const T qw = dw * q[3] - dx * q[0] - dy * q[1] - dz * q[2];
+                    const T inv = (T)1 / m_sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+                    q[0] = qx * inv; q[1] = qy * inv; q[2] = qz * inv; q[3] = qw * inv;
+                }
+                e.s[0] = p[0]; e.s[1] = p[1]; e.s[2] = p[2];
+                e.s[3] = q[0]; e.s[4] = q[1]; e.s[5] = q[2]; e.s[6] = q[3];
+                e.s[7] = v[0]; e.s[8] = v[1]; e.s[9] = v[2];
+                e.s[10] = w[0]; e.s[11] = w[1]; e.s[12] = w[2];
+            }
+        }
+        state_vector(e, st);
+
+        // ---- reference row for reward / mse (tracking: X_GOAL[min(c+1, L-1)])
+        T ref[D::NX];
+        const bool tracking = P->task == SCG_TASK_TRAJ_TRACKING;
+        {
+            int row = 0;
+            if (tracking) { row = c0 + 1; const int last = P->goal_rows - 1; row = row > last ? last : row; }
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) ref[k] = goal_tab[row * D::NX + k];
+        }
+        // ---- _get_reward
+        T rew;
+        if (P->cost == SCG_COST_RL_REWARD) {
+            T dist = (T)0;
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) {
+                T sv = st[k];
+                if constexpr (SYS == SCG_CARTPOLE) { if (k == 2) sv = normalize_angle(sv); }   // cartpole.py:619-620
+                const T err = sv - ref[k];
+                dist += P->rew_state_weight[k] * err * err;
+            }
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) {
+                const T ae = noisy[j] - P->u_goal[j];      // unclipped noisy action (quadrotor.py:828); cartpole U_GOAL = 0
+                dist += P->rew_act_weight[j] * ae * ae;
+            }
+            rew = P->rew_exponential ? m_exp(-dist) : -dist;
+        } else {
+            // quadratic cost with diagonal Q, R (lqr_utils.py:77-99) and the CLIPPED action.
+            T xr[D::NX];
+            if (tracking) {
+                // quadrotor: X_GOAL[c+1] (quadrotor.py:858); cartpole: X_GOAL[c] (cartpole.py:648); no clamping upstream
+                int row = (SYS == SCG_CARTPOLE) ? c0 : c0 + 1;
+                const int last = P->goal_rows - 1; row = row > last ? last : row;
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) xr[k] = goal_tab[row * D::NX + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) xr[k] = ref[k];
+            }
+            T cst = (T)0;
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) { const T err = st[k] - xr[k]; cst += (T)0.5 * P->q_diag[k] * err * err; }
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) { const T du = clipped[j] - P->u_goal[j]; cst += (T)0.5 * P->r_diag[j] * du * du; }
+            rew = -cst;
+        }
+        // ---- _get_done
+        bool done = false;
+        uint8_t flags = 0;
+        bool goal = false;
+        if (!tracking) {
+            T n2 = (T)0;
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) { const T err = st[k] - ref[k]; n2 += err * err; }
+            goal = m_sqrt(n2) < P->goal_tolerance;
+            done = goal;
+            if (goal && P->info_goal_reached) flags |= FLAG_GOAL;
+        }
+        if (P->done_on_oob) {
+            bool oob = false;
+            if constexpr (SYS == SCG_CARTPOLE) {
+                oob = st[0] < -P->x_threshold || st[0] > P->x_threshold || st[2] < -P->theta_threshold || st[2] > P->theta_threshold;
+            } else {
+                // positions + angles only (quadrotor.py:878-888)
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) {
+                    const bool masked = (SYS == SCG_QUAD_3D) ? ((k < 6 && (k & 1) == 0) || (k >= 6 && k < 9)) : ((k & 1) == 0);
+                    if (masked) oob = oob || st[k] < P->state_low[k] || st[k] > P->state_high[k];
+                }
+            }
+            if (!tracking) {
+                // stale `self.out_of_bounds` on goal_reached steps (see oracle/envs.py::_stale_oob)
+                const bool prev = P->oob_attr[env_index] != 0;
+                oob = goal ? prev : oob;
+                P->oob_attr[env_index] = oob ? 1 : 0;
+            }
+            if (oob) flags |= FLAG_OOB;
+            done = done || (oob && !goal);
+        }
+        // ---- _get_info: mse
+        T mse = (T)0;
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) {
+            T sv = st[k];
+            if (tracking) {
+                if constexpr (SYS == SCG_CARTPOLE) { if (k == 2) sv = normalize_angle(sv); }
+                if constexpr (SYS == SCG_QUAD_2D) { if (k == 4) sv = normalize_angle(sv); }
+                if constexpr (SYS == SCG_QUAD_3D) { if (k >= 6 && k < 9) sv = normalize_angle(sv); }
+            }
+            const T err = (sv - ref[k]) * P->mse_weight[k];
+            mse += err * err;
+        }
+        // ---- after_step
+        e.step = c0 + 1;
+        bool viol = false;
+        if (P->n_con_rows > 0) {
+            viol = constraints(P, st, noisy, c_out, c_stride, false);
+            if (viol) {
+                flags |= FLAG_VIOLATION;
+                if (P->done_on_violation) {
+                    done = true;
+                    if (P->cost == SCG_COST_RL_REWARD && P->use_penalty) rew = (T)0;
+                }
+            }
+            if (P->cost == SCG_COST_RL_REWARD && P->use_penalty && viol) {
+                if (P->rew_exponential) rew = m_exp(m_log(rew) - P->constraint_penalty);
+                else rew -= P->constraint_penalty;
+            }
+        }
+        if (e.step >= P->ctrl_steps) {
+            if (!done) flags |= FLAG_TRUNCATED;
+            done = true;
+        }
+        StepResult r;
+        r.reward = rew; r.mse = mse; r.done = done; r.flags = flags;
+        return r;
+    }
+};
+
+}  // namespace scg

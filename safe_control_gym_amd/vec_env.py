@@ -1,0 +1,426 @@
+"""HipVecEnv: the vectorised-environment boundary, one HIP launch per control step.
+
+Mirrors the reference's VecEnv contract
+(/root/reference/safe_control_gym/envs/env_wrappers/vectorized_env/vec_env.py:13-142 and
+dummy_vec_env.py:12-119): ``reset() -> (obs[N,.], {'n': infos})``,
+``step_async / step_wait -> (obs, rews, dones, {'n': infos})`` with auto-reset,
+``terminal_observation`` / ``terminal_info``, ``get_attr / set_attr / env_method``,
+``get_env_random_state / set_env_random_state``, ``close``, ``num_envs``,
+``observation_space``, ``action_space``.
+
+Two ways to consume a step:
+* the reference API above (NumPy in / NumPy out, ``info['n']`` is a lazy per-env view that
+  only touches the host when somebody indexes it);
+* ``step_tensors(actions)`` — device tensors in, a ``StepTensors`` bundle of device tensors
+  out, no host synchronisation at all (used by the PPO/SAC collectors in this package).
+"""
+import ctypes as C
+from abc import ABC, abstractmethod
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+from safe_control_gym_amd import _lib as L
+from safe_control_gym_amd.env_config import EnvSpec
+
+
+class VecEnv(ABC):
+    """Same abstract surface as the reference's VecEnv (vec_env.py:13-142)."""
+    closed = False
+    viewer = None
+    metadata = {'render.modes': ['human', 'rgb_array']}
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_async(self, actions):
+        pass
+
+    @abstractmethod
+    def step_wait(self):
+        pass
+
+    def close_extras(self):
+        pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.close_extras()
+        self.closed = True
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @abstractmethod
+    def get_attr(self, attr_name, indices=None):
+        pass
+
+    @abstractmethod
+    def set_attr(self, attr_name, values, indices=None):
+        pass
+
+    @abstractmethod
+    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
+        pass
+
+    def _get_indices(self, indices):
+        if indices is None:
+            indices = range(self.num_envs)
+        elif isinstance(indices, int):
+            indices = [indices]
+        return indices
+
+
+class StepTensors:
+    """Device-resident outputs of one vectorised step (all torch tensors on the env's device)."""
+    __slots__ = ('obs', 'reward', 'done', 'flags', 'c_values', 'mse', 'terminal_obs', 'state', 'noisy_action',
+                 'fin_return', 'fin_length', 'fin_violation', 'fin_mse')
+
+    @property
+    def truncated(self):
+        return (self.flags & L.FLAG_TRUNCATED) != 0
+
+    @property
+    def constraint_violation(self):
+        return (self.flags & L.FLAG_VIOLATION) != 0
+
+    @property
+    def out_of_bounds(self):
+        return (self.flags & L.FLAG_OOB) != 0
+
+    @property
+    def goal_reached(self):
+        return (self.flags & L.FLAG_GOAL) != 0
+
+
+class LazyInfoList(Sequence):
+    """``info['n']``: behaves like the reference's tuple of per-env dicts
+    (dummy_vec_env.py:41) but copies the columnar device arrays to the host only on first access."""
+
+    def __init__(self, venv, out, is_reset):
+        self._venv, self._out, self._is_reset, self._host = venv, out, is_reset, None
+
+    def __len__(self):
+        return self._venv.num_envs
+
+    def _fetch(self):
+        if self._host is None:
+            o = self._out
+            h = {k: getattr(o, k).cpu().numpy() for k in ('flags', 'mse', 'done', 'terminal_obs', 'fin_return',
+                                                           'fin_length', 'fin_violation', 'fin_mse')}
+            h['c_values'] = o.c_values.t().cpu().numpy() if o.c_values is not None else None
+            self._host = h
+        return self._host
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        v, h = self._venv, self._fetch()
+        spec = v.spec
+        if self._is_reset:
+            return v._reset_info(h, i, with_constraints=True)
+        flags = int(h['flags'][i])
+        step = {'current_step': None, 'constraint_violation': int(bool(flags & L.FLAG_VIOLATION)),
+                'mse': float(h['mse'][i])}
+        if spec.num_constraints_or_zero:
+            step['constraint_values'] = h['c_values'][i].astype(np.float64)
+        if spec.done_on_out_of_bound:
+            step['out_of_bounds'] = bool(flags & L.FLAG_OOB)
+        if spec.TASK == 'stabilization' and spec.COST == 'quadratic':
+            step['goal_reached'] = bool(flags & L.FLAG_GOAL)
+        if h['done'][i]:
+            step['current_step'] = int(h['fin_length'][i])
+            if flags & L.FLAG_TRUNCATED or step['current_step'] >= spec.CTRL_STEPS:
+                step['TimeLimit.truncated'] = bool(flags & L.FLAG_TRUNCATED)
+            info = v._reset_info(h, i)
+            info['terminal_observation'] = h['terminal_obs'][i].astype(np.float64)
+            info['terminal_info'] = step
+            info['episode'] = {'r': float(h['fin_return'][i]), 'l': float(h['fin_length'][i]),
+                               'constraint_violation': float(h['fin_violation'][i]), 'mse': float(h['fin_mse'][i])}
+            return info
+        step.pop('current_step')
+        return step
+
+
+class HipVecEnv(VecEnv):
+    """N independent copies of one environment stepped by libscg_hip.so on one GPU."""
+
+    def __init__(self, env_id, num_envs, seed=0, device=None, dtype=torch.float32, env_id_offset=0,
+                 return_numpy=True, **task_config):
+        L.lib()                                        # fail loudly, before touching torch.cuda
+        if not torch.cuda.is_available():
+            raise L.ScgError('HipVecEnv needs a HIP device (torch.cuda.is_available() is False); '
+                             'there is no CPU fallback.')
+        task_config = dict(task_config)
+        cfg_seed = task_config.pop('seed', None)
+        if seed is None:
+            seed = 0 if cfg_seed is None else cfg_seed
+        self.spec = EnvSpec(env_id, task_config)
+        spec = self.spec
+        spec.num_constraints_or_zero = len(spec.con_rows)
+        self.env_id = env_id
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.dtype = dtype
+        self._cdtype = L.F64 if dtype == torch.float64 else L.F32
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError('dtype must be torch.float32 or torch.float64')
+        self.seed_value = int(seed)
+        self.env_id_offset = int(env_id_offset)
+        self.return_numpy = return_numpy
+        VecEnv.__init__(self, int(num_envs), spec.observation_space, spec.action_space)
+        self._lib = L.lib()
+        cfg, x_goal = spec.to_c_config(self.num_envs, self._cdtype, self.seed_value, self.env_id_offset)
+        self._cfg = cfg
+        nbytes = C.c_size_t(0)
+        L.check(self._lib.scg_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+            base = self.workspace.data_ptr()
+            self._ws_ptr = (base + 255) // 256 * 256
+            handle = C.c_void_p()
+            L.check(self._lib.scg_create(C.byref(cfg), x_goal.ctypes.data_as(C.POINTER(C.c_double)),
+                                         self.device.index or 0, C.c_void_p(self._ws_ptr), nbytes.value, C.byref(handle)))
+        self._h = handle
+        N, spec = self.num_envs, self.spec
+        f = dict(dtype=dtype, device=self.device)
+        o = StepTensors()
+        o.obs = torch.zeros(N, spec.obs_dim, **f)
+        o.reward = torch.zeros(N, **f)
+        o.done = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        o.flags = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        o.c_values = torch.zeros(len(spec.con_rows), N, **f) if spec.con_rows else None
+        o.mse = torch.zeros(N, **f)
+        o.terminal_obs = torch.zeros(N, spec.obs_dim, **f)
+        o.state = torch.zeros(spec.nx, N, **f)
+        o.noisy_action = torch.zeros(spec.nu, N, **f)
+        o.fin_return = torch.zeros(N, **f)
+        o.fin_length = torch.zeros(N, dtype=torch.int32, device=self.device)
+        o.fin_violation = torch.zeros(N, **f)
+        o.fin_mse = torch.zeros(N, **f)
+        self.out = o
+        self.ep_return = torch.zeros(N, **f)
+        self.ep_length = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self.ep_violation = torch.zeros(N, **f)
+        self.ep_mse = torch.zeros(N, **f)
+        self._c_out = self._make_c_out(o)
+        self._actions = None
+        self._adv = None
+        self.closed = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _make_c_out(self, o, obs=None):
+        s = L.StepOut()
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        s.d_obs = p(obs if obs is not None else o.obs)
+        s.d_reward, s.d_done, s.d_flags = p(o.reward), p(o.done), p(o.flags)
+        s.d_c_values, s.d_mse, s.d_terminal_obs = p(o.c_values), p(o.mse), p(o.terminal_obs)
+        s.d_state, s.d_noisy_action = p(o.state), p(o.noisy_action)
+        s.d_ep_return, s.d_ep_length = p(self.ep_return), p(self.ep_length)
+        s.d_ep_violation, s.d_ep_mse = p(self.ep_violation), p(self.ep_mse)
+        s.d_fin_return, s.d_fin_length = p(o.fin_return), p(o.fin_length)
+        s.d_fin_violation, s.d_fin_mse = p(o.fin_violation), p(o.fin_mse)
+        return s
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _as_device(self, a, cols):
+        t = torch.as_tensor(a, device=self.device).to(self.dtype)
+        t = t.reshape(self.num_envs, cols).contiguous()
+        return t
+
+    # ------------------------------------------------------------------ fast (tensor) API
+    def reset_tensors(self, mask=None):
+        """Reset all envs (mask None) or the envs whose mask byte is non-zero.  Returns obs [N, obs_dim]."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            L.check(self._lib.scg_reset(self._h, C.c_void_p(m.data_ptr()) if m is not None else None,
+                                        C.byref(self._c_out), self._stream()))
+        return self.out.obs
+
+    def step_tensors(self, actions, adv_actions=None, out=None, c_out=None):
+        """One control step for every env.  `actions` [N, action_dim] device tensor of the env dtype.
+        Pass a prepared (StepTensors, StepOut) pair to write into caller-owned buffers (rollout storage)."""
+        a = actions
+        if a.dtype != self.dtype or a.device != self.device or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=self.dtype).contiguous()
+        adv_ptr = None
+        if adv_actions is not None:
+            adv = adv_actions.to(device=self.device, dtype=self.dtype).contiguous()
+            adv_ptr = C.c_void_p(adv.data_ptr())
+        with torch.cuda.device(self.device):
+            L.check(self._lib.scg_step(self._h, C.c_void_p(a.data_ptr()), adv_ptr,
+                                       C.byref(c_out if c_out is not None else self._c_out), self._stream()))
+        return out if out is not None else self.out
+
+    def bind_outputs(self, **tensors):
+        """A (StepTensors, StepOut) pair whose listed fields point at caller-owned tensors (e.g. slices of a
+        rollout buffer) and whose other fields alias this env's default output buffers."""
+        o = StepTensors()
+        for k in StepTensors.__slots__:
+            setattr(o, k, tensors.get(k, getattr(self.out, k)))
+        return o, self._make_c_out(o)
+
+    def rollout_random(self, k_steps):
+        """K fused control steps with in-kernel U(-1,1) actions (scg_rollout_random).
+        Returns (reward_sum [N], done_count [N], violation_count [N], last_obs [N, obs_dim])."""
+        N = self.num_envs
+        if not hasattr(self, '_ro'):
+            self._ro = (torch.zeros(N, dtype=self.dtype, device=self.device),
+                        torch.zeros(N, dtype=torch.int32, device=self.device),
+                        torch.zeros(N, dtype=torch.int32, device=self.device),
+                        torch.zeros(N, self.spec.obs_dim, dtype=self.dtype, device=self.device))
+            r = L.RolloutOut()
+            r.d_reward_sum, r.d_done_count, r.d_violation_count, r.d_last_obs = (C.c_void_p(t.data_ptr()) for t in self._ro)
+            self._ro_c = r
+        with torch.cuda.device(self.device):
+            L.check(self._lib.scg_rollout_random(self._h, int(k_steps), C.byref(self._ro_c), self._stream()))
+        return self._ro
+
+    # ------------------------------------------------------------------ reference VecEnv API
+    def reset(self):
+        obs = self.reset_tensors()
+        info = {'n': LazyInfoList(self, self.out, is_reset=True)}
+        return (obs.cpu().numpy().astype(np.float64) if self.return_numpy else obs), info
+
+    def step_async(self, actions):
+        self._actions = actions if torch.is_tensor(actions) else self._as_device(np.asarray(actions), self.spec.nu)
+
+    def set_adversary_control(self, actions):
+        """Batched BenchmarkEnv.set_adversary_control (benchmark_env.py:216-228)."""
+        spec = self.spec
+        if spec.adversary_disturbance is None:
+            raise RuntimeError('[ERROR] adversary_disturbance does not exist, env.set_adversary_control() cannot be called.')
+        a = self._as_device(actions, spec.adversary_dim) if not torch.is_tensor(actions) else actions.to(self.device, self.dtype)
+        a = a.clamp(-1.0, 1.0)
+        self._adv = a * spec.kw['adversary_disturbance_scale'] + spec.kw['adversary_disturbance_offset']
+
+    def step_wait(self):
+        out = self.step_tensors(self._actions, self._adv)
+        self._adv = None
+        info = {'n': LazyInfoList(self, out, is_reset=False)}
+        if self.return_numpy:
+            return (out.obs.cpu().numpy().astype(np.float64), out.reward.cpu().numpy().astype(np.float64),
+                    out.done.cpu().numpy().astype(bool), info)
+        return out.obs, out.reward, out.done.bool(), info
+
+    def _reset_info(self, host, i, with_constraints=False):
+        spec = self.spec
+        info = {'current_step': 0, 'x_reference': spec.X_GOAL, 'u_reference': spec.U_GOAL,
+                'physical_parameters': self.physical_parameters(i)}
+        if with_constraints and spec.n_state_con_rows and host.get('c_values') is not None:
+            # after_reset: state constraints only (benchmark_env.py:356-357)
+            info['constraint_values'] = host['c_values'][i][:spec.n_state_con_rows].astype(np.float64)
+        return info
+
+    def physical_parameters(self, i):
+        p = self.get_params(i, 1)[0]
+        if self.spec.name == 'cartpole':
+            return {'pole_effective_length': p[0], 'cart_mass': p[1], 'pole_mass': p[2]}
+        return {'quadrotor_mass': p[0], 'quadrotor_inertia': [p[1], p[2], p[3]]}
+
+    # ------------------------------------------------------------------ host accessors
+    def _host_io(self, fn, width, first, n, data=None):
+        buf = np.zeros((n, width), dtype=np.float64) if data is None else np.ascontiguousarray(data, dtype=np.float64).reshape(n, width)
+        with torch.cuda.device(self.device):
+            L.check(fn(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), int(first), int(n), self._stream()))
+        return buf
+
+    def get_raw_state(self, first=0, n=None):
+        n = self.num_envs - first if n is None else n
+        return self._host_io(self._lib.scg_get_state, self._n_state_arrays(), first, n)
+
+    def set_raw_state(self, states, first=0):
+        states = np.asarray(states, dtype=np.float64)
+        self._host_io(self._lib.scg_set_state, self._n_state_arrays(), first, states.shape[0], states)
+
+    def get_params(self, first=0, n=None):
+        n = self.num_envs - first if n is None else n
+        return self._host_io(self._lib.scg_get_params, len(self.spec.param_labels), first, n)
+
+    def set_params(self, params, first=0):
+        params = np.asarray(params, dtype=np.float64)
+        self._host_io(self._lib.scg_set_params, len(self.spec.param_labels), first, params.shape[0], params)
+
+    def get_counters(self):
+        step = np.zeros(self.num_envs, dtype=np.int32)
+        ep = np.zeros(self.num_envs, dtype=np.uint32)
+        with torch.cuda.device(self.device):
+            L.check(self._lib.scg_get_counters(self._h, step.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               ep.ctypes.data_as(C.POINTER(C.c_uint32)), 0, self.num_envs, self._stream()))
+        return step, ep
+
+    def set_counters(self, step=None, episode=None):
+        sp = None if step is None else np.ascontiguousarray(step, dtype=np.int32)
+        ep = None if episode is None else np.ascontiguousarray(episode, dtype=np.uint32)
+        with torch.cuda.device(self.device):
+            L.check(self._lib.scg_set_counters(
+                self._h, sp.ctypes.data_as(C.POINTER(C.c_int32)) if sp is not None else None,
+                ep.ctypes.data_as(C.POINTER(C.c_uint32)) if ep is not None else None, 0, self.num_envs, self._stream()))
+
+    def _n_state_arrays(self):
+        return {L.CARTPOLE: 4, L.QUAD_1D: 2, L.QUAD_2D: 6, L.QUAD_3D: 13}[self.spec.system]
+
+    # RNG state = Philox key + per-env (episode, step) counters + the workspace (disturbance offsets);
+    # round-trips through checkpoints like dummy_vec_env.py:68-74.
+    def get_env_random_state(self):
+        step, ep = self.get_counters()
+        return [{'seed': self.seed_value, 'env_id_offset': self.env_id_offset, 'step': step, 'episode': ep,
+                 'workspace': self.workspace.cpu()}]
+
+    def set_env_random_state(self, worker_random_states):
+        st = worker_random_states[0]
+        if st['seed'] != self.seed_value or st['env_id_offset'] != self.env_id_offset:
+            raise ValueError('random state belongs to a different seed / env shard')
+        self.workspace.copy_(st['workspace'].to(self.device))
+
+    # ------------------------------------------------------------------ attribute access
+    def get_attr(self, attr_name, indices=None):
+        idx = list(self._get_indices(indices))
+        if attr_name == 'state':
+            return list(self.out.state.t()[idx].cpu().numpy().astype(np.float64))
+        val = getattr(self.spec, attr_name) if hasattr(self.spec, attr_name) else getattr(self, attr_name)
+        return [val for _ in idx]
+
+    def set_attr(self, attr_name, values, indices=None):
+        raise NotImplementedError('per-env attribute mutation is not supported: all envs of a HipVecEnv share one config')
+
+    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
+        idx = list(self._get_indices(indices))
+        if method_name == 'set_adversary_control':
+            if len(idx) != self.num_envs:
+                raise NotImplementedError('set_adversary_control must address every env')
+            self.set_adversary_control(np.stack([a[0] for a in method_args]))
+            return [None] * len(idx)
+        raise NotImplementedError(f'env_method({method_name!r})')
+
+    def close_extras(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.scg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                               # noqa: BLE001
+            pass

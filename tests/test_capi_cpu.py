@@ -1,0 +1,124 @@
+"""CPU-only checks of the C-ABI library and the host-side config compiler (no kernel launches)."""
+import ctypes as C
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from safe_control_gym_amd import _lib as L
+    L.build()
+    return L.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'scg_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(scg_[a-z_0-9]+)\s*\(', hdr))
+    assert {'scg_create', 'scg_step', 'scg_reset', 'scg_gae', 'scg_rollout_random'} <= names
+    for n in names:
+        assert hasattr(lib, n), f'libscg_hip.so does not export {n}'
+
+
+def test_struct_layouts_agree(lib):
+    from safe_control_gym_amd import _lib as L
+    assert lib.scg_sizeof_config() == C.sizeof(L.Config)
+    assert lib.scg_sizeof_step_out() == C.sizeof(L.StepOut)
+    assert lib.scg_abi_version() == L.SCG_ABI_VERSION
+
+
+def _cases():
+    for p in sorted(glob.glob(os.path.join(GOLDEN, 'rollout_*.npz'))):
+        yield os.path.basename(p)[len('rollout_'):-4]
+
+
+@pytest.mark.parametrize('name', list(_cases()))
+def test_env_spec_matches_reference_fixtures(lib, name):
+    """Host-side derived quantities (X_GOAL, U_GOAL, spaces, action bounds, #constraints) equal the values
+    recorded from the reference's env objects."""
+    from safe_control_gym_amd import _lib as L
+    from safe_control_gym_amd.env_config import EnvSpec
+    g = np.load(os.path.join(GOLDEN, f'rollout_{name}.npz'))
+    meta = json.loads(str(g['meta_json']))
+    cfg = dict(meta['config'])
+    cfg.pop('seed', None)
+    spec = EnvSpec(meta['task'], cfg)
+    np.testing.assert_allclose(np.atleast_2d(spec.X_GOAL), np.atleast_2d(g['x_goal']), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(spec.U_GOAL, g['u_goal'], rtol=1e-15)
+    np.testing.assert_array_equal(spec.state_space.low, g['state_space_low'])
+    np.testing.assert_array_equal(spec.state_space.high, g['state_space_high'])
+    np.testing.assert_array_equal(spec.observation_space.low, g['observation_space_low'])
+    np.testing.assert_array_equal(spec.action_space.low, g['action_space_low'])
+    np.testing.assert_array_equal(spec.action_space.high, g['action_space_high'])
+    np.testing.assert_allclose(np.asarray(spec.physical_action_bounds[0], dtype=float), g['physical_action_low'], rtol=0)
+    assert len(spec.con_rows) == g['c_values'].shape[-1]
+    assert spec.obs_dim == g['obs'].shape[-1]
+    c, xg = spec.to_c_config(64, L.F32, 1)
+    dims = [C.c_int32() for _ in range(5)]
+    assert lib.scg_dims(C.byref(c), *[C.byref(d) for d in dims]) == 0
+    assert dims[0].value == spec.nx and dims[1].value == spec.nu and dims[2].value == spec.obs_dim
+    nb = C.c_size_t(0)
+    assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == 0 and nb.value > 0
+
+
+def test_invalid_config_is_reported_not_aborted(lib):
+    from safe_control_gym_amd import _lib as L
+    from safe_control_gym_amd.env_config import EnvSpec
+    spec = EnvSpec('cartpole', {})
+    c, _ = spec.to_c_config(8, L.F32, 0)
+    nb = C.c_size_t(0)
+    c.num_envs = 0
+    assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == -1
+    assert b'num_envs' in lib.scg_last_error()
+    c.num_envs = 8
+    c.abi_version = 99
+    assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == -1
+    assert b'abi_version' in lib.scg_last_error()
+    c.abi_version = L.SCG_ABI_VERSION
+    c.integrator = L.INT_RK4
+    assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == -1
+    assert lib.scg_step(None, None, None, None, None) == -1
+    assert lib.scg_gae(L.F32, None, None, None, None, None, None, None, 4, 4, 0.99, 0.95, 1, None) == -1
+
+
+def test_env_spec_error_behaviour_mirrors_reference():
+    from safe_control_gym_amd.env_config import EnvSpec
+    with pytest.raises(ValueError):      # benchmark_env.py:141-142
+        EnvSpec('cartpole', {'ctrl_freq': 15, 'pyb_freq': 100})
+    with pytest.raises(ValueError):      # quadrotor.py:200-201
+        EnvSpec('quadrotor', {'info_mse_metric_state_weight': [1, 2]})
+    with pytest.raises(ValueError):      # disturbances.py:211
+        EnvSpec('cartpole', {'disturbances': {'action': [{'disturbance_func': 'white_noise', 'std': 1}]}})
+    with pytest.raises(AssertionError):  # constraints.py:661
+        EnvSpec('quadrotor', {'constraints': [{'constraint_form': 'abs_bound', 'constrained_variable': 'state', 'bound': 1.0}]})
+    # quadrotor ignores the YAML randomisation tables (quadrotor.py:208,233) unless the extension is on
+    info = {'init_x': {'distrib': 'uniform', 'low': -2, 'high': 2}}
+    assert EnvSpec('quadrotor', {'init_state_randomization_info': info}).init_rand_info['init_x']['low'] == -0.5
+    assert EnvSpec('quadrotor', {'init_state_randomization_info': info,
+                                 'respect_randomization_info': True}).init_rand_info['init_x']['low'] == -2
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under safe_control_gym_amd/ may reference it."""
+    for p in glob.glob(os.path.join(ROOT, 'safe_control_gym_amd', '**', '*'), recursive=True):
+        if os.path.isfile(p) and p.endswith(('.py', '.h', '.hip', '.cpp')):
+            src = open(p, errors='ignore').read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), p
+
+
+def test_hip_vec_env_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from safe_control_gym_amd import _lib as L
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    with pytest.raises(L.ScgError):
+        HipVecEnv('cartpole', 4)
