@@ -130,7 +130,8 @@ typedef struct {
     int32_t obs_wrap_angle;     /* cartpole.py:598-599 */
     int32_t normalized_action;  /* normalized_rl_action_space */
     int32_t info_goal_reached;  /* stabilisation + quadratic cost: expose goal_reached */
-    int32_t pad0;
+    int32_t auto_reset;         /* 1: DummyVecEnv semantics (reset inside the step where done);
+                                   0: single-env semantics, the caller resets (BenchmarkEnv.step) */
     double goal_tolerance;      /* TASK_INFO['stabilization_goal_tolerance'] */
     double constraint_penalty;
     double rew_state_weight[SCG_MAX_STATE];

@@ -31,9 +31,10 @@ from oracle.rng import (CH_ACTION, CH_DYNAMICS, CH_OBSERVATION, CH_RESET, NumpyE
 from oracle.trajectory import generate_trajectory, transform_trajectory
 
 CHANNEL_OF_MODE = {'action': CH_ACTION, 'dynamics': CH_DYNAMICS, 'observation': CH_OBSERVATION}
-# Philox reset-draw item slots (must match scg_rng.h): init-state var j -> j (0..11),
-# inertial property p -> 12 + p (12..15), disturbance offset (channel ch, index k) -> 16 + 8*(ch-1) + k.
-ITEM_INIT0, ITEM_INERTIAL0, ITEM_DISTURB0 = 0, 12, 16
+# Philox reset-draw groups (must match scg_rng.h): item = group; variable j of the group uses block
+# j // 2 and the word pair (2*(j%2), 2*(j%2)+1).  j = INIT_STATE_LABELS index | inertial parameter index |
+# 4 * (channel - 1) + list index for disturbance offsets.
+GROUP_INIT, GROUP_INERTIAL, GROUP_DISTURB = 0, 1, 2
 
 
 def normalize_angle(x):
@@ -63,28 +64,30 @@ class Draws:
     def reset_integer(self, idx, channel, k, bound):
         if self.rng.kind == 'numpy':
             return np.array([self.rng.gens[i].integers(bound) for i in idx], dtype=np.int64)
-        tag = make_tag(CH_RESET, ITEM_DISTURB0 + 8 * (channel - 1) + k, 0)
-        return self.rng.integer_below(idx, self.env.episode, 0, tag, bound)
+        j = 4 * (channel - 1) + k
+        tag = make_tag(CH_RESET, GROUP_DISTURB, j // 2)
+        return self.rng.integer_below(idx, self.env.episode, 0, tag, bound, word=2 * (j % 2))
 
-    def reset_scalar(self, idx, item, spec):
-        """One draw per env in ``idx`` from a {distrib, args, **kwargs} spec."""
+    def reset_scalar(self, idx, group, j, spec):
+        """One draw per env in ``idx`` from a {distrib, args, **kwargs} spec (variable j of ``group``)."""
         spec = copy.deepcopy(spec)
         distrib = spec.pop('distrib')
         d_args = spec.pop('args', [])
         if self.rng.kind == 'numpy':
             return np.array([getattr(self.rng.gens[i], distrib)(*d_args, **spec) for i in idx], dtype=np.float64)
-        tag = make_tag(CH_RESET, item, 0)
+        tag = make_tag(CH_RESET, group, j // 2)
+        w0 = 2 * (j % 2)
         if distrib == 'uniform':
             low = d_args[0] if len(d_args) > 0 else spec.get('low', 0.0)
             high = d_args[1] if len(d_args) > 1 else spec.get('high', 1.0)
-            return low + (high - low) * self.rng.uniform01(idx, self.env.episode, 0, tag)
+            return low + (high - low) * self.rng.uniform01(idx, self.env.episode, 0, tag, word=w0)
         if distrib == 'normal':
             loc = d_args[0] if len(d_args) > 0 else spec.get('loc', 0.0)
             scale = d_args[1] if len(d_args) > 1 else spec.get('scale', 1.0)
-            return loc + scale * self.rng.normal01(idx, self.env.episode, 0, tag)
+            return loc + scale * self.rng.normal01_words(idx, self.env.episode, 0, tag, w0, w0 + 1)
         if distrib == 'choice':
             opts = np.asarray(d_args[0] if len(d_args) > 0 else spec['a'], dtype=np.float64)
-            return opts[self.rng.integer_below(idx, self.env.episode, 0, tag, len(opts))]
+            return opts[self.rng.integer_below(idx, self.env.episode, 0, tag, len(opts), word=w0)]
         raise NotImplementedError(f'oracle/philox: distribution {distrib}')
 
     # ---- per-step vector draws (disturbances.py:188,219,253) ----
@@ -209,12 +212,12 @@ class OracleBenchmarkEnv:
         self.adv_action = clipped * self.adversary_disturbance_scale + self.adversary_disturbance_offset
 
     # benchmark_env.py:237-268 — additive randomisation, keys in ``original_values`` order.
-    def _randomize_values_by_info(self, idx, names, base_values, info, item0):
+    def _randomize_values_by_info(self, idx, names, base_values, info, group):
         out = {}
         for j, name in enumerate(names):
             val = np.full(len(idx), float(base_values[name]))
             if name in info:
-                val = val + self.draws.reset_scalar(idx, item0 + j, info[name])
+                val = val + self.draws.reset_scalar(idx, group, j, info[name])
             out[name] = val
         return out
 
@@ -504,7 +507,7 @@ class OracleQuadrotor(OracleBenchmarkEnv):
         base = {'M': self.MASS, 'Ixx': self.J[0], 'Iyy': self.J[1], 'Izz': self.J[2]}
         if self.RANDOMIZED_INERTIAL_PROP:
             prop = self._randomize_values_by_info(idx, self.INERTIAL_NAMES, base,
-                                                  self.INERTIAL_PROP_RAND_INFO, ITEM_INERTIAL0)
+                                                  self.INERTIAL_PROP_RAND_INFO, GROUP_INERTIAL)
             if any(np.any(v < 0) for v in prop.values()):
                 raise ValueError('[ERROR] in Quadrotor.reset(), negative randomized inertial properties.')
         else:
@@ -514,7 +517,7 @@ class OracleQuadrotor(OracleBenchmarkEnv):
         labels = self.INIT_STATE_LABELS[self.QUAD_TYPE]
         if self.RANDOMIZED_INIT:
             iv = self._randomize_values_by_info(idx, labels, self.init_values,
-                                                self.INIT_STATE_RAND_INFO, ITEM_INIT0)
+                                                self.INIT_STATE_RAND_INFO, GROUP_INIT)
         else:
             iv = {k: np.full(len(idx), float(self.init_values[k])) for k in labels}
         zero = np.zeros(len(idx))
@@ -849,7 +852,7 @@ class OracleCartPole(OracleBenchmarkEnv):
         base = {'pole_length': self.EFFECTIVE_POLE_LENGTH, 'cart_mass': self.CART_MASS, 'pole_mass': self.POLE_MASS}
         if self.RANDOMIZED_INERTIAL_PROP:
             prop = self._randomize_values_by_info(idx, self.INERTIAL_NAMES, base,
-                                                  self.INERTIAL_PROP_RAND_INFO, ITEM_INERTIAL0)
+                                                  self.INERTIAL_PROP_RAND_INFO, GROUP_INERTIAL)
             if any(np.any(v < 0) for v in prop.values()):
                 raise ValueError('[ERROR] in CartPole.reset(), negative randomized inertial properties.')
         else:
@@ -859,7 +862,7 @@ class OracleCartPole(OracleBenchmarkEnv):
         self.pole_mass_env[idx] = prop['pole_mass']
         if self.RANDOMIZED_INIT:
             iv = self._randomize_values_by_info(idx, self.INIT_NAMES, self.init_values,
-                                                self.INIT_STATE_RAND_INFO, ITEM_INIT0)
+                                                self.INIT_STATE_RAND_INFO, GROUP_INIT)
         else:
             iv = {k: np.full(len(idx), float(self.init_values[k])) for k in self.INIT_NAMES}
         self.state[idx] = np.stack([iv[k] for k in self.INIT_NAMES], axis=1)

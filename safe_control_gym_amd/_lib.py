@@ -56,7 +56,7 @@ class Config(C.Structure):
         ('task', c_i32), ('cost', c_i32), ('obs_goal_horizon', c_i32), ('goal_rows', c_i32),
         ('rew_exponential', c_i32), ('done_on_out_of_bound', c_i32), ('done_on_violation', c_i32),
         ('use_constraint_penalty', c_i32), ('obs_wrap_angle', c_i32), ('normalized_action', c_i32),
-        ('info_goal_reached', c_i32), ('pad0', c_i32),
+        ('info_goal_reached', c_i32), ('auto_reset', c_i32),
         ('goal_tolerance', c_f64), ('constraint_penalty', c_f64),
         ('rew_state_weight', c_f64 * MAX_STATE), ('rew_act_weight', c_f64 * MAX_ACTION),
         ('q_diag', c_f64 * MAX_STATE), ('r_diag', c_f64 * MAX_ACTION),

@@ -14,6 +14,17 @@
 //                                       quadrotor.py:328-392, cartpole.py:266-352, benchmark_env.py:237-268,320-359
 // Written from the semantics (see oracle/ for the float64 CPU restatement they are tested against),
 // not translated: state is SoA in HBM, everything between load and store lives in registers.
+//
+// Performance notes (gfx950).  At the headline size (65 536 envs = 1024 waves on 1024 SIMDs) every SIMD
+// holds ONE wave, so a launch lasts as long as one wave's dependent instruction chain: the code below is
+// written to keep that chain short —
+//   * the engine substeps never call sin/cos: rpm are constant within a control step, so the attitude
+//     advances by small angles d = h*w (|d| <= h*100 by Bullet's velocity clamp) and (sin,cos) / the
+//     quaternion are rotated with short Taylor polynomials (error < 1 ulp, guarded by `small_angle`);
+//   * reciprocals of mass / inertia are hoisted out of the substep loop, clamps are v_med3;
+//   * disturbance code (Philox + Box-Muller per channel) is compiled out of the DIST=false kernels,
+//     which every shipped RL config uses; box constraints are evaluated per variable with static
+//     register indices; Philox draws at reset serve two variables per call.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -31,6 +42,8 @@ __device__ __forceinline__ void m_sincos(float x, float* s, float* c) { sincosf(
 __device__ __forceinline__ void m_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_rsqrt(float x) { return rsqrtf(x); }
+__device__ __forceinline__ double m_rsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float m_exp(float x) { return expf(x); }
 __device__ __forceinline__ double m_exp(double x) { return exp(x); }
 __device__ __forceinline__ float m_log(float x) { return logf(x); }
@@ -47,7 +60,8 @@ __device__ __forceinline__ float m_rint(float x) { return rintf(x); }
 __device__ __forceinline__ double m_rint(double x) { return rint(x); }
 __device__ __forceinline__ float m_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double m_floor(double x) { return floor(x); }
-template <typename T> __device__ __forceinline__ T m_clamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ float m_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double m_clamp(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 template <typename T> __device__ __forceinline__ T m_max(T a, T b) { return a > b ? a : b; }
 
 template <typename T> struct Const {
@@ -62,6 +76,30 @@ __device__ __forceinline__ T normalize_angle(T x) {
     T y = x + Const<T>::PI;
     y = y - Const<T>::TWO_PI * m_floor(y / Const<T>::TWO_PI);
     return y - Const<T>::PI;
+}
+
+// sin(d), cos(d) for |d| <= 0.125 (Taylor; truncation < 3e-18 in double, < 2e-10 in float).
+template <typename T>
+__device__ __forceinline__ void small_sincos(T d, T& sd, T& cd) {
+    const T d2 = d * d;
+    if constexpr (sizeof(T) == 8) {
+        sd = d * ((T)1 + d2 * ((T)(-1.0 / 6) + d2 * ((T)(1.0 / 120) + d2 * ((T)(-1.0 / 5040) + d2 * (T)(1.0 / 362880)))));
+        cd = (T)1 + d2 * ((T)-0.5 + d2 * ((T)(1.0 / 24) + d2 * ((T)(-1.0 / 720) + d2 * ((T)(1.0 / 40320) + d2 * (T)(-1.0 / 3628800)))));
+    } else {
+        sd = d * ((T)1 + d2 * ((T)(-1.0 / 6) + d2 * (T)(1.0 / 120)));
+        cd = (T)1 + d2 * ((T)-0.5 + d2 * ((T)(1.0 / 24) + d2 * (T)(-1.0 / 720)));
+    }
+}
+// sinc(a) = sin(a)/a and cos(a) from a2 = a*a, a <= 0.125.
+template <typename T>
+__device__ __forceinline__ void small_sinc_cos(T a2, T& sinc, T& ca) {
+    if constexpr (sizeof(T) == 8) {
+        sinc = (T)1 + a2 * ((T)(-1.0 / 6) + a2 * ((T)(1.0 / 120) + a2 * ((T)(-1.0 / 5040) + a2 * (T)(1.0 / 362880))));
+        ca = (T)1 + a2 * ((T)-0.5 + a2 * ((T)(1.0 / 24) + a2 * ((T)(-1.0 / 720) + a2 * ((T)(1.0 / 40320) + a2 * (T)(-1.0 / 3628800)))));
+    } else {
+        sinc = (T)1 + a2 * ((T)(-1.0 / 6) + a2 * (T)(1.0 / 120));
+        ca = (T)1 + a2 * ((T)-0.5 + a2 * ((T)(1.0 / 24) + a2 * (T)(-1.0 / 720)));
+    }
 }
 
 // ------------------------------------------------------------------ per-system dimensions
@@ -92,28 +130,30 @@ struct Env {
 };
 
 // ------------------------------------------------------------------ random helpers
+// Reset-time draws: variable j of group g uses Philox block j/2 of item g, words 2*(j&1) and 2*(j&1)+1.
 template <typename T>
-__device__ __forceinline__ T draw_rand(const DevRand<T>& r, RngKey key, uint32_t gid, uint32_t episode, uint32_t item) {
-    if (r.kind == SCG_RAND_NONE) return (T)0;
-    U4 w = rng_words(key, gid, episode, 0u, rng_tag(RNG_CH_RESET, item, 0));
-    if (r.kind == SCG_RAND_UNIFORM) return r.p0 + (r.p1 - r.p0) * u01<T>(w.x);
+__device__ __forceinline__ T rand_value(const DevRand<T>& r, uint32_t w0, uint32_t w1) {
+    if (r.kind == SCG_RAND_UNIFORM) return r.p0 + (r.p1 - r.p0) * u01<T>(w0);
     if (r.kind == SCG_RAND_NORMAL) {
-        T u1 = u01<T>(w.x), u2 = u01<T>(w.y);
+        const T u1 = u01<T>(w0), u2 = u01<T>(w1);
         return r.p0 + r.p1 * (m_sqrt((T)-2 * m_log(u1)) * m_cos(Const<T>::TWO_PI * u2));
     }
-    uint32_t k = int_below(w.x, (uint32_t)r.n_choice);
-    T v = r.choices[0];
+    if (r.kind == SCG_RAND_CHOICE) {
+        const uint32_t k = int_below(w0, (uint32_t)r.n_choice);
+        T v = r.choices[0];
 #pragma unroll
-    for (int c = 1; c < SCG_MAX_CHOICE; ++c) v = (k == (uint32_t)c) ? r.choices[c] : v;
-    return v;
+        for (int c = 1; c < SCG_MAX_CHOICE; ++c) v = (k == (uint32_t)c) ? r.choices[c] : v;
+        return v;
+    }
+    return (T)0;
 }
 
 // DisturbanceList.apply (disturbances.py:54-62) for one channel; `vec` has `dim` entries.
 // rng_step: Philox step index (pre-increment counter for action/dynamics; observation index for obs).
 template <typename T, int MAXDIM>
-__device__ __forceinline__ void apply_disturbances(const DevParams<T>* __restrict__ P, int ch, T* vec, int dim,
-                                                   RngKey key, uint32_t gid, uint32_t episode, uint32_t rng_step,
-                                                   int32_t ctrl_step, int env_index) {
+__device__ __noinline__ void apply_disturbances(const DevParams<T>* __restrict__ P, int ch, T* vec, int dim,
+                                                RngKey key, uint32_t gid, uint32_t episode, uint32_t rng_step,
+                                                int32_t ctrl_step, int env_index) {
     const int n = P->n_dist[ch];
     for (int k = 0; k < n; ++k) {
         const DevDist<T>& d = P->dist[ch][k];
@@ -130,35 +170,28 @@ __device__ __forceinline__ void apply_disturbances(const DevParams<T>* __restric
                     gain = ((T)po < d.half_duration) ? m_pow(d.decay_rate, (T)po) : (T)0;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < MAXDIM; ++j) if (j < dim) vec[j] += d.a[j] * gain;
+            for (int j = 0; j < dim; ++j) vec[j] += d.a[j] * gain;
         } else if (d.kind == SCG_DIST_UNIFORM || d.kind == SCG_DIST_PERIODIC) {
             U4 w{0, 0, 0, 0};
             T tphase = (T)0;
             if (d.kind == SCG_DIST_PERIODIC) tphase = d.two_pi_freq * ((T)(ctrl_step * P->substeps) * P->pyb_dt);
-#pragma unroll
-            for (int j = 0; j < MAXDIM; ++j) {
-                if (j < dim) {
-                    if ((j & 3) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 2)));
-                    T u = u01<T>(u4_get(w, j & 3));
-                    if (d.kind == SCG_DIST_UNIFORM) {
-                        vec[j] += (d.a[j] + (d.b[j] - d.a[j]) * u) * d.mask[j];
-                    } else {
-                        T phase = -Const<T>::PI + Const<T>::TWO_PI * u;
-                        vec[j] += d.a[j] * m_sin(tphase + phase);
-                    }
+            for (int j = 0; j < dim; ++j) {
+                if ((j & 3) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 2)));
+                const T u = u01<T>(u4_get(w, j & 3));
+                if (d.kind == SCG_DIST_UNIFORM) {
+                    vec[j] += (d.a[j] + (d.b[j] - d.a[j]) * u) * d.mask[j];
+                } else {
+                    const T phase = -Const<T>::PI + Const<T>::TWO_PI * u;
+                    vec[j] += d.a[j] * m_sin(tphase + phase);
                 }
             }
         } else if (d.kind == SCG_DIST_WHITE) {
             U4 w{0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < MAXDIM; ++j) {
-                if (j < dim) {
-                    if ((j & 1) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 1)));
-                    T u1 = u01<T>((j & 1) ? w.z : w.x), u2 = u01<T>((j & 1) ? w.w : w.y);
-                    T z = m_sqrt((T)-2 * m_log(u1)) * m_cos(Const<T>::TWO_PI * u2);
-                    vec[j] += d.a[j] * z * d.mask[j];
-                }
+            for (int j = 0; j < dim; ++j) {
+                if ((j & 1) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 1)));
+                const T u1 = u01<T>((j & 1) ? w.z : w.x), u2 = u01<T>((j & 1) ? w.w : w.y);
+                const T z = m_sqrt((T)-2 * m_log(u1)) * m_cos(Const<T>::TWO_PI * u2);
+                vec[j] += d.a[j] * z * d.mask[j];
             }
         }
     }
@@ -220,7 +253,8 @@ __device__ __forceinline__ T planar_pitch(T th) {
 }
 
 // ------------------------------------------------------------------ the environment
-template <int SYS, typename T>
+// DIST: any passive disturbance or adversary configured (host-selected kernel variant).
+template <int SYS, typename T, bool DIST>
 struct EnvOps {
     using D = Dims<SYS>;
     using E = Env<SYS, T>;
@@ -282,27 +316,38 @@ struct EnvOps {
     __device__ static __forceinline__ void reset(const DevParams<T>* __restrict__ P, int i, E& e, RngKey key) {
         e.episode += 1u;
         e.step = 0;
-        // disturbance offsets (ImpulseDisturbance.reset / StepDisturbance.reset)
-        for (int ch = 0; ch < 3; ++ch) {
-            for (int k = 0; k < P->n_dist[ch]; ++k) {
-                const DevDist<T>& d = P->dist[ch][k];
-                if (d.offset_slot >= 0) {
-                    U4 w = rng_words(key, e.gid, e.episode, 0u,
-                                     rng_tag(RNG_CH_RESET, RNG_ITEM_DISTURB0 + 8u * (uint32_t)ch + (uint32_t)k, 0));
-                    P->dist_offset[(size_t)d.offset_slot * P->num_envs + i] = (int32_t)int_below(w.x, (uint32_t)d.max_step);
+        if constexpr (DIST) {
+            // disturbance offsets (ImpulseDisturbance.reset / StepDisturbance.reset), variable index 4*ch + k
+            for (int ch = 0; ch < 3; ++ch) {
+                for (int k = 0; k < P->n_dist[ch]; ++k) {
+                    const DevDist<T>& d = P->dist[ch][k];
+                    if (d.offset_slot >= 0) {
+                        const int j = 4 * ch + k;
+                        U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_DISTURB, (uint32_t)(j >> 1)));
+                        P->dist_offset[(size_t)d.offset_slot * P->num_envs + i] =
+                            (int32_t)int_below((j & 1) ? w.z : w.x, (uint32_t)d.max_step);
+                    }
                 }
             }
         }
         if (P->per_env_params) {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k)
-                e.par[k] = P->base_param[k] + draw_rand(P->param_rand[k], key, e.gid, e.episode, RNG_ITEM_PARAM0 + (uint32_t)k);
+            for (int b = 0; b < (D::NP + 1) / 2; ++b) {
+                U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_PARAM, (uint32_t)b));
+                e.par[2 * b] = P->base_param[2 * b] + rand_value(P->param_rand[2 * b], w.x, w.y);
+                if (2 * b + 1 < D::NP) e.par[2 * b + 1] = P->base_param[2 * b + 1] + rand_value(P->param_rand[2 * b + 1], w.z, w.w);
+            }
         }
         T iv[D::NX];
 #pragma unroll
-        for (int k = 0; k < D::NX; ++k) {
-            iv[k] = P->init_state[k];
-            if (P->randomized_init) iv[k] += draw_rand(P->init_rand[k], key, e.gid, e.episode, RNG_ITEM_INIT0 + (uint32_t)k);
+        for (int k = 0; k < D::NX; ++k) iv[k] = P->init_state[k];
+        if (P->randomized_init) {
+#pragma unroll
+            for (int b = 0; b < D::NX / 2; ++b) {
+                U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));
+                iv[2 * b] += rand_value(P->init_rand[2 * b], w.x, w.y);
+                iv[2 * b + 1] += rand_value(P->init_rand[2 * b + 1], w.z, w.w);
+            }
         }
         if constexpr (SYS == SCG_CARTPOLE || SYS == SCG_QUAD_2D) {
 #pragma unroll
@@ -332,8 +377,10 @@ struct EnvOps {
         T o[D::NX];
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) o[k] = st[k];
-        if (P->n_dist[SCG_CH_OBSERVATION] > 0)
-            apply_disturbances<T, D::NX>(P, SCG_CH_OBSERVATION, o, D::NX, key, e.gid, e.episode, rng_step, ctrl_step, env_index);
+        if constexpr (DIST) {
+            if (P->n_dist[SCG_CH_OBSERVATION] > 0)
+                apply_disturbances<T, D::NX>(P, SCG_CH_OBSERVATION, o, D::NX, key, e.gid, e.episode, rng_step, ctrl_step, env_index);
+        }
         if constexpr (SYS == SCG_CARTPOLE) {
             if (P->obs_wrap_angle) o[2] = normalize_angle(o[2]);
         }
@@ -355,57 +402,70 @@ struct EnvOps {
         }
     }
 
-    // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset.
+    // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset
+    // (written densely at rows 0..n_state-1).  c_out may be null; `stride` = distance between rows.
     __device__ static __forceinline__ bool constraints(const DevParams<T>* __restrict__ P, const T* st, const T* act,
                                                        T* c_out, size_t stride, bool only_state) {
         bool viol = false;
-        int out_row = 0;
-        for (int r = 0; r < P->n_con_rows; ++r) {
-            const DevRow<T>& row = P->con[r];
-            if (only_state && row.var != 0) continue;
-            T c;
-            if (row.kind == SCG_ROW_SPARSE || row.kind == SCG_ROW_ABS) {
-                T v = (T)0;
-                if (row.var == 0) {
+        // (1) box rows, grouped by variable: static register index, uniform trip counts
 #pragma unroll
-                    for (int k = 0; k < D::NX; ++k) v = (row.index == k) ? st[k] : v;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < D::NU; ++k) v = (row.index == k) ? act[k] : v;
-                }
-                c = (row.kind == SCG_ROW_ABS) ? (m_abs(v) - row.b) : (row.sign * v - row.b);
-            } else if (row.kind == SCG_ROW_DENSE) {
-                c = (T)0;
-                if (row.var == 0) {
-#pragma unroll
-                    for (int k = 0; k < D::NX; ++k) c += row.coef[k] * st[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < D::NU; ++k) c += row.coef[k] * act[k];
-                }
-                c -= row.b;
-            } else {   // quadratic: v' P v - b over the state (or input) vector
-                const T* Pm = P->quad_P[row.index];
-                c = (T)0;
-                if (row.var == 0) {
-                    for (int a = 0; a < D::NX; ++a) {
-                        T acc = (T)0;
-                        for (int b = 0; b < D::NX; ++b) acc += Pm[a * D::NX + b] * st[b];
-                        c += st[a] * acc;
-                    }
-                } else {
-                    for (int a = 0; a < D::NU; ++a) {
-                        T acc = (T)0;
-                        for (int b = 0; b < D::NU; ++b) acc += Pm[a * D::NU + b] * act[b];
-                        c += act[a] * acc;
-                    }
-                }
-                c -= row.b;
+        for (int v = 0; v < D::NX + D::NU; ++v) {
+            if (only_state && v >= D::NX) break;
+            const T val = v < D::NX ? st[v < D::NX ? v : 0] : act[v >= D::NX ? v - D::NX : 0];
+            const int b0 = P->bv_first[v < D::NX ? v : SCG_MAX_STATE + (v - D::NX)];
+            const int b1 = P->bv_first[(v < D::NX ? v : SCG_MAX_STATE + (v - D::NX)) + 1];
+            for (int r = b0; r < b1; ++r) {
+                const int fl = P->bv_flags[r];
+                T c = (fl & 2) ? (m_abs(val) - P->bv_b[r]) : (P->bv_sign[r] * val - P->bv_b[r]);
+                const T rs = P->bv_round[r];
+                if (rs > (T)0) c = m_rint(c * rs) * P->bv_inv_round[r];
+                viol = viol || ((fl & 1) ? (c >= (T)0) : (c > (T)0));
+                if (c_out) c_out[(size_t)(only_state ? P->bv_state_pos[r] : P->bv_row[r]) * stride] = c;
             }
-            if (row.round_scale > (T)0) c = m_rint(c * row.round_scale) * row.inv_round_scale;
-            viol = viol || (row.strict ? (c >= (T)0) : (c > (T)0));
-            if (c_out) c_out[(size_t)out_row * stride] = c;
-            ++out_row;
+        }
+        // (2) dense / quadratic rows
+        if (P->n_generic_rows > 0) {
+            int state_pos = 0;
+            for (int r = 0; r < P->n_con_rows; ++r) {
+                const DevRow<T>& row = P->con[r];
+                const int my_state_pos = state_pos;
+                if (row.var == 0) ++state_pos;
+                if (row.kind == SCG_ROW_SPARSE || row.kind == SCG_ROW_ABS) continue;
+                if (only_state && row.var != 0) continue;
+                T c = (T)0;
+                if (row.kind == SCG_ROW_DENSE) {
+                    if (row.var == 0) {
+#pragma unroll
+                        for (int k = 0; k < D::NX; ++k) c += row.coef[k] * st[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < D::NU; ++k) c += row.coef[k] * act[k];
+                    }
+                } else {   // quadratic: v' P v over the state (or input) vector
+                    const T* Pm = P->quad_P[row.index];
+                    if (row.var == 0) {
+#pragma unroll
+                        for (int a = 0; a < D::NX; ++a) {
+                            T acc = (T)0;
+#pragma unroll
+                            for (int b = 0; b < D::NX; ++b) acc += Pm[a * D::NX + b] * st[b];
+                            c += st[a] * acc;
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < D::NU; ++a) {
+                            T acc = (T)0;
+#pragma unroll
+                            for (int b = 0; b < D::NU; ++b) acc += Pm[a * D::NU + b] * act[b];
+                            c += act[a] * acc;
+                        }
+                    }
+                }
+                c -= row.b;
+                if (row.round_scale > (T)0) c = m_rint(c * row.round_scale) * row.inv_round_scale;
+                viol = viol || (row.strict ? (c >= (T)0) : (c > (T)0));
+                if (c_out) c_out[(size_t)(only_state ? my_state_pos : r) * stride] = c;
+            }
         }
         return viol;
     }
@@ -429,31 +489,36 @@ struct EnvOps {
             }
             noisy[j] = a;
         }
-        if (P->n_dist[SCG_CH_ACTION] > 0)
-            apply_disturbances<T, D::NU>(P, SCG_CH_ACTION, noisy, D::NU, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
-        if (P->adversary_channel == SCG_CH_ACTION && adv) {
+        // ---- dynamics disturbance, sampled once per control step (quadrotor.py:413-435, cartpole.py:540-551)
+        T fd[D::DYN];
 #pragma unroll
-            for (int j = 0; j < D::NU; ++j) noisy[j] += adv[j];
+        for (int j = 0; j < D::DYN; ++j) fd[j] = (T)0;
+        bool has_dyn = false;
+        if constexpr (DIST) {
+            if (P->n_dist[SCG_CH_ACTION] > 0)
+                apply_disturbances<T, D::NU>(P, SCG_CH_ACTION, noisy, D::NU, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
+            if (P->adversary_channel == SCG_CH_ACTION && adv) {
+#pragma unroll
+                for (int j = 0; j < D::NU; ++j) noisy[j] += adv[j];
+            }
+            has_dyn = (P->n_dist[SCG_CH_DYNAMICS] > 0) || (P->adversary_channel == SCG_CH_DYNAMICS);
+            if (P->n_dist[SCG_CH_DYNAMICS] > 0)
+                apply_disturbances<T, D::DYN>(P, SCG_CH_DYNAMICS, fd, D::DYN, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
+            if (P->adversary_channel == SCG_CH_DYNAMICS && adv) {
+#pragma unroll
+                for (int j = 0; j < D::DYN; ++j) fd[j] += adv[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) {
             clipped[j] = m_clamp(noisy[j], P->act_low[j], P->act_high[j]);
             if (noisy_out) noisy_out[j] = noisy[j];
         }
-        // ---- dynamics disturbance, sampled once per control step (quadrotor.py:413-435, cartpole.py:540-551)
-        T fd[D::DYN];
-#pragma unroll
-        for (int j = 0; j < D::DYN; ++j) fd[j] = (T)0;
-        const bool has_dyn = (P->n_dist[SCG_CH_DYNAMICS] > 0) || (P->adversary_channel == SCG_CH_DYNAMICS);
-        if (P->n_dist[SCG_CH_DYNAMICS] > 0)
-            apply_disturbances<T, D::DYN>(P, SCG_CH_DYNAMICS, fd, D::DYN, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
-        if (P->adversary_channel == SCG_CH_DYNAMICS && adv) {
-#pragma unroll
-            for (int j = 0; j < D::DYN; ++j) fd[j] += adv[j];
-        }
         // ---- physics
         const T h = P->pyb_dt;
         const T vmax = P->vmax;
+        // |h * angular rate| <= h * vmax: Taylor rotations are exact to < 1 ulp below 0.125 rad
+        const bool small_angle = h * vmax * (T)1.7320508 <= (T)0.125;
         if constexpr (SYS == SCG_CARTPOLE) {
             const T force = clipped[0];
             const T l = e.par[0], M = e.par[1], m = e.par[2];
@@ -461,21 +526,33 @@ struct EnvOps {
             const T two_l = (T)2 * l;
             const T ip = m * (P->pole_box_width * P->pole_box_width + two_l * two_l) * (T)(1.0 / 12.0);
             const T a11 = M + m, a22 = ip + m * l * l, ml = m * l;
+            const T mgl = m * P->gravity * l;
             T x = e.s[0], xd = e.s[1], th = e.s[2], thd = e.s[3];
+            T sn, cs;
+            m_sincos(th, &sn, &cs);
             for (int k = 0; k < P->substeps; ++k) {
-                T sn, cs;
-                m_sincos(th, &sn, &cs);
+                if (!small_angle) m_sincos(th, &sn, &cs);
                 const T a12 = ml * cs;
                 T b1 = force + ml * thd * thd * sn;
-                T b2 = m * P->gravity * l * sn;
-                if (has_dyn) { b1 += fd[0]; b2 += l * (fd[0] * cs - fd[1] * sn); }
-                const T det = a11 * a22 - a12 * a12;
-                const T xdd = (a22 * b1 - a12 * b2) / det;
-                const T thdd = (a11 * b2 - a12 * b1) / det;
+                T b2 = mgl * sn;
+                if constexpr (DIST) {
+                    if (has_dyn) { b1 += fd[0]; b2 += l * (fd[0] * cs - fd[1] * sn); }
+                }
+                const T inv_det = (T)1 / (a11 * a22 - a12 * a12);
+                const T xdd = (a22 * b1 - a12 * b2) * inv_det;
+                const T thdd = (a11 * b2 - a12 * b1) * inv_det;
                 xd = m_clamp(xd + h * xdd, -vmax, vmax);
                 thd = m_clamp(thd + h * thdd, -vmax, vmax);
                 x += h * xd;
-                th += h * thd;
+                const T d = h * thd;
+                th += d;
+                if (small_angle) {
+                    T sd, cd;
+                    small_sincos(d, sd, cd);
+                    const T ns = sn * cd + cs * sd;
+                    cs = cs * cd - sn * sd;
+                    sn = ns;
+                }
             }
             e.s[0] = x; e.s[1] = xd; e.s[2] = th; e.s[3] = thd;
         } else {
@@ -499,6 +576,7 @@ struct EnvOps {
             }
             const T thrust = f[0] + f[1] + f[2] + f[3];
             const T mass = e.par[0];
+            const T inv_m = (T)1 / mass;
             const T g = P->gravity;
             const T arm = P->arm;
             if constexpr (SYS == SCG_QUAD_1D) {
@@ -511,59 +589,72 @@ struct EnvOps {
                 e.s[0] = z; e.s[1] = vz;
             } else if constexpr (SYS == SCG_QUAD_2D) {
                 // planar reduction of the free-body step: y, roll, yaw stay 0 (motors [T1,T2,T2,T1]/2)
-                const T iyy = e.par[2];
+                const T inv_iyy = (T)1 / e.par[2];
                 const T tau_prop = arm * (-f[0] + f[1] + f[2] - f[3]);
-                const T tm = thrust / mass;
+                const T tm = thrust * inv_m;
                 T x = e.s[0], vx = e.s[1], z = e.s[2], vz = e.s[3], th = e.s[4], w = e.s[5];
                 const T x0 = x, z0 = z;       // applyExternalForce point cached at the start of the control step
                 const T fx = has_dyn ? fd[0] : (T)0, fz = has_dyn ? fd[1] : (T)0;
+                const T fxm = fx * inv_m, fzm = fz * inv_m - g;
+                T sn, cs;
+                m_sincos(th, &sn, &cs);
                 for (int k = 0; k < P->substeps; ++k) {
-                    T sn, cs;
-                    m_sincos(th, &sn, &cs);
+                    if (!small_angle) m_sincos(th, &sn, &cs);
                     T tau = tau_prop;
-                    if (has_dyn) tau += (z0 - z) * fx - (x0 - x) * fz;      // ((p0 - p) x F)_y, base_aviary.py:272
-                    const T wd = tau / iyy;
-                    const T ax = sn * tm + fx / mass;
-                    const T az = cs * tm - g + fz / mass;
-                    w = m_clamp(w + h * wd, -vmax, vmax);
-                    vx = m_clamp(vx + h * ax, -vmax, vmax);
-                    vz = m_clamp(vz + h * az, -vmax, vmax);
+                    if constexpr (DIST) {
+                        if (has_dyn) tau += (z0 - z) * fx - (x0 - x) * fz;      // ((p0 - p) x F)_y, base_aviary.py:272
+                    }
+                    w = m_clamp(w + h * (tau * inv_iyy), -vmax, vmax);
+                    vx = m_clamp(vx + h * (sn * tm + fxm), -vmax, vmax);
+                    vz = m_clamp(vz + h * (cs * tm + fzm), -vmax, vmax);
                     x += h * vx;
                     z += h * vz;
-                    th += h * w;
+                    const T d = h * w;
+                    th += d;
+                    if (small_angle) {
+                        T sd, cd;
+                        small_sincos(d, sd, cd);
+                        const T ns = sn * cd + cs * sd;
+                        cs = cs * cd - sn * sd;
+                        sn = ns;
+                    }
                 }
                 e.s[0] = x; e.s[1] = vx; e.s[2] = z; e.s[3] = vz; e.s[4] = th; e.s[5] = w;
             } else {
                 const T J0 = e.par[1], J1 = e.par[2], J2 = e.par[3];
+                const T iJ0 = (T)1 / J0, iJ1 = (T)1 / J1, iJ2 = (T)1 / J2;
                 const T tb0 = arm * (f[0] + f[1] - f[2] - f[3]);
                 const T tb1 = arm * (-f[0] + f[1] + f[2] - f[3]);
                 const T tb2 = -tq[0] + tq[1] - tq[2] + tq[3];
+                const T tm = thrust * inv_m;
                 T p[3] = {e.s[0], e.s[1], e.s[2]};
                 T q[4] = {e.s[3], e.s[4], e.s[5], e.s[6]};
                 T v[3] = {e.s[7], e.s[8], e.s[9]};
                 T w[3] = {e.s[10], e.s[11], e.s[12]};
                 const T p0[3] = {p[0], p[1], p[2]};
+                const T hh = (T)0.5 * h;
                 for (int k = 0; k < P->substeps; ++k) {
                     T R[3][3];
                     quat_to_mat(q, R);
                     T t0 = tb0, t1 = tb1, t2 = tb2;
-                    if (has_dyn) {
-                        const T r0 = p0[0] - p[0], r1 = p0[1] - p[1], r2 = p0[2] - p[2];
-                        const T tw0 = r1 * fd[2] - r2 * fd[1], tw1 = r2 * fd[0] - r0 * fd[2], tw2 = r0 * fd[1] - r1 * fd[0];
-                        t0 += R[0][0] * tw0 + R[1][0] * tw1 + R[2][0] * tw2;
-                        t1 += R[0][1] * tw0 + R[1][1] * tw1 + R[2][1] * tw2;
-                        t2 += R[0][2] * tw0 + R[1][2] * tw1 + R[2][2] * tw2;
+                    T a0 = R[0][2] * tm, a1 = R[1][2] * tm, a2 = R[2][2] * tm - g;
+                    if constexpr (DIST) {
+                        if (has_dyn) {
+                            const T r0 = p0[0] - p[0], r1 = p0[1] - p[1], r2 = p0[2] - p[2];
+                            const T tw0 = r1 * fd[2] - r2 * fd[1], tw1 = r2 * fd[0] - r0 * fd[2], tw2 = r0 * fd[1] - r1 * fd[0];
+                            t0 += R[0][0] * tw0 + R[1][0] * tw1 + R[2][0] * tw2;
+                            t1 += R[0][1] * tw0 + R[1][1] * tw1 + R[2][1] * tw2;
+                            t2 += R[0][2] * tw0 + R[1][2] * tw1 + R[2][2] * tw2;
+                            a0 += fd[0] * inv_m; a1 += fd[1] * inv_m; a2 += fd[2] * inv_m;
+                        }
                     }
                     const T wb0 = R[0][0] * w[0] + R[1][0] * w[1] + R[2][0] * w[2];
                     const T wb1 = R[0][1] * w[0] + R[1][1] * w[1] + R[2][1] * w[2];
                     const T wb2 = R[0][2] * w[0] + R[1][2] * w[1] + R[2][2] * w[2];
                     const T jw0 = J0 * wb0, jw1 = J1 * wb1, jw2 = J2 * wb2;
-                    const T wd0 = (t0 - (wb1 * jw2 - wb2 * jw1)) / J0;
-                    const T wd1 = (t1 - (wb2 * jw0 - wb0 * jw2)) / J1;
-                    const T wd2 = (t2 - (wb0 * jw1 - wb1 * jw0)) / J2;
-                    const T tm = thrust / mass;
-                    T a0 = R[0][2] * tm, a1 = R[1][2] * tm, a2 = R[2][2] * tm - g;
-                    if (has_dyn) { a0 += fd[0] / mass; a1 += fd[1] / mass; a2 += fd[2] / mass; }
+                    const T wd0 = (t0 - (wb1 * jw2 - wb2 * jw1)) * iJ0;
+                    const T wd1 = (t1 - (wb2 * jw0 - wb0 * jw2)) * iJ1;
+                    const T wd2 = (t2 - (wb0 * jw1 - wb1 * jw0)) * iJ2;
                     w[0] = m_clamp(w[0] + h * (R[0][0] * wd0 + R[0][1] * wd1 + R[0][2] * wd2), -vmax, vmax);
                     w[1] = m_clamp(w[1] + h * (R[1][0] * wd0 + R[1][1] * wd1 + R[1][2] * wd2), -vmax, vmax);
                     w[2] = m_clamp(w[2] + h * (R[2][0] * wd0 + R[2][1] * wd1 + R[2][2] * wd2), -vmax, vmax);
@@ -571,18 +662,27 @@ struct EnvOps {
                     v[1] = m_clamp(v[1] + h * a1, -vmax, vmax);
                     v[2] = m_clamp(v[2] + h * a2, -vmax, vmax);
                     p[0] += h * v[0]; p[1] += h * v[1]; p[2] += h * v[2];
-                    // exponential-map orientation update (btMultiBody::stepPositionsMultiDof)
-                    T ang = m_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-                    if (ang * h > (T)0.78539816339744830962) ang = (T)0.78539816339744830962 / h;
-                    T kk;
-                    if (ang < (T)0.001) kk = (T)0.5 * h - (h * h * h) * (T)0.020833333333 * ang * ang;
-                    else kk = m_sin((T)0.5 * ang * h) / ang;
-                    const T dx = w[0] * kk, dy = w[1] * kk, dz = w[2] * kk, dw = m_cos((T)0.5 * ang * h);
+                    // exponential-map orientation update (btMultiBody::stepPositionsMultiDof):
+                    // dq = (w * sin(|w| h/2)/|w|, cos(|w| h/2)), q <- normalize(dq (x) q)
+                    const T w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+                    T kk, dw;
+                    if (small_angle) {
+                        T sinc;
+                        small_sinc_cos(hh * hh * w2, sinc, dw);
+                        kk = hh * sinc;
+                    } else {
+                        T ang = m_sqrt(w2);
+                        if (ang * h > (T)0.78539816339744830962) ang = (T)0.78539816339744830962 / h;
+                        if (ang < (T)0.001) kk = (T)0.5 * h - (h * h * h) * (T)0.020833333333 * ang * ang;
+                        else kk = m_sin((T)0.5 * ang * h) / ang;
+                        dw = m_cos((T)0.5 * ang * h);
+                    }
+                    const T dx = w[0] * kk, dy = w[1] * kk, dz = w[2] * kk;
                     const T qx = dw * q[0] + dx * q[3] + dy * q[2] - dz * q[1];
                     const T qy = dw * q[1] - dx * q[2] + dy * q[3] + dz * q[0];
                     const T qz = dw * q[2] + dx * q[1] - dy * q[0] + dz * q[3];
                     const T qw = dw * q[3] - dx * q[0] - dy * q[1] - dz * q[2];
-                    const T inv = (T)1 / m_sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+                    const T inv = m_rsqrt(qx * qx + qy * qy + qz * qz + qw * qw);
                     q[0] = qx * inv; q[1] = qy * inv; q[2] = qz * inv; q[3] = qw * inv;
                 }
                 e.s[0] = p[0]; e.s[1] = p[1]; e.s[2] = p[2];

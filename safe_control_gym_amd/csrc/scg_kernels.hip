@@ -54,11 +54,11 @@ __device__ __forceinline__ const T* stage_goal(const DevParams<T>* __restrict__ 
     return tab;
 }
 
-template <int SYS, typename T>
+template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void reset_kernel(const DevParams<T>* __restrict__ P,
                                                       const uint8_t* __restrict__ mask, StepOut<T> O) {
     extern __shared__ __align__(16) unsigned char smem[];
-    using Ops = EnvOps<SYS, T>;
+    using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const T* goal = stage_goal(P, smem);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,11 +84,11 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const DevParams<T>* __rest
     Ops::store(P, i, e, true);
 }
 
-template <int SYS, typename T>
+template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const DevParams<T>* __restrict__ P, const T* __restrict__ action,
                                                      const T* __restrict__ adv, StepOut<T> O) {
     extern __shared__ __align__(16) unsigned char smem[];
-    using Ops = EnvOps<SYS, T>;
+    using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const T* goal = stage_goal(P, smem);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,7 +141,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevParams<T>* __restr
         O.ep_mse[i] = r.done ? (T)0 : acc;
     }
     // observation of the step: terminal_observation where done, else the returned obs
-    if (r.done) {
+    const bool do_reset = r.done && P->auto_reset;
+    if (r.done && !P->auto_reset && O.terminal_obs)
+        Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, O.terminal_obs + (size_t)i * P->nobs);
+    if (do_reset) {
         if (O.terminal_obs) Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, O.terminal_obs + (size_t)i * P->nobs);
         Ops::reset(P, i, e, key);               // auto-reset (dummy_vec_env.py:33-38)
         Ops::state_vector(e, st);
@@ -153,15 +156,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const DevParams<T>* __restr
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) O.state[(size_t)k * N + i] = st[k];
     }
-    Ops::store(P, i, e, r.done);
+    Ops::store(P, i, e, do_reset);
 }
 
-template <int SYS, typename T>
+template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const DevParams<T>* __restrict__ P, int k_steps,
                                                                T* __restrict__ reward_sum, int32_t* __restrict__ done_count,
                                                                int32_t* __restrict__ violation_count, T* __restrict__ last_obs) {
     extern __shared__ __align__(16) unsigned char smem[];
-    using Ops = EnvOps<SYS, T>;
+    using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const T* goal = stage_goal(P, smem);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,9 +187,11 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const DevParams<T
         viols += (r.flags & FLAG_VIOLATION) ? 1 : 0;
         if (r.done) {
             ++dones;
-            dirty = true;
-            Ops::reset(P, i, e, key);
-            Ops::state_vector(e, st);
+            if (P->auto_reset) {
+                dirty = true;
+                Ops::reset(P, i, e, key);
+                Ops::state_vector(e, st);
+            }
         }
     }
     if (reward_sum) reward_sum[i] = rsum;
@@ -304,6 +309,7 @@ struct scg_env {
     int32_t* d_dist_offset;
     uint8_t* d_oob;
     bool has_reset;
+    bool has_dist;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -400,6 +406,7 @@ static void fill_params(const scg_env* e, const scg_config& c, DevParams<T>& p) 
     p.nx = e->nx; p.nu = e->nu; p.nobs = e->nobs; p.ns = e->ns; p.np = e->np;
     p.per_env_params = c.randomized_inertial_prop;
     p.randomized_init = c.randomized_init;
+    p.auto_reset = c.auto_reset;
     p.n_offset_slots = e->n_offset_slots;
     p.goal_tolerance = (T)c.goal_tolerance; p.constraint_penalty = (T)c.constraint_penalty;
     for (int k = 0; k < SCG_MAX_STATE; ++k) {
@@ -454,6 +461,30 @@ static void fill_params(const scg_env* e, const scg_config& c, DevParams<T>& p) 
     }
     for (int q = 0; q < SCG_MAX_QUAD_CON; ++q)
         for (int j = 0; j < SCG_MAX_STATE * SCG_MAX_STATE; ++j) p.quad_P[q][j] = (T)c.quad_P[q][j];
+    // box rows regrouped by variable slot (state k -> k, input j -> SCG_MAX_STATE + j)
+    {
+        int n = 0, generic = 0;
+        std::vector<int> state_pos(c.n_con_rows, 0);
+        int sp = 0;
+        for (int r = 0; r < c.n_con_rows; ++r) { state_pos[r] = sp; if (c.con[r].var == 0) ++sp; }
+        for (int slot = 0; slot < SCG_MAX_STATE + SCG_MAX_ACTION; ++slot) {
+            p.bv_first[slot] = n;
+            const int var = slot < SCG_MAX_STATE ? 0 : 1, index = slot < SCG_MAX_STATE ? slot : slot - SCG_MAX_STATE;
+            for (int r = 0; r < c.n_con_rows; ++r) {
+                const DevRow<T>& d = p.con[r];
+                if ((d.kind == SCG_ROW_SPARSE || d.kind == SCG_ROW_ABS) && d.var == var && d.index == index) {
+                    p.bv_row[n] = r; p.bv_state_pos[n] = state_pos[r];
+                    p.bv_flags[n] = (d.strict ? 1 : 0) | (d.kind == SCG_ROW_ABS ? 2 : 0);
+                    p.bv_sign[n] = d.sign; p.bv_b[n] = d.b; p.bv_round[n] = d.round_scale; p.bv_inv_round[n] = d.inv_round_scale;
+                    ++n;
+                }
+            }
+        }
+        p.bv_first[SCG_MAX_STATE + SCG_MAX_ACTION] = n;
+        for (int r = 0; r < c.n_con_rows; ++r)
+            if (p.con[r].kind != SCG_ROW_SPARSE && p.con[r].kind != SCG_ROW_ABS) ++generic;
+        p.n_box_rows = n; p.n_generic_rows = generic;
+    }
     p.x_goal = (const T*)e->d_goal;
     p.state = (T*)e->d_state; p.param = (T*)e->d_param; p.step = e->d_step; p.episode = e->d_episode;
     p.dist_offset = e->d_dist_offset; p.oob_attr = e->d_oob;
@@ -497,6 +528,7 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->d_state = w + L.state; e->d_param = w + L.param; e->d_step = (int32_t*)(w + L.step);
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->has_reset = false;
+    e->has_dist = cfg->n_dist[0] > 0 || cfg->n_dist[1] > 0 || cfg->n_dist[2] > 0 || cfg->adversary_channel >= 0;
     hipError_t err = hipMemset(d_workspace, 0, L.total);
     if (err == hipSuccess) err = hipMemset(e->d_episode, 0xff, (size_t)cfg->num_envs * 4);   // first reset -> episode 0
     if (err != hipSuccess) { delete e; return fail(SCG_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(err)); }
@@ -528,20 +560,24 @@ static StepOut<T> typed_out(const scg_step_out* o) {
     return t;
 }
 
-#define DISPATCH_SYS(env, T, CALL)                                             \
+#define DISPATCH_SYS_D(env, T, CALL)                                           \
     switch ((env)->cfg.system) {                                               \
         case SCG_CARTPOLE: { constexpr int S = SCG_CARTPOLE; CALL; } break;    \
         case SCG_QUAD_1D: { constexpr int S = SCG_QUAD_1D; CALL; } break;      \
         case SCG_QUAD_2D: { constexpr int S = SCG_QUAD_2D; CALL; } break;      \
         default: { constexpr int S = SCG_QUAD_3D; CALL; } break;               \
     }
+// DIST kernel variant only when a disturbance or an adversary is configured
+#define DISPATCH_SYS(env, T, CALL)                                             \
+    if ((env)->has_dist) { constexpr bool DD = true; DISPATCH_SYS_D(env, T, CALL) } \
+    else { constexpr bool DD = false; DISPATCH_SYS_D(env, T, CALL) }
 
 template <typename T>
 static int launch_reset(scg_env* env, const uint8_t* mask, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
     StepOut<T> O = typed_out<T>(out);
     const DevParams<T>* P = (const DevParams<T>*)env->d_params;
-    DISPATCH_SYS(env, T, (reset_kernel<S, T><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, mask, O)));
+    DISPATCH_SYS(env, T, (reset_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, mask, O)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }
@@ -551,7 +587,7 @@ static int launch_step(scg_env* env, const void* action, const void* adv, const 
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
     StepOut<T> O = typed_out<T>(out);
     const DevParams<T>* P = (const DevParams<T>*)env->d_params;
-    DISPATCH_SYS(env, T, (step_kernel<S, T><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, (const T*)action, (const T*)adv, O)));
+    DISPATCH_SYS(env, T, (step_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, (const T*)action, (const T*)adv, O)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }
@@ -564,7 +600,7 @@ static int launch_rollout(scg_env* env, int k, const scg_rollout_out* o, hipStre
     int32_t* dc = o ? o->d_done_count : nullptr;
     int32_t* vc = o ? o->d_violation_count : nullptr;
     T* lo = o ? (T*)o->d_last_obs : nullptr;
-    DISPATCH_SYS(env, T, (rollout_random_kernel<S, T><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, k, rs, dc, vc, lo)));
+    DISPATCH_SYS(env, T, (rollout_random_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, k, rs, dc, vc, lo)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }

@@ -45,6 +45,7 @@ struct DevParams {
     int32_t nx, nu, nobs, ns, np;       // state_dim, action_dim, obs_dim, raw state arrays, per-env params
     int32_t per_env_params;             // randomized_inertial_prop: read params from the workspace
     int32_t randomized_init, n_offset_slots;
+    int32_t auto_reset, pad1;
     T goal_tolerance, constraint_penalty;
     T rew_state_weight[SCG_MAX_STATE], rew_act_weight[SCG_MAX_ACTION];
     T q_diag[SCG_MAX_STATE], r_diag[SCG_MAX_ACTION];
@@ -63,6 +64,14 @@ struct DevParams {
     int32_t adversary_channel;
     DevDist<T> dist[3][SCG_MAX_DISTURB];
     int32_t n_con_rows, n_state_con_rows;
+    // box rows (SPARSE / ABS) regrouped by constrained variable so the kernel indexes registers statically:
+    // variable slot v (0..NX-1 state, NX..NX+NU-1 input) owns entries [bv_first[v], bv_first[v+1])
+    int32_t n_box_rows, n_generic_rows;
+    int32_t bv_first[SCG_MAX_STATE + SCG_MAX_ACTION + 1];
+    int32_t bv_row[SCG_MAX_CON_ROWS];        // output row in the stacked constraint vector
+    int32_t bv_state_pos[SCG_MAX_CON_ROWS];  // output row among the state-only rows (reset-time evaluation)
+    int32_t bv_flags[SCG_MAX_CON_ROWS];      // bit0 strict, bit1 abs
+    T bv_sign[SCG_MAX_CON_ROWS], bv_b[SCG_MAX_CON_ROWS], bv_round[SCG_MAX_CON_ROWS], bv_inv_round[SCG_MAX_CON_ROWS];
     DevRow<T> con[SCG_MAX_CON_ROWS];
     T quad_P[SCG_MAX_QUAD_CON][SCG_MAX_STATE * SCG_MAX_STATE];
     // device pointers

@@ -5,8 +5,10 @@
 //   counter = (global_env_id, episode_index, step_index, tag)
 //   tag     = (channel << 16) | (item << 8) | block
 //   channel: 0 reset, 1 action, 2 dynamics, 3 observation, 4 random-action
-//   reset items: init-state var j -> j (0..11); inertial parameter p -> 12 + p;
-//                disturbance offset (channel c in 1..3, index k) -> 16 + 8 * (c - 1) + k
+//   reset draws (channel 0, step 0): item = group (0 initial state, 1 inertial parameters, 2 disturbance
+//                offsets); variable j of a group uses block j/2 and the word pair (2*(j&1), 2*(j&1)+1):
+//                uniform / choice / integer draws consume the first word, normal draws both.
+//                j = INIT_STATE_LABELS index | inertial parameter index | 4 * scg_channel + list index
 //   u01(word)    = ((word >> 8) + 0.5) * 2^-24     (exact in fp32)
 //   normal(w0,w1)= sqrt(-2 ln u01(w0)) * cos(2 pi u01(w1))
 //
@@ -26,7 +28,7 @@ namespace scg {
 
 enum : uint32_t { RNG_CH_RESET = 0, RNG_CH_ACTION = 1, RNG_CH_DYNAMICS = 2, RNG_CH_OBSERVATION = 3,
                   RNG_CH_RANDOM_ACTION = 4 };
-enum : uint32_t { RNG_ITEM_INIT0 = 0, RNG_ITEM_PARAM0 = 12, RNG_ITEM_DISTURB0 = 16 };
+enum : uint32_t { RNG_GROUP_INIT = 0, RNG_GROUP_PARAM = 1, RNG_GROUP_DISTURB = 2 };
 
 struct U4 { uint32_t x, y, z, w; };
 

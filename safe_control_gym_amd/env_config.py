@@ -597,9 +597,10 @@ class EnvSpec:
         return r
 
     # ------------------------------------------------------------------ -> scg_config
-    def to_c_config(self, num_envs, dtype, seed, env_id_offset=0):
+    def to_c_config(self, num_envs, dtype, seed, env_id_offset=0, auto_reset=True):
         kw = self.kw
         c = L.Config()
+        c.auto_reset = int(bool(auto_reset))
         c.abi_version, c.system, c.dtype, c.integrator = L.SCG_ABI_VERSION, self.system, dtype, L.INT_PYB_EULER
         c.num_envs, c.env_id_offset, c.seed = int(num_envs), int(env_id_offset), int(seed) & 0xFFFFFFFFFFFFFFFF
         c.substeps, c.ctrl_steps = self.PYB_STEPS_PER_CTRL, int(self.CTRL_STEPS)

@@ -85,10 +85,19 @@ def get_config(idx):
 
 
 def load_task(name):
-    """(env_id, task_config) from safe_control_gym_amd/configs/<name>.yaml."""
+    """(env_id, task_config) from safe_control_gym_amd/configs/<name>.yaml.  The YAML's `seed` is only
+    the default the reference uses when the caller passes none (train_rl_controller.py:28-36); it is
+    returned as task_config['seed'] removed -> use ``load_task_seed`` if you want it."""
     with open(os.path.join(CONFIG_DIR, name + '.yaml')) as f:
         d = yaml.safe_load(f)
-    return d['task'], d['task_config']
+    cfg = dict(d['task_config'])
+    cfg.pop('seed', None)
+    return d['task'], cfg
+
+
+def load_task_seed(name):
+    with open(os.path.join(CONFIG_DIR, name + '.yaml')) as f:
+        return yaml.safe_load(f)['task_config'].get('seed')
 
 
 # env ids of the reference (envs/__init__.py:5-11); entry points build the single-env facade.

@@ -164,7 +164,7 @@ class HipVecEnv(VecEnv):
     """N independent copies of one environment stepped by libscg_hip.so on one GPU."""
 
     def __init__(self, env_id, num_envs, seed=0, device=None, dtype=torch.float32, env_id_offset=0,
-                 return_numpy=True, **task_config):
+                 return_numpy=True, auto_reset=True, **task_config):
         L.lib()                                        # fail loudly, before touching torch.cuda
         if not torch.cuda.is_available():
             raise L.ScgError('HipVecEnv needs a HIP device (torch.cuda.is_available() is False); '
@@ -187,7 +187,8 @@ class HipVecEnv(VecEnv):
         self.return_numpy = return_numpy
         VecEnv.__init__(self, int(num_envs), spec.observation_space, spec.action_space)
         self._lib = L.lib()
-        cfg, x_goal = spec.to_c_config(self.num_envs, self._cdtype, self.seed_value, self.env_id_offset)
+        cfg, x_goal = spec.to_c_config(self.num_envs, self._cdtype, self.seed_value, self.env_id_offset, auto_reset)
+        self.auto_reset = bool(auto_reset)
         self._cfg = cfg
         nbytes = C.c_size_t(0)
         L.check(self._lib.scg_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
