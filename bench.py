@@ -91,6 +91,8 @@ def main():
     dev = torch.device('cuda', torch.cuda.current_device())
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     env_id, cfg = load_task(args.task)
+    if os.environ.get('SCG_BENCH_OVERRIDE'):      # dev only: ablations of the task config
+        cfg.update(json.loads(os.environ['SCG_BENCH_OVERRIDE']))
     N = args.envs
     env = HipVecEnv(env_id, N, seed=1337, dtype=dtype, env_id_offset=rank * N, return_numpy=False, **cfg)
     nu = env.spec.nu

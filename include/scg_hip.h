@@ -273,6 +273,16 @@ int scg_abi_version(void);
 size_t scg_sizeof_config(void);
 size_t scg_sizeof_step_out(void);
 
+/* Config specialisation.  The hot path is latency-bound at the headline size (one wave per SIMD), so the
+ * fastest kernels are the ones compiled for ONE task config: scg_spec_source() returns the text of a small
+ * header (every hot parameter as an exact hexadecimal literal + the FNV-1a hash of that text); compiling
+ * the library sources with `hipcc -DSCG_SPEC -include <that header>` yields a library with the same ABI
+ * whose kernels have the config baked in.  scg_create() of such a library refuses any other config.
+ * `buf` may be NULL to query the length.  Instance fields (num_envs, env_id_offset, seed) are not part of
+ * the hash; dtype is. */
+int scg_spec_source(const scg_config* cfg, char* buf, size_t capacity, size_t* length, uint64_t* hash);
+uint64_t scg_spec_hash(void);    /* 0 = generic library, else the hash this library was specialised for */
+
 #ifdef __cplusplus
 }
 #endif

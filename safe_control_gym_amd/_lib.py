@@ -12,7 +12,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libscg_hip.so')
 SOURCES = ['scg_kernels.hip']
-HEADERS = ['scg_env_core.h', 'scg_params.h', 'scg_rng.h', os.path.join('..', '..', 'include', 'scg_hip.h')]
+HEADERS = ['scg_env_core.h', 'scg_env_kernels.h', 'scg_gae_kernels.h', 'scg_params.h', 'scg_rng.h', 'scg_spec.h',
+           os.path.join('..', '..', 'include', 'scg_hip.h')]
+SPEC_DIR = os.path.join(PKG_DIR, 'spec')
 
 SCG_ABI_VERSION = 1
 MAX_STATE, MAX_ACTION, MAX_GOAL_HORIZON = 12, 4, 4
@@ -95,7 +97,7 @@ class RolloutOut(C.Structure):
 EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step',
            'scg_rollout_random', 'scg_set_state', 'scg_get_state', 'scg_set_params', 'scg_get_params',
            'scg_set_counters', 'scg_get_counters', 'scg_gae', 'scg_last_error', 'scg_abi_version',
-           'scg_sizeof_config', 'scg_sizeof_step_out']
+           'scg_sizeof_config', 'scg_sizeof_step_out', 'scg_spec_source', 'scg_spec_hash']
 
 
 class ScgError(RuntimeError):
@@ -120,23 +122,20 @@ def build(force=False, verbose=False):
 
 
 _lib = None
+_spec_libs = {}
 
 
-def lib():
-    """The loaded library.  Raises ScgError (never falls back) if it is missing or inconsistent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ScgError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+def _bind(path):
+    if not os.path.exists(path):
+        raise ScgError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                        '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
     try:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
     except OSError as exc:
-        raise ScgError(f'cannot load {LIB_PATH}: {exc}') from exc
+        raise ScgError(f'cannot load {path}: {exc}') from exc
     for name in EXPORTS:
         if not hasattr(L, name):
-            raise ScgError(f'{LIB_PATH} does not export {name}')
+            raise ScgError(f'{path} does not export {name}')
     L.scg_last_error.restype = C.c_char_p
     L.scg_sizeof_config.restype = C.c_size_t
     L.scg_sizeof_step_out.restype = C.c_size_t
@@ -158,10 +157,79 @@ def lib():
     L.scg_get_counters.argtypes = [c_vp, C.POINTER(c_i32), C.POINTER(C.c_uint32), C.c_int, C.c_int, c_vp]
     L.scg_gae.argtypes = [C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                           c_f64, c_f64, C.c_int, c_vp]
-    _lib = L
+    L.scg_spec_source.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(c_u64)]
+    L.scg_spec_hash.restype = c_u64
     return L
 
 
-def check(rc):
+def lib():
+    """The generic library (any config).  Raises ScgError (never falls back) if it is missing or inconsistent."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+# ---------------------------------------------------------------------------- config-specialised builds
+def spec_source(cfg):
+    """(source text, hash) of the specialisation header for a scg_config (generated by the library itself)."""
+    L = lib()
+    n, h = C.c_size_t(0), c_u64(0)
+    check(L.scg_spec_source(C.byref(cfg), None, 0, C.byref(n), C.byref(h)))
+    buf = C.create_string_buffer(n.value)
+    check(L.scg_spec_source(C.byref(cfg), buf, n.value, C.byref(n), C.byref(h)))
+    return buf.value.decode(), int(h.value)
+
+
+def spec_paths(hash_value):
+    tag = f'{hash_value:016x}'
+    return os.path.join(SPEC_DIR, f'scg_spec_{tag}.h'), os.path.join(SPEC_DIR, f'libscg_spec_{tag}.so')
+
+
+def build_spec(cfg, force=False, verbose=False):
+    """Compile libscg_spec_<hash>.so: the same sources with this task config as compile-time constants."""
+    src, h = spec_source(cfg)
+    hdr, so = spec_paths(h)
+    os.makedirs(SPEC_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
+    deps = srcs + [os.path.normpath(os.path.join(CSRC_DIR, x)) for x in HEADERS]
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
+        return so
+    with open(hdr, 'w') as f:
+        f.write(src)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSCG_SPEC', '-include', hdr,
+           '-o', so] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise ScgError('hipcc failed (specialised build):\n' + res.stdout + res.stderr)
+    return so
+
+
+def lib_for(cfg, specialize='auto'):
+    """Library to drive an env with this config: the matching specialised build when it exists in-tree
+    (or, with specialize=True, after compiling it now), else the generic library."""
+    if specialize in (False, 'off', None):
+        return lib(), False
+    _, h = spec_source(cfg)
+    if h in _spec_libs:
+        return _spec_libs[h], True
+    _, so = spec_paths(h)
+    if not os.path.exists(so):
+        if specialize is True or specialize == 'build':
+            build_spec(cfg)
+        else:
+            return lib(), False
+    L = _bind(so)
+    if int(L.scg_spec_hash()) != h:
+        raise ScgError(f'{so} was built for another config')
+    _spec_libs[h] = L
+    return L, True
+
+
+def check(rc, L=None):
     if rc != 0:
-        raise ScgError(f'libscg_hip error {rc}: {lib().scg_last_error().decode()}')
+        L = L if L is not None else lib()
+        raise ScgError(f'libscg_hip error {rc}: {L.scg_last_error().decode()}')

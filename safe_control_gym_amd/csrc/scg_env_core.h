@@ -31,6 +31,13 @@
 #include "scg_params.h"
 #include "scg_rng.h"
 
+// box-constraint loop: fully unrolled when the row table is a compile-time constant (specialised build)
+#ifdef SCG_SPEC
+#define SCG_BOX_UNROLL _Pragma("unroll")
+#else
+#define SCG_BOX_UNROLL _Pragma("unroll 8")
+#endif
+
 namespace scg {
 
 // ------------------------------------------------------------------ math wrappers
@@ -109,6 +116,23 @@ template <> struct Dims<SCG_QUAD_1D> { enum { NX = 2, NU = 1, NS = 2, NP = 4, DY
 template <> struct Dims<SCG_QUAD_2D> { enum { NX = 6, NU = 2, NS = 6, NP = 4, DYN = 2 }; };
 template <> struct Dims<SCG_QUAD_3D> { enum { NX = 12, NU = 4, NS = 13, NP = 4, DYN = 3 }; };
 
+// X_GOAL table access: LDS copy (generic build, table fits) or global memory.  Kept as two typed pointers
+// and a flag: selecting between an LDS-derived and a global generic pointer trips a gfx950 backend bug
+// ("V_CMP_NE_U32 0, src_shared_base: operand has incorrect register class", ROCm 7.2).
+template <typename T>
+struct GoalTab {
+    const T* lds;
+    const T* glob;
+    bool in_lds;
+    __device__ __forceinline__ T operator[](int k) const {
+#ifdef SCG_SPEC
+        return glob[k];
+#else
+        return in_lds ? lds[k] : glob[k];
+#endif
+    }
+};
+
 // Device view of scg_step_out with typed pointers.
 template <typename T>
 struct StepOut {
@@ -132,17 +156,17 @@ struct Env {
 // ------------------------------------------------------------------ random helpers
 // Reset-time draws: variable j of group g uses Philox block j/2 of item g, words 2*(j&1) and 2*(j&1)+1.
 template <typename T>
-__device__ __forceinline__ T rand_value(const DevRand<T>& r, uint32_t w0, uint32_t w1) {
+__device__ __forceinline__ T rand_value(const HotRand<T>& r, const DevRand<T>& full, uint32_t w0, uint32_t w1) {
     if (r.kind == SCG_RAND_UNIFORM) return r.p0 + (r.p1 - r.p0) * u01<T>(w0);
     if (r.kind == SCG_RAND_NORMAL) {
         const T u1 = u01<T>(w0), u2 = u01<T>(w1);
         return r.p0 + r.p1 * (m_sqrt((T)-2 * m_log(u1)) * m_cos(Const<T>::TWO_PI * u2));
     }
-    if (r.kind == SCG_RAND_CHOICE) {
-        const uint32_t k = int_below(w0, (uint32_t)r.n_choice);
-        T v = r.choices[0];
+    if (r.kind == SCG_RAND_CHOICE) {          // choice lists live in the cold block
+        const uint32_t k = int_below(w0, (uint32_t)full.n_choice);
+        T v = full.choices[0];
 #pragma unroll
-        for (int c = 1; c < SCG_MAX_CHOICE; ++c) v = (k == (uint32_t)c) ? r.choices[c] : v;
+        for (int c = 1; c < SCG_MAX_CHOICE; ++c) v = (k == (uint32_t)c) ? full.choices[c] : v;
         return v;
     }
     return (T)0;
@@ -150,16 +174,18 @@ __device__ __forceinline__ T rand_value(const DevRand<T>& r, uint32_t w0, uint32
 
 // DisturbanceList.apply (disturbances.py:54-62) for one channel; `vec` has `dim` entries.
 // rng_step: Philox step index (pre-increment counter for action/dynamics; observation index for obs).
+// (forceinline: a real call would pass the LDS-resident parameter block as a flat pointer, which the gfx950
+//  backend of ROCm 7.2 mis-selects — "V_CMP_NE_U32 0, src_shared_base: incorrect register class".)
 template <typename T, int MAXDIM>
-__device__ __noinline__ void apply_disturbances(const DevParams<T>* __restrict__ P, int ch, T* vec, int dim,
+__device__ __forceinline__ void apply_disturbances(const PV<T>& P, int ch, T* vec, int dim,
                                                 RngKey key, uint32_t gid, uint32_t episode, uint32_t rng_step,
                                                 int32_t ctrl_step, int env_index) {
-    const int n = P->n_dist[ch];
+    const int n = P.c.n_dist[ch];
     for (int k = 0; k < n; ++k) {
-        const DevDist<T>& d = P->dist[ch][k];
+        const DevDist<T>& d = P.i.cold->dist[ch][k];
         const uint32_t rch = (uint32_t)(ch + 1);
         if (d.kind == SCG_DIST_IMPULSE || d.kind == SCG_DIST_STEP) {
-            int32_t off = d.offset_slot >= 0 ? P->dist_offset[(size_t)d.offset_slot * P->num_envs + env_index] : d.step_offset;
+            int32_t off = d.offset_slot >= 0 ? P.i.cold->dist_offset[(size_t)d.offset_slot * P.i.num_envs + env_index] : d.step_offset;
             T gain = (T)0;
             if (ctrl_step >= off) {
                 if (d.kind == SCG_DIST_STEP) {
@@ -174,7 +200,7 @@ __device__ __noinline__ void apply_disturbances(const DevParams<T>* __restrict__
         } else if (d.kind == SCG_DIST_UNIFORM || d.kind == SCG_DIST_PERIODIC) {
             U4 w{0, 0, 0, 0};
             T tphase = (T)0;
-            if (d.kind == SCG_DIST_PERIODIC) tphase = d.two_pi_freq * ((T)(ctrl_step * P->substeps) * P->pyb_dt);
+            if (d.kind == SCG_DIST_PERIODIC) tphase = d.two_pi_freq * ((T)(ctrl_step * P.c.substeps) * P.c.pyb_dt);
             for (int j = 0; j < dim; ++j) {
                 if ((j & 3) == 0) w = rng_words(key, gid, episode, rng_step, rng_tag(rch, (uint32_t)k, (uint32_t)(j >> 2)));
                 const T u = u01<T>(u4_get(w, j & 3));
@@ -260,32 +286,38 @@ struct EnvOps {
     using E = Env<SYS, T>;
     static constexpr bool IS_QUAD = (SYS != SCG_CARTPOLE);
 
-    __device__ static __forceinline__ void load(const DevParams<T>* __restrict__ P, int i, E& e) {
-        const size_t N = (size_t)P->num_envs;
+    // Split load: the raw state / counters are requested before the LDS staging barrier (P = global block),
+    // the inertial parameters afterwards (P = LDS copy).
+    __device__ static __forceinline__ void load_state(const PV<T>& P, int i, E& e) {
+        const size_t N = (size_t)P.i.num_envs;
+        T* __restrict__ sp = P.i.state;
 #pragma unroll
-        for (int k = 0; k < D::NS; ++k) e.s[k] = P->state[k * N + i];
-        if (P->per_env_params) {
+        for (int k = 0; k < D::NS; ++k) e.s[k] = sp[k * N + i];
+        e.step = P.i.step[i];
+        e.episode = P.i.episode[i];
+        e.gid = (uint32_t)(P.i.env_id_offset + i);
+    }
+    __device__ static __forceinline__ void load_params(const PV<T>& P, int i, E& e) {
+        const size_t N = (size_t)P.i.num_envs;
+        if (P.c.per_env_params) {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k) e.par[k] = P->param[k * N + i];
+            for (int k = 0; k < D::NP; ++k) e.par[k] = P.i.param[k * N + i];
         } else {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k) e.par[k] = P->base_param[k];
+            for (int k = 0; k < D::NP; ++k) e.par[k] = P.c.base_param[k];
         }
-        e.step = P->step[i];
-        e.episode = P->episode[i];
-        e.gid = (uint32_t)(P->env_id_offset + i);
     }
 
-    __device__ static __forceinline__ void store(const DevParams<T>* __restrict__ P, int i, const E& e, bool params_dirty) {
-        const size_t N = (size_t)P->num_envs;
+    __device__ static __forceinline__ void store(const PV<T>& P, int i, const E& e, bool params_dirty) {
+        const size_t N = (size_t)P.i.num_envs;
 #pragma unroll
-        for (int k = 0; k < D::NS; ++k) P->state[k * N + i] = e.s[k];
-        if (P->per_env_params && params_dirty) {
+        for (int k = 0; k < D::NS; ++k) P.i.state[k * N + i] = e.s[k];
+        if (P.c.per_env_params && params_dirty) {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k) P->param[k * N + i] = e.par[k];
+            for (int k = 0; k < D::NP; ++k) P.i.param[k * N + i] = e.par[k];
         }
-        P->step[i] = e.step;
-        P->episode[i] = e.episode;
+        P.i.step[i] = e.step;
+        P.i.episode[i] = e.episode;
     }
 
     // env.state (the vector the reference exposes), from the raw simulator state.
@@ -313,40 +345,40 @@ struct EnvOps {
 
     // Reset one env (Quadrotor.reset / CartPole.reset).  Increments the episode index, draws disturbance
     // offsets, inertial parameters and the initial state (each addressed by its own Philox counter).
-    __device__ static __forceinline__ void reset(const DevParams<T>* __restrict__ P, int i, E& e, RngKey key) {
+    __device__ static __forceinline__ void reset(const PV<T>& P, int i, E& e, RngKey key) {
         e.episode += 1u;
         e.step = 0;
         if constexpr (DIST) {
             // disturbance offsets (ImpulseDisturbance.reset / StepDisturbance.reset), variable index 4*ch + k
             for (int ch = 0; ch < 3; ++ch) {
-                for (int k = 0; k < P->n_dist[ch]; ++k) {
-                    const DevDist<T>& d = P->dist[ch][k];
+                for (int k = 0; k < P.c.n_dist[ch]; ++k) {
+                    const DevDist<T>& d = P.i.cold->dist[ch][k];
                     if (d.offset_slot >= 0) {
                         const int j = 4 * ch + k;
                         U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_DISTURB, (uint32_t)(j >> 1)));
-                        P->dist_offset[(size_t)d.offset_slot * P->num_envs + i] =
+                        P.i.cold->dist_offset[(size_t)d.offset_slot * P.i.num_envs + i] =
                             (int32_t)int_below((j & 1) ? w.z : w.x, (uint32_t)d.max_step);
                     }
                 }
             }
         }
-        if (P->per_env_params) {
+        if (P.c.per_env_params) {
 #pragma unroll
             for (int b = 0; b < (D::NP + 1) / 2; ++b) {
                 U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_PARAM, (uint32_t)b));
-                e.par[2 * b] = P->base_param[2 * b] + rand_value(P->param_rand[2 * b], w.x, w.y);
-                if (2 * b + 1 < D::NP) e.par[2 * b + 1] = P->base_param[2 * b + 1] + rand_value(P->param_rand[2 * b + 1], w.z, w.w);
+                e.par[2 * b] = P.c.base_param[2 * b] + rand_value(P.c.param_rand[2 * b], P.i.cold->param_rand[2 * b], w.x, w.y);
+                if (2 * b + 1 < D::NP) e.par[2 * b + 1] = P.c.base_param[2 * b + 1] + rand_value(P.c.param_rand[2 * b + 1], P.i.cold->param_rand[2 * b + 1], w.z, w.w);
             }
         }
         T iv[D::NX];
 #pragma unroll
-        for (int k = 0; k < D::NX; ++k) iv[k] = P->init_state[k];
-        if (P->randomized_init) {
+        for (int k = 0; k < D::NX; ++k) iv[k] = P.c.init_state[k];
+        if (P.c.randomized_init) {
 #pragma unroll
             for (int b = 0; b < D::NX / 2; ++b) {
                 U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));
-                iv[2 * b] += rand_value(P->init_rand[2 * b], w.x, w.y);
-                iv[2 * b + 1] += rand_value(P->init_rand[2 * b + 1], w.z, w.w);
+                iv[2 * b] += rand_value(P.c.init_rand[2 * b], P.i.cold->init_rand[2 * b], w.x, w.y);
+                iv[2 * b + 1] += rand_value(P.c.init_rand[2 * b + 1], P.i.cold->init_rand[2 * b + 1], w.z, w.w);
             }
         }
         if constexpr (SYS == SCG_CARTPOLE || SYS == SCG_QUAD_2D) {
@@ -371,25 +403,25 @@ struct EnvOps {
     //               benchmark_env.py:433-437, quadrotor.py:813-816)
     //   rng_step:   Philox step index of the observation (0 at reset, k after the k-th step)
     //   ctrl_step:  ctrl_step_counter seen by impulse/step disturbances (pre-increment value)
-    __device__ static __forceinline__ void write_obs(const DevParams<T>* __restrict__ P, const T* goal_tab, const T* st,
+    __device__ static __forceinline__ void write_obs(const PV<T>& P, const GoalTab<T>& goal_tab, const T* st,
                                                      const E& e, RngKey key, int next_index, uint32_t rng_step,
                                                      int32_t ctrl_step, int env_index, T* dst) {
         T o[D::NX];
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) o[k] = st[k];
         if constexpr (DIST) {
-            if (P->n_dist[SCG_CH_OBSERVATION] > 0)
+            if (P.c.n_dist[SCG_CH_OBSERVATION] > 0)
                 apply_disturbances<T, D::NX>(P, SCG_CH_OBSERVATION, o, D::NX, key, e.gid, e.episode, rng_step, ctrl_step, env_index);
         }
         if constexpr (SYS == SCG_CARTPOLE) {
-            if (P->obs_wrap_angle) o[2] = normalize_angle(o[2]);
+            if (P.c.obs_wrap_angle) o[2] = normalize_angle(o[2]);
         }
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
-        const int h = P->obs_goal_horizon;
-        if (h > 0 && P->cost == SCG_COST_RL_REWARD) {
-            if (P->task == SCG_TASK_TRAJ_TRACKING) {
-                const int last = P->goal_rows - 1;
+        const int h = P.c.obs_goal_horizon;
+        if (h > 0 && P.c.cost == SCG_COST_RL_REWARD) {
+            if (P.c.task == SCG_TASK_TRAJ_TRACKING) {
+                const int last = P.c.goal_rows - 1;
                 for (int r = 0; r < h; ++r) {
                     int row = next_index + r; row = row > last ? last : row;
 #pragma unroll
@@ -404,33 +436,35 @@ struct EnvOps {
 
     // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset
     // (written densely at rows 0..n_state-1).  c_out may be null; `stride` = distance between rows.
-    __device__ static __forceinline__ bool constraints(const DevParams<T>* __restrict__ P, const T* st, const T* act,
+    __device__ static __forceinline__ bool constraints(const PV<T>& P, const T* st, const T* act,
                                                        T* c_out, size_t stride, bool only_state) {
         bool viol = false;
-        // (1) box rows, grouped by variable: static register index, uniform trip counts
+        // (1) box rows: flat, unrolled so the row loads are all in flight together; the constrained
+        //     variable is picked from registers with a select chain (no dependent memory round trips)
+        const int nb = only_state ? P.c.n_box_state_rows : P.c.n_box_rows;     // state slots come first
+SCG_BOX_UNROLL
+        for (int r = 0; r < nb; ++r) {
+            const BoxRow<T> br = P.c.box[r];
+            const int fl = br.packed >> 16;
+            const int slot = (br.packed >> 24) & 0x1f;
+            T val = (T)0;
 #pragma unroll
-        for (int v = 0; v < D::NX + D::NU; ++v) {
-            if (only_state && v >= D::NX) break;
-            const T val = v < D::NX ? st[v < D::NX ? v : 0] : act[v >= D::NX ? v - D::NX : 0];
-            const int b0 = P->bv_first[v < D::NX ? v : SCG_MAX_STATE + (v - D::NX)];
-            const int b1 = P->bv_first[(v < D::NX ? v : SCG_MAX_STATE + (v - D::NX)) + 1];
-            for (int r = b0; r < b1; ++r) {
-                const int fl = P->bv_flags[r];
-                T c = (fl & 2) ? (m_abs(val) - P->bv_b[r]) : (P->bv_sign[r] * val - P->bv_b[r]);
-                const T rs = P->bv_round[r];
-                if (rs > (T)0) c = m_rint(c * rs) * P->bv_inv_round[r];
-                viol = viol || ((fl & 1) ? (c >= (T)0) : (c > (T)0));
-                if (c_out) c_out[(size_t)(only_state ? P->bv_state_pos[r] : P->bv_row[r]) * stride] = c;
-            }
+            for (int k = 0; k < D::NX; ++k) val = (slot == k) ? st[k] : val;
+#pragma unroll
+            for (int k = 0; k < D::NU; ++k) val = (slot == SCG_MAX_STATE + k) ? act[k] : val;
+            T c = (fl & 2) ? (m_abs(val) - br.b) : (((fl & 4) ? -val : val) - br.b);
+            if (P.c.box_round > (T)0) c = m_rint(c * P.c.box_round) * P.c.box_inv_round;
+            viol = viol || ((fl & 1) ? (c >= (T)0) : (c > (T)0));
+            if (c_out) c_out[(size_t)(only_state ? ((br.packed >> 8) & 0xff) : (br.packed & 0xff)) * stride] = c;
         }
         // (2) dense / quadratic rows
-        if (P->n_generic_rows > 0) {
+        if (P.c.n_generic_rows > 0) {
             int state_pos = 0;
-            for (int r = 0; r < P->n_con_rows; ++r) {
-                const DevRow<T>& row = P->con[r];
+            for (int r = 0; r < P.c.n_con_rows; ++r) {
+                const DevRow<T>& row = P.i.cold->con[r];
                 const int my_state_pos = state_pos;
                 if (row.var == 0) ++state_pos;
-                if (row.kind == SCG_ROW_SPARSE || row.kind == SCG_ROW_ABS) continue;
+                if (row.is_box) continue;
                 if (only_state && row.var != 0) continue;
                 T c = (T)0;
                 if (row.kind == SCG_ROW_DENSE) {
@@ -442,7 +476,7 @@ struct EnvOps {
                         for (int k = 0; k < D::NU; ++k) c += row.coef[k] * act[k];
                     }
                 } else {   // quadratic: v' P v over the state (or input) vector
-                    const T* Pm = P->quad_P[row.index];
+                    const T* Pm = P.i.cold->quad_P[row.index];
                     if (row.var == 0) {
 #pragma unroll
                         for (int a = 0; a < D::NX; ++a) {
@@ -474,7 +508,7 @@ struct EnvOps {
 
     // One control step, no auto-reset.  `act_in` = raw controller action; `adv` = adversary action or null.
     // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
-    __device__ static __forceinline__ StepResult step(const DevParams<T>* __restrict__ P, const T* goal_tab, E& e,
+    __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,
                                                       T* st, T* noisy_out, T* c_out, size_t c_stride) {
         const int32_t c0 = e.step;      // ctrl_step_counter before the increment
@@ -483,9 +517,9 @@ struct EnvOps {
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) {
             T a = act_in[j];
-            if (P->normalized_action) {
-                if constexpr (IS_QUAD) a = ((T)1 + P->act_scale * a) * P->hover_thrust;
-                else a = P->act_scale * a;
+            if (P.c.normalized_action) {
+                if constexpr (IS_QUAD) a = ((T)1 + P.c.act_scale * a) * P.c.hover_thrust;
+                else a = P.c.act_scale * a;
             }
             noisy[j] = a;
         }
@@ -495,42 +529,43 @@ struct EnvOps {
         for (int j = 0; j < D::DYN; ++j) fd[j] = (T)0;
         bool has_dyn = false;
         if constexpr (DIST) {
-            if (P->n_dist[SCG_CH_ACTION] > 0)
+            if (P.c.n_dist[SCG_CH_ACTION] > 0)
                 apply_disturbances<T, D::NU>(P, SCG_CH_ACTION, noisy, D::NU, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
-            if (P->adversary_channel == SCG_CH_ACTION && adv) {
+            if (P.c.adversary_channel == SCG_CH_ACTION && adv) {
 #pragma unroll
                 for (int j = 0; j < D::NU; ++j) noisy[j] += adv[j];
             }
-            has_dyn = (P->n_dist[SCG_CH_DYNAMICS] > 0) || (P->adversary_channel == SCG_CH_DYNAMICS);
-            if (P->n_dist[SCG_CH_DYNAMICS] > 0)
+            has_dyn = (P.c.n_dist[SCG_CH_DYNAMICS] > 0) || (P.c.adversary_channel == SCG_CH_DYNAMICS);
+            if (P.c.n_dist[SCG_CH_DYNAMICS] > 0)
                 apply_disturbances<T, D::DYN>(P, SCG_CH_DYNAMICS, fd, D::DYN, key, e.gid, e.episode, (uint32_t)c0, c0, env_index);
-            if (P->adversary_channel == SCG_CH_DYNAMICS && adv) {
+            if (P.c.adversary_channel == SCG_CH_DYNAMICS && adv) {
 #pragma unroll
                 for (int j = 0; j < D::DYN; ++j) fd[j] += adv[j];
             }
         }
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) {
-            clipped[j] = m_clamp(noisy[j], P->act_low[j], P->act_high[j]);
+            clipped[j] = m_clamp(noisy[j], P.c.act_low[j], P.c.act_high[j]);
             if (noisy_out) noisy_out[j] = noisy[j];
         }
         // ---- physics
-        const T h = P->pyb_dt;
-        const T vmax = P->vmax;
-        // |h * angular rate| <= h * vmax: Taylor rotations are exact to < 1 ulp below 0.125 rad
-        const bool small_angle = h * vmax * (T)1.7320508 <= (T)0.125;
+        const T h = P.c.pyb_dt;
+        const T vmax = P.c.vmax;
+        // Taylor rotations are exact to < 1 ulp below 0.125 rad.  Planar systems rotate by d = h*w with
+        // |w| <= vmax (Bullet's clamp); the 3-D exponential map uses the half angle |w| h / 2, |w| <= sqrt(3) vmax.
+        const bool small_angle = (SYS == SCG_QUAD_3D) ? (h * vmax * (T)0.8660254 <= (T)0.125) : (h * vmax <= (T)0.125);
         if constexpr (SYS == SCG_CARTPOLE) {
             const T force = clipped[0];
             const T l = e.par[0], M = e.par[1], m = e.par[2];
             // Bullet recomputes the pole inertia from its collision box (see oracle/bullet.py::pole_inertia).
             const T two_l = (T)2 * l;
-            const T ip = m * (P->pole_box_width * P->pole_box_width + two_l * two_l) * (T)(1.0 / 12.0);
+            const T ip = m * (P.c.pole_box_width * P.c.pole_box_width + two_l * two_l) * (T)(1.0 / 12.0);
             const T a11 = M + m, a22 = ip + m * l * l, ml = m * l;
-            const T mgl = m * P->gravity * l;
+            const T mgl = m * P.c.gravity * l;
             T x = e.s[0], xd = e.s[1], th = e.s[2], thd = e.s[3];
             T sn, cs;
             m_sincos(th, &sn, &cs);
-            for (int k = 0; k < P->substeps; ++k) {
+            for (int k = 0; k < P.c.substeps; ++k) {
                 if (!small_angle) m_sincos(th, &sn, &cs);
                 const T a12 = ml * cs;
                 T b1 = force + ml * thd * thd * sn;
@@ -562,27 +597,27 @@ struct EnvOps {
 #pragma unroll
             for (int j = 0; j < D::NU; ++j) {
                 T thr = m_max(clipped[j], (T)0);
-                pwm[j] = (m_sqrt(thr / (T)n_motor / P->kf) - P->pwm2rpm_const) / P->pwm2rpm_scale;
+                pwm[j] = (m_sqrt(thr / (T)n_motor / P.c.kf) - P.c.pwm2rpm_const) / P.c.pwm2rpm_scale;
             }
             if constexpr (D::NU == 1) { pwm[1] = pwm[0]; pwm[2] = pwm[0]; pwm[3] = pwm[0]; }
             if constexpr (D::NU == 2) { pwm[2] = pwm[1]; pwm[3] = pwm[0]; }
             T f[4], tq[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                T p = m_clamp(pwm[j], P->pwm_min, P->pwm_max);
-                T rpm = P->pwm2rpm_scale * p + P->pwm2rpm_const;
-                f[j] = rpm * rpm * P->kf;
-                tq[j] = rpm * rpm * P->km;
+                T p = m_clamp(pwm[j], P.c.pwm_min, P.c.pwm_max);
+                T rpm = P.c.pwm2rpm_scale * p + P.c.pwm2rpm_const;
+                f[j] = rpm * rpm * P.c.kf;
+                tq[j] = rpm * rpm * P.c.km;
             }
             const T thrust = f[0] + f[1] + f[2] + f[3];
             const T mass = e.par[0];
             const T inv_m = (T)1 / mass;
-            const T g = P->gravity;
-            const T arm = P->arm;
+            const T g = P.c.gravity;
+            const T arm = P.c.arm;
             if constexpr (SYS == SCG_QUAD_1D) {
                 T z = e.s[0], vz = e.s[1];
                 const T az = thrust / mass - g + (has_dyn ? fd[0] / mass : (T)0);
-                for (int k = 0; k < P->substeps; ++k) {
+                for (int k = 0; k < P.c.substeps; ++k) {
                     vz = m_clamp(vz + h * az, -vmax, vmax);
                     z += h * vz;
                 }
@@ -598,7 +633,7 @@ struct EnvOps {
                 const T fxm = fx * inv_m, fzm = fz * inv_m - g;
                 T sn, cs;
                 m_sincos(th, &sn, &cs);
-                for (int k = 0; k < P->substeps; ++k) {
+                for (int k = 0; k < P.c.substeps; ++k) {
                     if (!small_angle) m_sincos(th, &sn, &cs);
                     T tau = tau_prop;
                     if constexpr (DIST) {
@@ -633,7 +668,7 @@ struct EnvOps {
                 T w[3] = {e.s[10], e.s[11], e.s[12]};
                 const T p0[3] = {p[0], p[1], p[2]};
                 const T hh = (T)0.5 * h;
-                for (int k = 0; k < P->substeps; ++k) {
+                for (int k = 0; k < P.c.substeps; ++k) {
                     T R[3][3];
                     quat_to_mat(q, R);
                     T t0 = tb0, t1 = tb1, t2 = tb2;
@@ -695,37 +730,37 @@ struct EnvOps {
 
         // ---- reference row for reward / mse (tracking: X_GOAL[min(c+1, L-1)])
         T ref[D::NX];
-        const bool tracking = P->task == SCG_TASK_TRAJ_TRACKING;
+        const bool tracking = P.c.task == SCG_TASK_TRAJ_TRACKING;
         {
             int row = 0;
-            if (tracking) { row = c0 + 1; const int last = P->goal_rows - 1; row = row > last ? last : row; }
+            if (tracking) { row = c0 + 1; const int last = P.c.goal_rows - 1; row = row > last ? last : row; }
 #pragma unroll
             for (int k = 0; k < D::NX; ++k) ref[k] = goal_tab[row * D::NX + k];
         }
         // ---- _get_reward
         T rew;
-        if (P->cost == SCG_COST_RL_REWARD) {
+        if (P.c.cost == SCG_COST_RL_REWARD) {
             T dist = (T)0;
 #pragma unroll
             for (int k = 0; k < D::NX; ++k) {
                 T sv = st[k];
                 if constexpr (SYS == SCG_CARTPOLE) { if (k == 2) sv = normalize_angle(sv); }   // cartpole.py:619-620
                 const T err = sv - ref[k];
-                dist += P->rew_state_weight[k] * err * err;
+                dist += P.c.rew_state_weight[k] * err * err;
             }
 #pragma unroll
             for (int j = 0; j < D::NU; ++j) {
-                const T ae = noisy[j] - P->u_goal[j];      // unclipped noisy action (quadrotor.py:828); cartpole U_GOAL = 0
-                dist += P->rew_act_weight[j] * ae * ae;
+                const T ae = noisy[j] - P.c.u_goal[j];      // unclipped noisy action (quadrotor.py:828); cartpole U_GOAL = 0
+                dist += P.c.rew_act_weight[j] * ae * ae;
             }
-            rew = P->rew_exponential ? m_exp(-dist) : -dist;
+            rew = P.c.rew_exponential ? m_exp(-dist) : -dist;
         } else {
             // quadratic cost with diagonal Q, R (lqr_utils.py:77-99) and the CLIPPED action.
             T xr[D::NX];
             if (tracking) {
                 // quadrotor: X_GOAL[c+1] (quadrotor.py:858); cartpole: X_GOAL[c] (cartpole.py:648); no clamping upstream
                 int row = (SYS == SCG_CARTPOLE) ? c0 : c0 + 1;
-                const int last = P->goal_rows - 1; row = row > last ? last : row;
+                const int last = P.c.goal_rows - 1; row = row > last ? last : row;
 #pragma unroll
                 for (int k = 0; k < D::NX; ++k) xr[k] = goal_tab[row * D::NX + k];
             } else {
@@ -734,9 +769,9 @@ struct EnvOps {
             }
             T cst = (T)0;
 #pragma unroll
-            for (int k = 0; k < D::NX; ++k) { const T err = st[k] - xr[k]; cst += (T)0.5 * P->q_diag[k] * err * err; }
+            for (int k = 0; k < D::NX; ++k) { const T err = st[k] - xr[k]; cst += (T)0.5 * P.c.q_diag[k] * err * err; }
 #pragma unroll
-            for (int j = 0; j < D::NU; ++j) { const T du = clipped[j] - P->u_goal[j]; cst += (T)0.5 * P->r_diag[j] * du * du; }
+            for (int j = 0; j < D::NU; ++j) { const T du = clipped[j] - P.c.u_goal[j]; cst += (T)0.5 * P.c.r_diag[j] * du * du; }
             rew = -cst;
         }
         // ---- _get_done
@@ -747,27 +782,27 @@ struct EnvOps {
             T n2 = (T)0;
 #pragma unroll
             for (int k = 0; k < D::NX; ++k) { const T err = st[k] - ref[k]; n2 += err * err; }
-            goal = m_sqrt(n2) < P->goal_tolerance;
+            goal = m_sqrt(n2) < P.c.goal_tolerance;
             done = goal;
-            if (goal && P->info_goal_reached) flags |= FLAG_GOAL;
+            if (goal && P.c.info_goal_reached) flags |= FLAG_GOAL;
         }
-        if (P->done_on_oob) {
+        if (P.c.done_on_oob) {
             bool oob = false;
             if constexpr (SYS == SCG_CARTPOLE) {
-                oob = st[0] < -P->x_threshold || st[0] > P->x_threshold || st[2] < -P->theta_threshold || st[2] > P->theta_threshold;
+                oob = st[0] < -P.c.x_threshold || st[0] > P.c.x_threshold || st[2] < -P.c.theta_threshold || st[2] > P.c.theta_threshold;
             } else {
                 // positions + angles only (quadrotor.py:878-888)
 #pragma unroll
                 for (int k = 0; k < D::NX; ++k) {
                     const bool masked = (SYS == SCG_QUAD_3D) ? ((k < 6 && (k & 1) == 0) || (k >= 6 && k < 9)) : ((k & 1) == 0);
-                    if (masked) oob = oob || st[k] < P->state_low[k] || st[k] > P->state_high[k];
+                    if (masked) oob = oob || st[k] < P.c.state_low[k] || st[k] > P.c.state_high[k];
                 }
             }
             if (!tracking) {
                 // stale `self.out_of_bounds` on goal_reached steps (see oracle/envs.py::_stale_oob)
-                const bool prev = P->oob_attr[env_index] != 0;
+                const bool prev = P.i.oob_attr[env_index] != 0;
                 oob = goal ? prev : oob;
-                P->oob_attr[env_index] = oob ? 1 : 0;
+                P.i.oob_attr[env_index] = oob ? 1 : 0;
             }
             if (oob) flags |= FLAG_OOB;
             done = done || (oob && !goal);
@@ -782,27 +817,27 @@ struct EnvOps {
                 if constexpr (SYS == SCG_QUAD_2D) { if (k == 4) sv = normalize_angle(sv); }
                 if constexpr (SYS == SCG_QUAD_3D) { if (k >= 6 && k < 9) sv = normalize_angle(sv); }
             }
-            const T err = (sv - ref[k]) * P->mse_weight[k];
+            const T err = (sv - ref[k]) * P.c.mse_weight[k];
             mse += err * err;
         }
         // ---- after_step
         e.step = c0 + 1;
         bool viol = false;
-        if (P->n_con_rows > 0) {
+        if (P.c.n_con_rows > 0) {
             viol = constraints(P, st, noisy, c_out, c_stride, false);
             if (viol) {
                 flags |= FLAG_VIOLATION;
-                if (P->done_on_violation) {
+                if (P.c.done_on_violation) {
                     done = true;
-                    if (P->cost == SCG_COST_RL_REWARD && P->use_penalty) rew = (T)0;
+                    if (P.c.cost == SCG_COST_RL_REWARD && P.c.use_penalty) rew = (T)0;
                 }
             }
-            if (P->cost == SCG_COST_RL_REWARD && P->use_penalty && viol) {
-                if (P->rew_exponential) rew = m_exp(m_log(rew) - P->constraint_penalty);
-                else rew -= P->constraint_penalty;
+            if (P.c.cost == SCG_COST_RL_REWARD && P.c.use_penalty && viol) {
+                if (P.c.rew_exponential) rew = m_exp(m_log(rew) - P.c.constraint_penalty);
+                else rew -= P.c.constraint_penalty;
             }
         }
-        if (e.step >= P->ctrl_steps) {
+        if (e.step >= P.c.ctrl_steps) {
             if (!done) flags |= FLAG_TRUNCATED;
             done = true;
         }

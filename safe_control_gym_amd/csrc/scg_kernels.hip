@@ -1,14 +1,10 @@
-// scg_kernels.hip — gfx950 kernels + the C ABI of libscg_hip.so (include/scg_hip.h).
+// scg_kernels.hip — the C ABI of libscg_hip.so (include/scg_hip.h) + kernel dispatch.
 //
-// Kernel geometry (CDNA4: 64-lane waves, 256 CUs in 8 XCDs, 160 KB LDS/CU):
-//   * one thread = one environment; 256-thread workgroups (4 waves, one per SIMD of a CU);
-//   * raw simulator state is SoA ([component][env]) so each wave's loads/stores are 256 contiguous bytes;
-//   * the X_GOAL reference table and nothing else is shared between lanes: it is staged once per
-//     workgroup into LDS (rows are indexed by each env's own step counter after de-synchronised
-//     resets, so a scalar/broadcast path is not enough);
-//   * the whole control step (action pre-processing, disturbance draws, PYB_FREQ/CTRL_FREQ integrator
-//     substeps, observation/reward/done/info/constraints, episode statistics, auto-reset) is ONE launch;
-//   * no MFMA: there is no dense contraction on this path, the bound is HBM bandwidth.
+// Built two ways from the same sources:
+//   hipcc ... scg_kernels.hip                              -> libscg_hip.so (any config, parameters staged in LDS)
+//   hipcc ... -DSCG_SPEC -include <generated>.h scg_kernels.hip
+//                                                          -> libscg_spec_<hash>.so: one task config baked in as
+//                                                             compile-time constants (see emit_spec_source below)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -19,9 +15,13 @@
 #include <vector>
 
 #include "../../include/scg_hip.h"
-#include "scg_env_core.h"
 #include "scg_params.h"
 #include "scg_rng.h"
+#ifdef SCG_SPEC
+#include "scg_spec.h"
+#endif
+#include "scg_env_kernels.h"
+#include "scg_gae_kernels.h"
 
 using namespace scg;
 
@@ -40,257 +40,6 @@ extern "C" int scg_abi_version(void) { return SCG_ABI_VERSION; }
 extern "C" size_t scg_sizeof_config(void) { return sizeof(scg_config); }
 extern "C" size_t scg_sizeof_step_out(void) { return sizeof(scg_step_out); }
 
-constexpr int BLOCK = 256;
-constexpr size_t LDS_GOAL_LIMIT = 64 * 1024;
-
-// ------------------------------------------------------------------ kernels
-template <typename T>
-__device__ __forceinline__ const T* stage_goal(const DevParams<T>* __restrict__ P, unsigned char* smem) {
-    if (!P->goal_in_lds) return P->x_goal;
-    T* tab = reinterpret_cast<T*>(smem);
-    const int n = P->goal_rows * P->nx;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) tab[k] = P->x_goal[k];
-    __syncthreads();
-    return tab;
-}
-
-template <int SYS, typename T, bool DIST>
-__global__ __launch_bounds__(BLOCK) void reset_kernel(const DevParams<T>* __restrict__ P,
-                                                      const uint8_t* __restrict__ mask, StepOut<T> O) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    using Ops = EnvOps<SYS, T, DIST>;
-    using D = Dims<SYS>;
-    const T* goal = stage_goal(P, smem);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P->num_envs) return;
-    if (mask && !mask[i]) return;
-    const RngKey key{P->key0, P->key1};
-    typename Ops::E e;
-    Ops::load(P, i, e);
-    Ops::reset(P, i, e, key);
-    T st[D::NX];
-    Ops::state_vector(e, st);
-    if (O.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, O.obs + (size_t)i * P->nobs);
-    if (O.c_values && P->n_state_con_rows > 0) Ops::constraints(P, st, st, O.c_values + i, (size_t)P->num_envs, true);
-    if (O.state) {
-#pragma unroll
-        for (int k = 0; k < D::NX; ++k) O.state[(size_t)k * P->num_envs + i] = st[k];
-    }
-    if (O.ep_return) O.ep_return[i] = (T)0;
-    if (O.ep_length) O.ep_length[i] = 0;
-    if (O.ep_violation) O.ep_violation[i] = (T)0;
-    if (O.ep_mse) O.ep_mse[i] = (T)0;
-    if (P->oob_attr) P->oob_attr[i] = 0;
-    Ops::store(P, i, e, true);
-}
-
-template <int SYS, typename T, bool DIST>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const DevParams<T>* __restrict__ P, const T* __restrict__ action,
-                                                     const T* __restrict__ adv, StepOut<T> O) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    using Ops = EnvOps<SYS, T, DIST>;
-    using D = Dims<SYS>;
-    const T* goal = stage_goal(P, smem);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = P->num_envs;
-    if (i >= N) return;
-    const RngKey key{P->key0, P->key1};
-    typename Ops::E e;
-    Ops::load(P, i, e);
-    T act[D::NU];
-#pragma unroll
-    for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];
-    T advv[D::DYN > D::NU ? D::DYN : D::NU];
-    const T* advp = nullptr;
-    if (adv && P->adversary_channel >= 0) {
-        const int ad = P->adversary_channel == SCG_CH_ACTION ? D::NU : D::DYN;
-        for (int j = 0; j < ad; ++j) advv[j] = adv[(size_t)i * ad + j];
-        advp = advv;
-    }
-    T st[D::NX], noisy[D::NU];
-    const int32_t c0 = e.step;
-    typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy,
-                                           O.c_values ? O.c_values + i : nullptr, (size_t)N);
-    if (O.reward) O.reward[i] = r.reward;
-    if (O.done) O.done[i] = r.done ? 1 : 0;
-    if (O.flags) O.flags[i] = r.flags;
-    if (O.mse) O.mse[i] = r.mse;
-    if (O.noisy_action) {
-#pragma unroll
-        for (int j = 0; j < D::NU; ++j) O.noisy_action[(size_t)j * N + i] = noisy[j];
-    }
-    // columnar VecRecordEpisodeStatistics (record_episode_statistics.py:139-166)
-    if (O.ep_return) {
-        const T acc = O.ep_return[i] + r.reward;
-        if (r.done && O.fin_return) O.fin_return[i] = acc;
-        O.ep_return[i] = r.done ? (T)0 : acc;
-    }
-    if (O.ep_length) {
-        const int32_t acc = O.ep_length[i] + 1;
-        if (r.done && O.fin_length) O.fin_length[i] = acc;
-        O.ep_length[i] = r.done ? 0 : acc;
-    }
-    if (O.ep_violation) {
-        const T acc = O.ep_violation[i] + ((r.flags & FLAG_VIOLATION) ? (T)1 : (T)0);
-        if (r.done && O.fin_violation) O.fin_violation[i] = acc;
-        O.ep_violation[i] = r.done ? (T)0 : acc;
-    }
-    if (O.ep_mse) {
-        const T acc = O.ep_mse[i] + r.mse;
-        if (r.done && O.fin_mse) O.fin_mse[i] = acc;
-        O.ep_mse[i] = r.done ? (T)0 : acc;
-    }
-    // observation of the step: terminal_observation where done, else the returned obs
-    const bool do_reset = r.done && P->auto_reset;
-    if (r.done && !P->auto_reset && O.terminal_obs)
-        Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, O.terminal_obs + (size_t)i * P->nobs);
-    if (do_reset) {
-        if (O.terminal_obs) Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, O.terminal_obs + (size_t)i * P->nobs);
-        Ops::reset(P, i, e, key);               // auto-reset (dummy_vec_env.py:33-38)
-        Ops::state_vector(e, st);
-        if (O.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, O.obs + (size_t)i * P->nobs);
-    } else {
-        if (O.obs) Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, O.obs + (size_t)i * P->nobs);
-    }
-    if (O.state) {
-#pragma unroll
-        for (int k = 0; k < D::NX; ++k) O.state[(size_t)k * N + i] = st[k];
-    }
-    Ops::store(P, i, e, do_reset);
-}
-
-template <int SYS, typename T, bool DIST>
-__global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const DevParams<T>* __restrict__ P, int k_steps,
-                                                               T* __restrict__ reward_sum, int32_t* __restrict__ done_count,
-                                                               int32_t* __restrict__ violation_count, T* __restrict__ last_obs) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    using Ops = EnvOps<SYS, T, DIST>;
-    using D = Dims<SYS>;
-    const T* goal = stage_goal(P, smem);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P->num_envs) return;
-    const RngKey key{P->key0, P->key1};
-    typename Ops::E e;
-    Ops::load(P, i, e);
-    T rsum = (T)0;
-    int32_t dones = 0, viols = 0;
-    bool dirty = false;
-    T st[D::NX];
-    for (int k = 0; k < k_steps; ++k) {
-        // actions ~ U(-1, 1): Philox channel 4, item 0, word j
-        U4 w = rng_words(key, e.gid, e.episode, (uint32_t)e.step, rng_tag(RNG_CH_RANDOM_ACTION, 0, 0));
-        T act[D::NU], noisy[D::NU];
-#pragma unroll
-        for (int j = 0; j < D::NU; ++j) act[j] = (T)-1 + (T)2 * u01<T>(u4_get(w, j));
-        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, nullptr, 0);
-        rsum += r.reward;
-        viols += (r.flags & FLAG_VIOLATION) ? 1 : 0;
-        if (r.done) {
-            ++dones;
-            if (P->auto_reset) {
-                dirty = true;
-                Ops::reset(P, i, e, key);
-                Ops::state_vector(e, st);
-            }
-        }
-    }
-    if (reward_sum) reward_sum[i] = rsum;
-    if (done_count) done_count[i] = dones;
-    if (violation_count) violation_count[i] = viols;
-    if (last_obs) {
-        const bool fresh = e.step == 0;
-        const int32_t c0 = e.step - 1;
-        Ops::write_obs(P, goal, st, e, key, fresh ? 1 : c0 + 2, fresh ? 0u : (uint32_t)(c0 + 1), fresh ? 0 : c0, i,
-                       last_obs + (size_t)i * P->nobs);
-    }
-    Ops::store(P, i, e, dirty);
-}
-
-// ---- GAE / returns (controllers/ppo/ppo_utils.py:374-400), buffers [T][N] -------------------------
-// (a) one thread per env walking T backwards: every load/store is coalesced across the wave.
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void gae_env_kernel(T* __restrict__ rew, const T* __restrict__ v, const T* __restrict__ mask,
-                                                        const T* __restrict__ term_v, const T* __restrict__ last_v,
-                                                        T* __restrict__ ret, T* __restrict__ adv, int Tn, int N, T gamma,
-                                                        T lam, int use_gae) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    T run_ret = last_v[n], run_adv = (T)0, v_next = last_v[n];
-    for (int t = Tn - 1; t >= 0; --t) {
-        const size_t idx = (size_t)t * N + n;
-        T r = rew[idx];
-        if (term_v) { r += gamma * term_v[idx]; rew[idx] = r; }
-        const T m = mask[idx], vt = v[idx];
-        run_ret = r + gamma * m * run_ret;
-        if (use_gae) {
-            const T delta = r + gamma * m * v_next - vt;
-            run_adv = run_adv * lam * gamma * m + delta;
-        } else {
-            run_adv = run_ret - vt;
-        }
-        ret[idx] = run_ret;
-        adv[idx] = run_adv;
-        v_next = vt;
-    }
-}
-
-// (b) small N (the reference's own shape, T=1000 x N=4): one 64-lane wave per env, segmented affine scan
-// over time.  Each element is the map x -> a x + b; (a,b) o (a',b') = (a a', b + a b'); mask = 0 gives a = 0,
-// i.e. the segment boundary.  Lane L of a chunk holds time t_hi - L, so an inclusive scan along the lanes
-// composes the maps in the order the sequential recursion applies them.
-template <typename T>
-__device__ __forceinline__ void affine_scan64(T& a, T& b) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const T pa = __shfl_up(a, off, 64), pb = __shfl_up(b, off, 64);
-        if (lane >= off) { b = a * pb + b; a = a * pa; }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void gae_wave_kernel(T* __restrict__ rew, const T* __restrict__ v, const T* __restrict__ mask,
-                                                      const T* __restrict__ term_v, const T* __restrict__ last_v,
-                                                      T* __restrict__ ret, T* __restrict__ adv, int Tn, int N, T gamma, T lam,
-                                                      int use_gae) {
-    const int n = blockIdx.x;
-    const int lane = threadIdx.x;
-    T carry_ret = last_v[n], carry_adv = (T)0, carry_v = last_v[n];
-    for (int t_hi = Tn - 1; t_hi >= 0; t_hi -= 64) {
-        const int t = t_hi - lane;
-        const bool live = t >= 0;
-        const size_t idx = live ? (size_t)t * N + n : 0;
-        T r = (T)0, m = (T)1, vt = (T)0;
-        if (live) {
-            r = rew[idx];
-            if (term_v) { r += gamma * term_v[idx]; rew[idx] = r; }
-            m = mask[idx];
-            vt = v[idx];
-        }
-        T v_next = __shfl_up(vt, 1, 64);
-        if (lane == 0) v_next = carry_v;
-        // returns: ret_t = r_t + (gamma m_t) ret_{t+1}
-        T a1 = live ? gamma * m : (T)1, b1 = live ? r : (T)0;
-        affine_scan64(a1, b1);
-        const T my_ret = a1 * carry_ret + b1;
-        T my_adv;
-        if (use_gae) {
-            const T delta = r + gamma * m * v_next - vt;
-            T a2 = live ? lam * gamma * m : (T)1, b2 = live ? delta : (T)0;
-            affine_scan64(a2, b2);
-            my_adv = a2 * carry_adv + b2;
-        } else {
-            my_adv = my_ret - vt;
-        }
-        if (live) { ret[idx] = my_ret; adv[idx] = my_adv; }
-        // carry = value at the earliest time of this chunk = last live lane
-        const int last_lane = t_hi >= 63 ? 63 : t_hi;
-        carry_ret = __shfl(my_ret, last_lane, 64);
-        carry_adv = __shfl(my_adv, last_lane, 64);
-        carry_v = __shfl(vt, last_lane, 64);
-    }
-}
-
 // ------------------------------------------------------------------ host side
 struct scg_env {
     scg_config cfg;
@@ -299,7 +48,10 @@ struct scg_env {
     int nx, nu, nobs, ns, np;
     int n_offset_slots;
     size_t lds_bytes;
-    void* d_params;          // DevParams<T> on device
+    bool goal_in_lds;
+    int goal_lds16;
+    void* d_params;          // DevParams<T> (cold block) on device
+    void* d_cfg;             // CfgParams<T> on device (generic build: staged into LDS by every workgroup)
     void* d_goal;            // X_GOAL table on device
     // workspace partition (device pointers)
     void* d_state;
@@ -391,6 +143,13 @@ extern "C" int scg_workspace_bytes(const scg_config* cfg, size_t* bytes) {
     return SCG_OK;
 }
 
+
+// A constraint row is served by the hot box table when it is a +-1 sparse row or an abs row and shares the
+// common rounding scale; every other row goes through the generic loop.
+static bool row_is_box(const scg_con_row& row, double common_round) {
+    const bool boxk = row.kind == SCG_ROW_SPARSE || row.kind == SCG_ROW_ABS;
+    return boxk && row.round_scale == common_round && (row.kind == SCG_ROW_ABS || row.sign == 1.0 || row.sign == -1.0);
+}
 template <typename T>
 static void fill_params(const scg_env* e, const scg_config& c, DevParams<T>& p) {
     std::memset(&p, 0, sizeof(p));
@@ -402,7 +161,7 @@ static void fill_params(const scg_env* e, const scg_config& c, DevParams<T>& p) 
     p.done_on_violation = c.done_on_violation; p.use_penalty = c.use_constraint_penalty;
     p.obs_wrap_angle = c.obs_wrap_angle; p.normalized_action = c.normalized_action;
     p.info_goal_reached = c.info_goal_reached;
-    p.goal_in_lds = e->lds_bytes > 0;
+    p.goal_in_lds = e->goal_in_lds;
     p.nx = e->nx; p.nu = e->nu; p.nobs = e->nobs; p.ns = e->ns; p.np = e->np;
     p.per_env_params = c.randomized_inertial_prop;
     p.randomized_init = c.randomized_init;
@@ -452,6 +211,7 @@ static void fill_params(const scg_env* e, const scg_config& c, DevParams<T>& p) 
         const scg_con_row& s = c.con[r];
         DevRow<T>& d = p.con[r];
         d.kind = s.kind; d.var = s.var; d.index = s.index; d.strict = s.strict;
+        d.is_box = 0;
         d.sign = (T)s.sign; d.b = (T)s.b;
         // rounding to `decimals` places is only meaningful in double precision (np.round(., 8) on float64)
         const bool round = s.round_scale > 0 && sizeof(T) == 8;
@@ -461,56 +221,244 @@ static void fill_params(const scg_env* e, const scg_config& c, DevParams<T>& p) 
     }
     for (int q = 0; q < SCG_MAX_QUAD_CON; ++q)
         for (int j = 0; j < SCG_MAX_STATE * SCG_MAX_STATE; ++j) p.quad_P[q][j] = (T)c.quad_P[q][j];
-    // box rows regrouped by variable slot (state k -> k, input j -> SCG_MAX_STATE + j)
-    {
-        int n = 0, generic = 0;
-        std::vector<int> state_pos(c.n_con_rows, 0);
-        int sp = 0;
-        for (int r = 0; r < c.n_con_rows; ++r) { state_pos[r] = sp; if (c.con[r].var == 0) ++sp; }
-        for (int slot = 0; slot < SCG_MAX_STATE + SCG_MAX_ACTION; ++slot) {
-            p.bv_first[slot] = n;
-            const int var = slot < SCG_MAX_STATE ? 0 : 1, index = slot < SCG_MAX_STATE ? slot : slot - SCG_MAX_STATE;
-            for (int r = 0; r < c.n_con_rows; ++r) {
-                const DevRow<T>& d = p.con[r];
-                if ((d.kind == SCG_ROW_SPARSE || d.kind == SCG_ROW_ABS) && d.var == var && d.index == index) {
-                    p.bv_row[n] = r; p.bv_state_pos[n] = state_pos[r];
-                    p.bv_flags[n] = (d.strict ? 1 : 0) | (d.kind == SCG_ROW_ABS ? 2 : 0);
-                    p.bv_sign[n] = d.sign; p.bv_b[n] = d.b; p.bv_round[n] = d.round_scale; p.bv_inv_round[n] = d.inv_round_scale;
-                    ++n;
-                }
-            }
-        }
-        p.bv_first[SCG_MAX_STATE + SCG_MAX_ACTION] = n;
-        for (int r = 0; r < c.n_con_rows; ++r)
-            if (p.con[r].kind != SCG_ROW_SPARSE && p.con[r].kind != SCG_ROW_ABS) ++generic;
-        p.n_box_rows = n; p.n_generic_rows = generic;
-    }
     p.x_goal = (const T*)e->d_goal;
     p.state = (T*)e->d_state; p.param = (T*)e->d_param; p.step = e->d_step; p.episode = e->d_episode;
     p.dist_offset = e->d_dist_offset; p.oob_attr = e->d_oob;
 }
+
+
+// ---- hot configuration block -------------------------------------------------------------------
+// scg_config -> CfgParams<double>: the single place where the hot parameters are derived.
+static void build_cfg(const scg_config& c, CfgParams<double>& h) {
+    std::memset(&h, 0, sizeof(h));
+    int32_t nx, nu, nobs, ns, np;
+    scg_dims(&c, &nx, &nu, &nobs, &ns, &np);
+    h.substeps = c.substeps; h.ctrl_steps = c.ctrl_steps; h.task = c.task; h.cost = c.cost;
+    h.obs_goal_horizon = c.obs_goal_horizon; h.goal_rows = c.goal_rows; h.nobs = nobs; h.nx = nx;
+    h.rew_exponential = c.rew_exponential; h.done_on_oob = c.done_on_out_of_bound;
+    h.done_on_violation = c.done_on_violation; h.use_penalty = c.use_constraint_penalty;
+    h.obs_wrap_angle = c.obs_wrap_angle; h.normalized_action = c.normalized_action;
+    h.info_goal_reached = c.info_goal_reached;
+    h.goal_in_lds = (size_t)c.goal_rows * nx * elem_size(c.dtype) <= LDS_GOAL_LIMIT;
+    h.per_env_params = c.randomized_inertial_prop; h.randomized_init = c.randomized_init;
+    h.auto_reset = c.auto_reset; h.adversary_channel = c.adversary_channel;
+    h.n_con_rows = c.n_con_rows; h.n_state_con_rows = c.n_state_con_rows;
+    for (int k = 0; k < 3; ++k) h.n_dist[k] = c.n_dist[k];
+    h.pyb_dt = c.pyb_dt; h.goal_tolerance = c.goal_tolerance; h.constraint_penalty = c.constraint_penalty;
+    h.x_threshold = c.x_threshold; h.theta_threshold = c.theta_threshold; h.act_scale = c.act_scale;
+    h.hover_thrust = c.hover_thrust; h.kf = c.kf; h.km = c.km; h.pwm2rpm_scale = c.pwm2rpm_scale;
+    h.pwm2rpm_const = c.pwm2rpm_const; h.pwm_min = c.pwm_min; h.pwm_max = c.pwm_max; h.gravity = c.gravity;
+    h.arm = c.arm; h.vmax = c.max_coordinate_velocity; h.pole_box_width = c.pole_box_width;
+    for (int k = 0; k < SCG_MAX_STATE; ++k) {
+        h.rew_state_weight[k] = c.rew_state_weight[k]; h.q_diag[k] = c.q_diag[k]; h.mse_weight[k] = c.mse_weight[k];
+        h.state_low[k] = c.state_low[k]; h.state_high[k] = c.state_high[k]; h.init_state[k] = c.init_state[k];
+        h.init_rand[k].kind = c.init_rand[k].kind; h.init_rand[k].p0 = c.init_rand[k].p0; h.init_rand[k].p1 = c.init_rand[k].p1;
+    }
+    for (int k = 0; k < SCG_MAX_ACTION; ++k) {
+        h.rew_act_weight[k] = c.rew_act_weight[k]; h.r_diag[k] = c.r_diag[k]; h.u_goal[k] = c.u_goal[k];
+        h.act_low[k] = c.act_low[k]; h.act_high[k] = c.act_high[k];
+    }
+    for (int k = 0; k < SCG_MAX_PARAM; ++k) {
+        h.base_param[k] = c.base_param[k];
+        h.param_rand[k].kind = c.param_rand[k].kind; h.param_rand[k].p0 = c.param_rand[k].p0; h.param_rand[k].p1 = c.param_rand[k].p1;
+    }
+    // box rows (SPARSE with sign +-1, ABS) sharing one rounding scale, sorted by variable slot (state first)
+    double common = -1.0;
+    for (int r = 0; r < c.n_con_rows; ++r)
+        if (c.con[r].kind == SCG_ROW_SPARSE || c.con[r].kind == SCG_ROW_ABS) { common = c.con[r].round_scale; break; }
+    std::vector<int> state_pos(c.n_con_rows > 0 ? c.n_con_rows : 1, 0);
+    int sp = 0, n = 0;
+    for (int r = 0; r < c.n_con_rows; ++r) { state_pos[r] = sp; if (c.con[r].var == 0) ++sp; }
+    for (int slot = 0; slot < SCG_MAX_STATE + SCG_MAX_ACTION; ++slot) {
+        if (slot == SCG_MAX_STATE) h.n_box_state_rows = n;
+        const int var = slot < SCG_MAX_STATE ? 0 : 1, index = slot < SCG_MAX_STATE ? slot : slot - SCG_MAX_STATE;
+        for (int r = 0; r < c.n_con_rows; ++r) {
+            if (!row_is_box(c.con[r], common) || c.con[r].var != var || c.con[r].index != index) continue;
+            const scg_con_row& row = c.con[r];
+            const int flags = (row.strict ? 1 : 0) | (row.kind == SCG_ROW_ABS ? 2 : 0) | (row.sign < 0 ? 4 : 0);
+            h.box[n].packed = r | (state_pos[r] << 8) | (flags << 16) | (slot << 24);
+            h.box[n].b = row.b;
+            ++n;
+        }
+    }
+    h.n_box_rows = n;
+    h.n_generic_rows = c.n_con_rows - n;
+    h.box_round = common > 0 ? common : 0.0;
+    h.box_inv_round = common > 0 ? 1.0 / common : 0.0;
+}
+
+template <typename T>
+static void convert_cfg(const CfgParams<double>& d, CfgParams<T>& o) {
+    std::memset(&o, 0, sizeof(o));
+#define SCG_X(f) o.f = d.f;
+    SCG_CFG_INT_FIELDS(SCG_X)
+#undef SCG_X
+#define SCG_X(f, n) for (int k = 0; k < n; ++k) o.f[k] = d.f[k];
+    SCG_CFG_INT_ARRAYS(SCG_X)
+#undef SCG_X
+#define SCG_X(f) o.f = (T)d.f;
+    SCG_CFG_T_FIELDS(SCG_X)
+#undef SCG_X
+#define SCG_X(f, n) for (int k = 0; k < n; ++k) o.f[k] = (T)d.f[k];
+    SCG_CFG_T_ARRAYS(SCG_X)
+#undef SCG_X
+    for (int k = 0; k < SCG_MAX_PARAM; ++k) { o.param_rand[k].kind = d.param_rand[k].kind; o.param_rand[k].p0 = (T)d.param_rand[k].p0; o.param_rand[k].p1 = (T)d.param_rand[k].p1; }
+    for (int k = 0; k < SCG_MAX_STATE; ++k) { o.init_rand[k].kind = d.init_rand[k].kind; o.init_rand[k].p0 = (T)d.init_rand[k].p0; o.init_rand[k].p1 = (T)d.init_rand[k].p1; }
+    for (int k = 0; k < SCG_MAX_CON_ROWS; ++k) { o.box[k].packed = d.box[k].packed; o.box[k].b = (T)d.box[k].b; }
+    // np.round(., decimals) is only meaningful in double precision
+    if (sizeof(T) != 8) { o.box_round = (T)0; o.box_inv_round = (T)0; }
+}
+
+// ---- config specialisation: C++ source of a constexpr CfgParams<T> for this config ------------------
+static uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ULL;
+    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ULL; }
+    return h;
+}
+
+static std::string spec_body(const scg_config& c) {
+    CfgParams<double> h;
+    build_cfg(c, h);
+    std::string s;
+    char buf[256];
+    auto addi = [&](const char* name, long v) { std::snprintf(buf, sizeof buf, "    c.%s = %ld;\n", name, v); s += buf; };
+    auto addt = [&](const char* name, double v) { std::snprintf(buf, sizeof buf, "    c.%s = (T)%a;\n", name, v); s += buf; };
+#define SCG_X(f) addi(#f, (long)h.f);
+    SCG_CFG_INT_FIELDS(SCG_X)
+#undef SCG_X
+#define SCG_X(f, n) for (int k = 0; k < n; ++k) { std::snprintf(buf, sizeof buf, "    c.%s[%d] = %ld;\n", #f, k, (long)h.f[k]); s += buf; }
+    SCG_CFG_INT_ARRAYS(SCG_X)
+#undef SCG_X
+#define SCG_X(f) addt(#f, h.f);
+    SCG_CFG_T_FIELDS(SCG_X)
+#undef SCG_X
+#define SCG_X(f, n) for (int k = 0; k < n; ++k) { std::snprintf(buf, sizeof buf, "    c.%s[%d] = (T)%a;\n", #f, k, h.f[k]); s += buf; }
+    SCG_CFG_T_ARRAYS(SCG_X)
+#undef SCG_X
+    for (int k = 0; k < SCG_MAX_PARAM; ++k) {
+        std::snprintf(buf, sizeof buf, "    c.param_rand[%d].kind = %d; c.param_rand[%d].p0 = (T)%a; c.param_rand[%d].p1 = (T)%a;\n",
+                      k, h.param_rand[k].kind, k, h.param_rand[k].p0, k, h.param_rand[k].p1); s += buf;
+    }
+    for (int k = 0; k < SCG_MAX_STATE; ++k) {
+        std::snprintf(buf, sizeof buf, "    c.init_rand[%d].kind = %d; c.init_rand[%d].p0 = (T)%a; c.init_rand[%d].p1 = (T)%a;\n",
+                      k, h.init_rand[k].kind, k, h.init_rand[k].p0, k, h.init_rand[k].p1); s += buf;
+    }
+    for (int k = 0; k < h.n_box_rows; ++k) {
+        std::snprintf(buf, sizeof buf, "    c.box[%d].packed = %d; c.box[%d].b = (T)%a;\n", k, h.box[k].packed, k, h.box[k].b); s += buf;
+    }
+    s += "    if (sizeof(T) != 8) { c.box_round = (T)0; c.box_inv_round = (T)0; }\n";
+    std::snprintf(buf, sizeof buf, "// system %d dtype %d dist %d\n", c.system, c.dtype,
+                  (int)(c.n_dist[0] > 0 || c.n_dist[1] > 0 || c.n_dist[2] > 0 || c.adversary_channel >= 0));
+    s += buf;
+    return s;
+}
+
+static std::string emit_spec_source(const scg_config& c, uint64_t* hash_out) {
+    const std::string body = spec_body(c);
+    const uint64_t hash = fnv1a(body);
+    if (hash_out) *hash_out = hash;
+    char buf[256];
+    std::string s = "// Generated by scg_spec_source() (libscg_hip.so) — one task config as compile-time constants.\n";
+    std::snprintf(buf, sizeof buf, "#define SCG_SPEC_HASH 0x%016llxULL\n#define SCG_SPEC_SYS %d\n#define SCG_SPEC_DTYPE %d\n#define SCG_SPEC_DIST %d\n",
+                  (unsigned long long)hash, c.system, c.dtype,
+                  (int)(c.n_dist[0] > 0 || c.n_dist[1] > 0 || c.n_dist[2] > 0 || c.adversary_channel >= 0));
+    s += buf;
+    s += "#define SCG_SPEC_FILL(c) \\\n";
+    // body as a macro so that scg_spec.h can expand it inside a constexpr function template
+    std::string m;
+    for (char ch : body) { if (ch == '\n') m += " \\\n"; else m += ch; }
+    s += m;
+    s += "\n";
+    return s;
+}
+
+extern "C" int scg_spec_source(const scg_config* cfg, char* buf, size_t capacity, size_t* length, uint64_t* hash) {
+    if (int rc = validate(cfg)) return rc;
+    uint64_t h = 0;
+    const std::string src = emit_spec_source(*cfg, &h);
+    if (length) *length = src.size() + 1;
+    if (hash) *hash = h;
+    if (buf) {
+        if (capacity < src.size() + 1) return fail(SCG_ERR_INVALID, "buffer too small for the specialisation source");
+        std::memcpy(buf, src.c_str(), src.size() + 1);
+    }
+    return SCG_OK;
+}
+
+// 0 for the generic library, the baked-in config hash for a specialised one.
+extern "C" uint64_t scg_spec_hash(void) {
+#ifdef SCG_SPEC
+    return SCG_SPEC_HASH;
+#else
+    return 0;
+#endif
+}
+
+extern "C" int scg_destroy(scg_env* env);
 
 template <typename T>
 static int upload(scg_env* e, const double* h_x_goal) {
     const size_t ng = (size_t)e->cfg.goal_rows * e->nx;
     std::vector<T> tab(ng);
     for (size_t k = 0; k < ng; ++k) tab[k] = (T)h_x_goal[k];
-    HIP_TRY(hipMalloc(&e->d_goal, ng * sizeof(T)));
+    HIP_TRY(hipMalloc(&e->d_goal, align_up(ng * sizeof(T), 16) + 16));
+    HIP_TRY(hipMemset(e->d_goal, 0, align_up(ng * sizeof(T), 16) + 16));
     HIP_TRY(hipMemcpy(e->d_goal, tab.data(), ng * sizeof(T), hipMemcpyHostToDevice));
+    // hot block
+    CfgParams<double> hd;
+    build_cfg(e->cfg, hd);
+    CfgParams<T>* hc = new (std::nothrow) CfgParams<T>;
     DevParams<T>* hp = new (std::nothrow) DevParams<T>;
-    if (!hp) return fail(SCG_ERR_NOMEM, "host allocation failed");
+    if (!hc || !hp) { delete hc; delete hp; return fail(SCG_ERR_NOMEM, "host allocation failed"); }
+    convert_cfg<T>(hd, *hc);
     fill_params<T>(e, e->cfg, *hp);
+    // rows served by the box table are skipped by the generic loop; other sparse rows become one-hot dense rows
+    for (int k = 0; k < hd.n_box_rows; ++k) hp->con[hd.box[k].packed & 0xff].is_box = 1;
+    for (int r = 0; r < e->cfg.n_con_rows; ++r) {
+        DevRow<T>& d = hp->con[r];
+        if (!d.is_box && d.kind == SCG_ROW_SPARSE) {
+            for (int j = 0; j < SCG_MAX_STATE; ++j) d.coef[j] = (T)0;
+            d.coef[d.index] = d.sign;
+            d.kind = SCG_ROW_DENSE;
+        }
+    }
+    hp->n_box_rows = hd.n_box_rows; hp->n_generic_rows = hd.n_generic_rows;
     hipError_t err = hipMalloc(&e->d_params, sizeof(DevParams<T>));
     if (err == hipSuccess) err = hipMemcpy(e->d_params, hp, sizeof(DevParams<T>), hipMemcpyHostToDevice);
+    const size_t cfg_bytes = lds16(sizeof(CfgParams<T>));
+    if (err == hipSuccess) err = hipMalloc(&e->d_cfg, cfg_bytes);
+    if (err == hipSuccess) err = hipMemset(e->d_cfg, 0, cfg_bytes);
+    if (err == hipSuccess) err = hipMemcpy(e->d_cfg, hc, sizeof(CfgParams<T>), hipMemcpyHostToDevice);
+    delete hc;
     delete hp;
     if (err != hipSuccess) return fail(SCG_ERR_HIP, std::string("uploading parameters: ") + hipGetErrorString(err));
     return SCG_OK;
+}
+
+template <typename T>
+static InstParams<T> inst_of(const scg_env* e) {
+    InstParams<T> I;
+    I.cold = (const DevParams<T>*)e->d_params; I.x_goal = (const T*)e->d_goal; I.state = (T*)e->d_state;
+    I.param = (T*)e->d_param; I.step = e->d_step; I.episode = e->d_episode; I.oob_attr = e->d_oob;
+    I.num_envs = e->cfg.num_envs; I.env_id_offset = e->cfg.env_id_offset;
+    I.key0 = (uint32_t)(e->cfg.seed & 0xffffffffu); I.key1 = (uint32_t)(e->cfg.seed >> 32);
+    I.goal_lds16 = e->goal_lds16; I.pad = 0;
+    return I;
 }
 
 extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int device, void* d_workspace,
                           size_t workspace_bytes, scg_env** out) {
     if (int rc = validate(cfg)) return rc;
     if (!h_x_goal || !d_workspace || !out) return fail(SCG_ERR_INVALID, "NULL argument to scg_create");
+#ifdef SCG_SPEC
+    {
+        uint64_t h = 0;
+        (void)emit_spec_source(*cfg, &h);
+        if (h != SCG_SPEC_HASH)
+            return fail(SCG_ERR_INVALID, "this library is specialised for another task config (hash mismatch); "
+                                         "use libscg_hip.so or rebuild the specialisation");
+    }
+#endif
     const Layout L = layout_of(cfg);
     if (workspace_bytes < L.total) return fail(SCG_ERR_INVALID, "workspace too small (see scg_workspace_bytes)");
     if ((uintptr_t)d_workspace % 256 != 0) return fail(SCG_ERR_INVALID, "workspace must be 256-byte aligned");
@@ -523,17 +471,24 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->nx = nx; e->nu = nu; e->nobs = nobs; e->ns = ns; e->np = np;
     e->n_offset_slots = count_offset_slots(cfg);
     const size_t tab_bytes = (size_t)cfg->goal_rows * nx * elem_size(cfg->dtype);
-    e->lds_bytes = tab_bytes <= LDS_GOAL_LIMIT ? align_up(tab_bytes, 16) : 0;
+    e->goal_in_lds = tab_bytes <= LDS_GOAL_LIMIT;
+    e->goal_lds16 = e->goal_in_lds ? (int)(align_up(tab_bytes, 16) / 16) : 0;
+    const size_t cfg_sz = cfg->dtype == SCG_F64 ? sizeof(CfgParams<double>) : sizeof(CfgParams<float>);
+#ifdef SCG_SPEC
+    e->lds_bytes = 0; e->goal_lds16 = 0;
+#else
+    e->lds_bytes = lds16(cfg_sz) + (size_t)e->goal_lds16 * 16;
+#endif
     unsigned char* w = (unsigned char*)d_workspace;
     e->d_state = w + L.state; e->d_param = w + L.param; e->d_step = (int32_t*)(w + L.step);
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
-    e->d_params = nullptr; e->d_goal = nullptr; e->has_reset = false;
+    e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
     e->has_dist = cfg->n_dist[0] > 0 || cfg->n_dist[1] > 0 || cfg->n_dist[2] > 0 || cfg->adversary_channel >= 0;
     hipError_t err = hipMemset(d_workspace, 0, L.total);
     if (err == hipSuccess) err = hipMemset(e->d_episode, 0xff, (size_t)cfg->num_envs * 4);   // first reset -> episode 0
     if (err != hipSuccess) { delete e; return fail(SCG_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(err)); }
     int rc = cfg->dtype == SCG_F64 ? upload<double>(e, h_x_goal) : upload<float>(e, h_x_goal);
-    if (rc) { if (e->d_goal) (void)hipFree(e->d_goal); if (e->d_params) (void)hipFree(e->d_params); delete e; return rc; }
+    if (rc) { scg_destroy(e); return rc; }
     *out = e;
     return SCG_OK;
 }
@@ -543,10 +498,22 @@ extern "C" int scg_destroy(scg_env* env) {
     (void)hipSetDevice(env->device);
     if (env->d_goal) (void)hipFree(env->d_goal);
     if (env->d_params) (void)hipFree(env->d_params);
+    if (env->d_cfg) (void)hipFree(env->d_cfg);
     delete env;
     return SCG_OK;
 }
 
+
+// The specialised build instantiates the kernels for its own dtype only.
+#ifdef SCG_SPEC
+#if SCG_SPEC_DTYPE == 1
+#define SCG_BY_DTYPE(env, fn, ...) fn<double>(__VA_ARGS__)
+#else
+#define SCG_BY_DTYPE(env, fn, ...) fn<float>(__VA_ARGS__)
+#endif
+#else
+#define SCG_BY_DTYPE(env, fn, ...) ((env)->dtype == SCG_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+#endif
 template <typename T>
 static StepOut<T> typed_out(const scg_step_out* o) {
     StepOut<T> t{};
@@ -568,16 +535,23 @@ static StepOut<T> typed_out(const scg_step_out* o) {
         default: { constexpr int S = SCG_QUAD_3D; CALL; } break;               \
     }
 // DIST kernel variant only when a disturbance or an adversary is configured
+#ifdef SCG_SPEC
+// specialised build: exactly one (system, DIST) combination is instantiated
+#define DISPATCH_SYS(env, T, CALL)                                             \
+    { constexpr int S = SCG_SPEC_SYS; constexpr bool DD = SCG_SPEC_DIST != 0; CALL; }
+#else
 #define DISPATCH_SYS(env, T, CALL)                                             \
     if ((env)->has_dist) { constexpr bool DD = true; DISPATCH_SYS_D(env, T, CALL) } \
     else { constexpr bool DD = false; DISPATCH_SYS_D(env, T, CALL) }
+#endif
 
 template <typename T>
 static int launch_reset(scg_env* env, const uint8_t* mask, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
     StepOut<T> O = typed_out<T>(out);
-    const DevParams<T>* P = (const DevParams<T>*)env->d_params;
-    DISPATCH_SYS(env, T, (reset_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, mask, O)));
+    const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
+    const InstParams<T> I = inst_of<T>(env);
+    DISPATCH_SYS(env, T, (reset_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, mask, O)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }
@@ -586,8 +560,9 @@ template <typename T>
 static int launch_step(scg_env* env, const void* action, const void* adv, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
     StepOut<T> O = typed_out<T>(out);
-    const DevParams<T>* P = (const DevParams<T>*)env->d_params;
-    DISPATCH_SYS(env, T, (step_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, (const T*)action, (const T*)adv, O)));
+    const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
+    const InstParams<T> I = inst_of<T>(env);
+    DISPATCH_SYS(env, T, (step_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }
@@ -595,12 +570,13 @@ static int launch_step(scg_env* env, const void* action, const void* adv, const 
 template <typename T>
 static int launch_rollout(scg_env* env, int k, const scg_rollout_out* o, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
-    const DevParams<T>* P = (const DevParams<T>*)env->d_params;
+    const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
+    const InstParams<T> I = inst_of<T>(env);
     T* rs = o ? (T*)o->d_reward_sum : nullptr;
     int32_t* dc = o ? o->d_done_count : nullptr;
     int32_t* vc = o ? o->d_violation_count : nullptr;
     T* lo = o ? (T*)o->d_last_obs : nullptr;
-    DISPATCH_SYS(env, T, (rollout_random_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(P, k, rs, dc, vc, lo)));
+    DISPATCH_SYS(env, T, (rollout_random_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, k, rs, dc, vc, lo)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }
@@ -608,8 +584,7 @@ static int launch_rollout(scg_env* env, int k, const scg_rollout_out* o, hipStre
 extern "C" int scg_reset(scg_env* env, const uint8_t* d_mask, const scg_step_out* out, void* stream) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
     HIP_TRY(hipSetDevice(env->device));
-    int rc = env->dtype == SCG_F64 ? launch_reset<double>(env, d_mask, out, (hipStream_t)stream)
-                                   : launch_reset<float>(env, d_mask, out, (hipStream_t)stream);
+    int rc = SCG_BY_DTYPE(env, launch_reset, env, d_mask, out, (hipStream_t)stream);
     if (rc == SCG_OK && !d_mask) env->has_reset = true;
     return rc;
 }
@@ -620,8 +595,7 @@ extern "C" int scg_step(scg_env* env, const void* d_action, const void* d_adv_ac
     // benchmark_env.py:230-235: "You must call env.reset() at least once before using env.step()."
     if (!env->has_reset) return fail(SCG_ERR_STATE, "scg_reset (all envs) must be called before scg_step");
     HIP_TRY(hipSetDevice(env->device));
-    return env->dtype == SCG_F64 ? launch_step<double>(env, d_action, d_adv_action, out, (hipStream_t)stream)
-                                 : launch_step<float>(env, d_action, d_adv_action, out, (hipStream_t)stream);
+    return SCG_BY_DTYPE(env, launch_step, env, d_action, d_adv_action, out, (hipStream_t)stream);
 }
 
 extern "C" int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_out* out, void* stream) {
@@ -629,8 +603,7 @@ extern "C" int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_o
     if (k_steps <= 0) return fail(SCG_ERR_INVALID, "k_steps must be positive");
     if (!env->has_reset) return fail(SCG_ERR_STATE, "scg_reset (all envs) must be called before scg_rollout_random");
     HIP_TRY(hipSetDevice(env->device));
-    return env->dtype == SCG_F64 ? launch_rollout<double>(env, k_steps, out, (hipStream_t)stream)
-                                 : launch_rollout<float>(env, k_steps, out, (hipStream_t)stream);
+    return SCG_BY_DTYPE(env, launch_rollout, env, k_steps, out, (hipStream_t)stream);
 }
 
 // ---- host accessors ---------------------------------------------------------------------------
@@ -709,8 +682,8 @@ static int launch_gae(void* rew, const void* v, const void* mask, const void* te
     // >= 16 waves' worth of envs: the per-env walk already fills the chip with coalesced traffic;
     // below that, parallelise over time with the wave-level segmented scan.
     if (N >= 1024 || Tn < 64) {
-        const int grid = (N + BLOCK - 1) / BLOCK;
-        gae_env_kernel<T><<<dim3(grid), dim3(BLOCK), 0, st>>>((T*)rew, (const T*)v, (const T*)mask, (const T*)term,
+        const int grid = (N + GAE_BLOCK - 1) / GAE_BLOCK;
+        gae_env_kernel<T><<<dim3(grid), dim3(GAE_BLOCK), 0, st>>>((T*)rew, (const T*)v, (const T*)mask, (const T*)term,
                                                              (const T*)last, (T*)ret, (T*)adv, Tn, N, (T)gamma, (T)lam, use_gae);
     } else {
         gae_wave_kernel<T><<<dim3(N), dim3(64), 0, st>>>((T*)rew, (const T*)v, (const T*)mask, (const T*)term,

@@ -29,6 +29,7 @@ struct DevRand {
 template <typename T>
 struct DevRow {
     int32_t kind, var, index, strict;
+    int32_t is_box, pad;        // evaluated through the BoxRow table (hot path) instead of the generic loop
     T sign, b, round_scale, inv_round_scale;
     T coef[SCG_MAX_STATE];
 };
@@ -64,14 +65,7 @@ struct DevParams {
     int32_t adversary_channel;
     DevDist<T> dist[3][SCG_MAX_DISTURB];
     int32_t n_con_rows, n_state_con_rows;
-    // box rows (SPARSE / ABS) regrouped by constrained variable so the kernel indexes registers statically:
-    // variable slot v (0..NX-1 state, NX..NX+NU-1 input) owns entries [bv_first[v], bv_first[v+1])
     int32_t n_box_rows, n_generic_rows;
-    int32_t bv_first[SCG_MAX_STATE + SCG_MAX_ACTION + 1];
-    int32_t bv_row[SCG_MAX_CON_ROWS];        // output row in the stacked constraint vector
-    int32_t bv_state_pos[SCG_MAX_CON_ROWS];  // output row among the state-only rows (reset-time evaluation)
-    int32_t bv_flags[SCG_MAX_CON_ROWS];      // bit0 strict, bit1 abs
-    T bv_sign[SCG_MAX_CON_ROWS], bv_b[SCG_MAX_CON_ROWS], bv_round[SCG_MAX_CON_ROWS], bv_inv_round[SCG_MAX_CON_ROWS];
     DevRow<T> con[SCG_MAX_CON_ROWS];
     T quad_P[SCG_MAX_QUAD_CON][SCG_MAX_STATE * SCG_MAX_STATE];
     // device pointers
@@ -82,6 +76,93 @@ struct DevParams {
     uint32_t* episode;          // [N]
     int32_t* dist_offset;       // [n_offset_slots][N]
     uint8_t* oob_attr;          // [N] persistent `self.out_of_bounds` attribute (stale-on-goal quirk)
+};
+
+// Box constraint row (bounded / default / abs_bound), grouped by constrained variable.
+//   packed = row | state_pos << 8 | flags << 16 | slot << 24;  flags: bit0 strict, bit1 abs, bit2 negative
+//   sign; slot: state k -> k, input j -> SCG_MAX_STATE + j (rows are sorted by slot, state rows first)
+template <typename T>
+struct BoxRow {
+    int32_t packed;
+    T b;
+};
+
+template <typename T>
+struct HotRand {
+    int32_t kind;
+    T p0, p1;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Hot-path parameters.
+//
+// CfgParams<T>: every NUMBER the control step needs (no pointers), including the box-constraint table.
+//   * generic library: one copy in device memory; each workgroup stages it into LDS with one 16-byte load
+//     per thread (all in flight together with the per-env state loads) and reads fields from LDS;
+//   * config-specialised builds (SCG_SPEC, see scg_spec.h): a `static constexpr CfgParams<T>` — every
+//     field is a compile-time constant, branches on config flags vanish, loops fully unroll and there is
+//     no parameter traffic at all.
+//   Why: with 65 536 envs every SIMD holds ONE wave, so each dependent memory round trip (scalar or LDS
+//   parameter fetch, ~100-600 cycles) is exposed latency: rocprofv3 PMC on the generic kernel shows 62 %
+//   of wave cycles in s_waitcnt (profiles/r01_pmc_generic.md).
+// InstParams<T>: pointers and per-instance integers, passed by value as a kernel argument.
+// ---------------------------------------------------------------------------------------------------
+#define SCG_CFG_INT_FIELDS(X)                                                                          \
+    X(substeps) X(ctrl_steps) X(task) X(cost) X(obs_goal_horizon) X(goal_rows) X(nobs) X(nx)           \
+    X(rew_exponential) X(done_on_oob) X(done_on_violation) X(use_penalty) X(obs_wrap_angle)            \
+    X(normalized_action) X(info_goal_reached) X(goal_in_lds) X(per_env_params) X(randomized_init)      \
+    X(auto_reset) X(adversary_channel) X(n_con_rows) X(n_state_con_rows) X(n_generic_rows)             \
+    X(n_box_rows) X(n_box_state_rows)
+#define SCG_CFG_INT_ARRAYS(X) X(n_dist, 3)
+#define SCG_CFG_T_FIELDS(X)                                                                            \
+    X(box_round) X(box_inv_round) X(pyb_dt) X(goal_tolerance) X(constraint_penalty) X(x_threshold)     \
+    X(theta_threshold) X(act_scale) X(hover_thrust) X(kf) X(km) X(pwm2rpm_scale) X(pwm2rpm_const)      \
+    X(pwm_min) X(pwm_max) X(gravity) X(arm) X(vmax) X(pole_box_width)
+#define SCG_CFG_T_ARRAYS(X)                                                                            \
+    X(rew_state_weight, SCG_MAX_STATE) X(rew_act_weight, SCG_MAX_ACTION) X(q_diag, SCG_MAX_STATE)       \
+    X(r_diag, SCG_MAX_ACTION) X(mse_weight, SCG_MAX_STATE) X(u_goal, SCG_MAX_ACTION)                    \
+    X(state_low, SCG_MAX_STATE) X(state_high, SCG_MAX_STATE) X(act_low, SCG_MAX_ACTION)                 \
+    X(act_high, SCG_MAX_ACTION) X(base_param, SCG_MAX_PARAM) X(init_state, SCG_MAX_STATE)
+
+template <typename T>
+struct CfgParams {
+#define SCG_X(f) int32_t f;
+    SCG_CFG_INT_FIELDS(SCG_X)
+#undef SCG_X
+#define SCG_X(f, n) int32_t f[n];
+    SCG_CFG_INT_ARRAYS(SCG_X)
+#undef SCG_X
+#define SCG_X(f) T f;
+    SCG_CFG_T_FIELDS(SCG_X)
+#undef SCG_X
+#define SCG_X(f, n) T f[n];
+    SCG_CFG_T_ARRAYS(SCG_X)
+#undef SCG_X
+    HotRand<T> param_rand[SCG_MAX_PARAM];
+    HotRand<T> init_rand[SCG_MAX_STATE];
+    BoxRow<T> box[SCG_MAX_CON_ROWS];     // sorted by variable slot, state rows first
+};
+
+template <typename T>
+struct InstParams {
+    const DevParams<T>* cold;   // disturbance tables, generic constraint rows, choice lists
+    const T* x_goal;            // [goal_rows][nx] in device memory
+    T* state;
+    T* param;
+    int32_t* step;
+    uint32_t* episode;
+    uint8_t* oob_attr;
+    int32_t num_envs, env_id_offset;
+    uint32_t key0, key1;
+    int32_t goal_lds16;         // generic build: number of 16-byte chunks of x_goal staged into LDS (0 = read from global)
+    int32_t pad;
+};
+
+// What the env code sees.
+template <typename T>
+struct PV {
+    const CfgParams<T>& c;
+    const InstParams<T>& i;
 };
 
 // Number of raw state arrays / per-env params / dims per system.

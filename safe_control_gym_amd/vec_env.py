@@ -164,7 +164,7 @@ class HipVecEnv(VecEnv):
     """N independent copies of one environment stepped by libscg_hip.so on one GPU."""
 
     def __init__(self, env_id, num_envs, seed=0, device=None, dtype=torch.float32, env_id_offset=0,
-                 return_numpy=True, auto_reset=True, **task_config):
+                 return_numpy=True, auto_reset=True, specialize='auto', **task_config):
         L.lib()                                        # fail loudly, before touching torch.cuda
         if not torch.cuda.is_available():
             raise L.ScgError('HipVecEnv needs a HIP device (torch.cuda.is_available() is False); '
@@ -186,18 +186,19 @@ class HipVecEnv(VecEnv):
         self.env_id_offset = int(env_id_offset)
         self.return_numpy = return_numpy
         VecEnv.__init__(self, int(num_envs), spec.observation_space, spec.action_space)
-        self._lib = L.lib()
         cfg, x_goal = spec.to_c_config(self.num_envs, self._cdtype, self.seed_value, self.env_id_offset, auto_reset)
         self.auto_reset = bool(auto_reset)
+        # config-specialised library when one was built for this config (specialize=True compiles it now)
+        self._lib, self.specialized = L.lib_for(cfg, specialize)
         self._cfg = cfg
         nbytes = C.c_size_t(0)
-        L.check(self._lib.scg_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        self._chk(self._lib.scg_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
             base = self.workspace.data_ptr()
             self._ws_ptr = (base + 255) // 256 * 256
             handle = C.c_void_p()
-            L.check(self._lib.scg_create(C.byref(cfg), x_goal.ctypes.data_as(C.POINTER(C.c_double)),
+            self._chk(self._lib.scg_create(C.byref(cfg), x_goal.ctypes.data_as(C.POINTER(C.c_double)),
                                          self.device.index or 0, C.c_void_p(self._ws_ptr), nbytes.value, C.byref(handle)))
         self._h = handle
         N, spec = self.num_envs, self.spec
@@ -225,6 +226,9 @@ class HipVecEnv(VecEnv):
         self._actions = None
         self._adv = None
         self.closed = False
+
+    def _chk(self, rc):
+        L.check(rc, self._lib)
 
     # ------------------------------------------------------------------ plumbing
     def _make_c_out(self, o, obs=None):
@@ -255,7 +259,7 @@ class HipVecEnv(VecEnv):
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         with torch.cuda.device(self.device):
-            L.check(self._lib.scg_reset(self._h, C.c_void_p(m.data_ptr()) if m is not None else None,
+            self._chk(self._lib.scg_reset(self._h, C.c_void_p(m.data_ptr()) if m is not None else None,
                                         C.byref(self._c_out), self._stream()))
         return self.out.obs
 
@@ -270,7 +274,7 @@ class HipVecEnv(VecEnv):
             adv = adv_actions.to(device=self.device, dtype=self.dtype).contiguous()
             adv_ptr = C.c_void_p(adv.data_ptr())
         with torch.cuda.device(self.device):
-            L.check(self._lib.scg_step(self._h, C.c_void_p(a.data_ptr()), adv_ptr,
+            self._chk(self._lib.scg_step(self._h, C.c_void_p(a.data_ptr()), adv_ptr,
                                        C.byref(c_out if c_out is not None else self._c_out), self._stream()))
         return out if out is not None else self.out
 
@@ -295,7 +299,7 @@ class HipVecEnv(VecEnv):
             r.d_reward_sum, r.d_done_count, r.d_violation_count, r.d_last_obs = (C.c_void_p(t.data_ptr()) for t in self._ro)
             self._ro_c = r
         with torch.cuda.device(self.device):
-            L.check(self._lib.scg_rollout_random(self._h, int(k_steps), C.byref(self._ro_c), self._stream()))
+            self._chk(self._lib.scg_rollout_random(self._h, int(k_steps), C.byref(self._ro_c), self._stream()))
         return self._ro
 
     # ------------------------------------------------------------------ reference VecEnv API
@@ -344,7 +348,7 @@ class HipVecEnv(VecEnv):
     def _host_io(self, fn, width, first, n, data=None):
         buf = np.zeros((n, width), dtype=np.float64) if data is None else np.ascontiguousarray(data, dtype=np.float64).reshape(n, width)
         with torch.cuda.device(self.device):
-            L.check(fn(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), int(first), int(n), self._stream()))
+            self._chk(fn(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), int(first), int(n), self._stream()))
         return buf
 
     def get_raw_state(self, first=0, n=None):
@@ -367,7 +371,7 @@ class HipVecEnv(VecEnv):
         step = np.zeros(self.num_envs, dtype=np.int32)
         ep = np.zeros(self.num_envs, dtype=np.uint32)
         with torch.cuda.device(self.device):
-            L.check(self._lib.scg_get_counters(self._h, step.ctypes.data_as(C.POINTER(C.c_int32)),
+            self._chk(self._lib.scg_get_counters(self._h, step.ctypes.data_as(C.POINTER(C.c_int32)),
                                                ep.ctypes.data_as(C.POINTER(C.c_uint32)), 0, self.num_envs, self._stream()))
         return step, ep
 
@@ -375,7 +379,7 @@ class HipVecEnv(VecEnv):
         sp = None if step is None else np.ascontiguousarray(step, dtype=np.int32)
         ep = None if episode is None else np.ascontiguousarray(episode, dtype=np.uint32)
         with torch.cuda.device(self.device):
-            L.check(self._lib.scg_set_counters(
+            self._chk(self._lib.scg_set_counters(
                 self._h, sp.ctypes.data_as(C.POINTER(C.c_int32)) if sp is not None else None,
                 ep.ctypes.data_as(C.POINTER(C.c_uint32)) if ep is not None else None, 0, self.num_envs, self._stream()))
 
