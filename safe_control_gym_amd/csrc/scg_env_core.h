@@ -405,7 +405,8 @@ struct EnvOps {
     //   ctrl_step:  ctrl_step_counter seen by impulse/step disturbances (pre-increment value)
     __device__ static __forceinline__ void write_obs(const PV<T>& P, const GoalTab<T>& goal_tab, const T* st,
                                                      const E& e, RngKey key, int next_index, uint32_t rng_step,
-                                                     int32_t ctrl_step, int env_index, T* dst) {
+                                                     int32_t ctrl_step, int env_index, T* __restrict__ dst,
+                                                     const T* ext_pre = nullptr) {
         T o[D::NX];
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) o[k] = st[k];
@@ -416,22 +417,51 @@ struct EnvOps {
         if constexpr (SYS == SCG_CARTPOLE) {
             if (P.c.obs_wrap_angle) o[2] = normalize_angle(o[2]);
         }
-#pragma unroll
-        for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
         const int h = P.c.obs_goal_horizon;
         if (h > 0 && P.c.cost == SCG_COST_RL_REWARD) {
+            // gather the goal rows into registers first: the table loads must not be interleaved with the
+            // stores below (the compiler has to assume they alias and would serialise load -> store -> load)
             if (P.c.task == SCG_TASK_TRAJ_TRACKING) {
                 const int last = P.c.goal_rows - 1;
+                if (h == 1) {
+                    T g[D::NX];
+                    if (ext_pre) {
+#pragma unroll
+                        for (int k = 0; k < D::NX; ++k) g[k] = ext_pre[k];
+                    } else {
+                        int row = next_index; row = row > last ? last : row;
+#pragma unroll
+                        for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[row * D::NX + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
+#pragma unroll
+                    for (int k = 0; k < D::NX; ++k) dst[D::NX + k] = g[k];
+                    return;
+                }
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
                 for (int r = 0; r < h; ++r) {
                     int row = next_index + r; row = row > last ? last : row;
+                    T g[D::NX];
 #pragma unroll
-                    for (int k = 0; k < D::NX; ++k) dst[D::NX * (1 + r) + k] = goal_tab[row * D::NX + k];
+                    for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[row * D::NX + k];
+#pragma unroll
+                    for (int k = 0; k < D::NX; ++k) dst[D::NX * (1 + r) + k] = g[k];
                 }
             } else {
+                T g[D::NX];
 #pragma unroll
-                for (int k = 0; k < D::NX; ++k) dst[D::NX + k] = goal_tab[k];
+                for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[k];
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
+#pragma unroll
+                for (int k = 0; k < D::NX; ++k) dst[D::NX + k] = g[k];
             }
+            return;
         }
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
     }
 
     // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset
@@ -510,7 +540,8 @@ SCG_BOX_UNROLL
     // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
     __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,
-                                                      T* st, T* noisy_out, T* c_out, size_t c_stride) {
+                                                      T* st, T* noisy_out, T* c_out, size_t c_stride,
+                                                      const T* ref_pre = nullptr) {
         const int32_t c0 = e.step;      // ctrl_step_counter before the increment
         // ---- _preprocess_control
         T noisy[D::NU], clipped[D::NU];
@@ -731,7 +762,10 @@ SCG_BOX_UNROLL
         // ---- reference row for reward / mse (tracking: X_GOAL[min(c+1, L-1)])
         T ref[D::NX];
         const bool tracking = P.c.task == SCG_TASK_TRAJ_TRACKING;
-        {
+        if (ref_pre) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) ref[k] = ref_pre[k];
+        } else {
             int row = 0;
             if (tracking) { row = c0 + 1; const int last = P.c.goal_rows - 1; row = row > last ? last : row; }
 #pragma unroll

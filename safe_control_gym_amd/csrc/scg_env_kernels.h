@@ -134,6 +134,38 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
     Ops::store(P, i, e, true);
 }
 
+// Per-thread output addresses, computed at kernel entry so that every kernarg (pointer) is fetched in the
+// first scalar-load round instead of lazily at its first use deep inside the kernel.
+template <typename T>
+struct OutPtrs {
+    T* obs; T* reward; uint8_t* done; uint8_t* flags; T* c_values; T* mse; T* terminal_obs; T* state;
+    T* noisy_action; T* ep_return; int32_t* ep_length; T* ep_violation; T* ep_mse;
+    T* fin_return; int32_t* fin_length; T* fin_violation; T* fin_mse;
+};
+
+template <typename T>
+__device__ __forceinline__ OutPtrs<T> out_ptrs(const StepOut<T>& O, int i, int nobs) {
+    OutPtrs<T> p;
+    p.obs = O.obs ? O.obs + (size_t)i * nobs : nullptr;
+    p.terminal_obs = O.terminal_obs ? O.terminal_obs + (size_t)i * nobs : nullptr;
+    p.reward = O.reward ? O.reward + i : nullptr;
+    p.done = O.done ? O.done + i : nullptr;
+    p.flags = O.flags ? O.flags + i : nullptr;
+    p.c_values = O.c_values ? O.c_values + i : nullptr;
+    p.mse = O.mse ? O.mse + i : nullptr;
+    p.state = O.state ? O.state + i : nullptr;
+    p.noisy_action = O.noisy_action ? O.noisy_action + i : nullptr;
+    p.ep_return = O.ep_return ? O.ep_return + i : nullptr;
+    p.ep_length = O.ep_length ? O.ep_length + i : nullptr;
+    p.ep_violation = O.ep_violation ? O.ep_violation + i : nullptr;
+    p.ep_mse = O.ep_mse ? O.ep_mse + i : nullptr;
+    p.fin_return = O.fin_return ? O.fin_return + i : nullptr;
+    p.fin_length = O.fin_length ? O.fin_length + i : nullptr;
+    p.fin_violation = O.fin_violation ? O.fin_violation + i : nullptr;
+    p.fin_mse = O.fin_mse ? O.fin_mse + i : nullptr;
+    return p;
+}
+
 template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                      const T* __restrict__ action, const T* __restrict__ adv, StepOut<T> O) {
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = I.num_envs;
     const bool live = i < N;
-    // ---- everything this thread needs from HBM is requested before the single wait
+    // ---- memory round 1: kernargs (all pointers are consumed right here)
     typename Ops::E e;
     T act[D::NU];
     T ep_ret = (T)0, ep_viol = (T)0, ep_mse = (T)0;
@@ -153,19 +185,23 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     const GoalTab<T> goal{nullptr, I.x_goal, false};
     if (!live) return;
     const PV<T>& Pg = P;
+    const int nobs_early = kcfg.nobs;
 #else
     extern __shared__ __align__(16) unsigned char smem[];
     const StageRegs SR = stage_issue(Cg, I);
     const PV<T> Pg{*Cg, I};
+    const int nobs_early = D::NX * (1 + I.obs_ext_rows);
 #endif
+    const OutPtrs<T> Q = out_ptrs(O, live ? i : 0, nobs_early);
+    // ---- memory round 2: everything this thread needs from HBM, requested before the single wait
     if (live) {
         Ops::load_state(Pg, i, e);
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];
-        if (O.ep_return) ep_ret = O.ep_return[i];
-        if (O.ep_length) ep_len = O.ep_length[i];
-        if (O.ep_violation) ep_viol = O.ep_violation[i];
-        if (O.ep_mse) ep_mse = O.ep_mse[i];
+        if (Q.ep_return) ep_ret = *Q.ep_return;
+        if (Q.ep_length) ep_len = *Q.ep_length;
+        if (Q.ep_violation) ep_viol = *Q.ep_violation;
+        if (Q.ep_mse) ep_mse = *Q.ep_mse;
     }
 #ifndef SCG_SPEC
     const CfgParams<T>* cl;
@@ -175,6 +211,25 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
 #endif
     Ops::load_params(P, i, e);
     const RngKey key{I.key0, I.key1};
+    const int32_t c0 = e.step;
+    // ---- memory round 3 (overlapped with the integrator): reference rows of X_GOAL for this step
+    const bool pre_rows = P.c.task == SCG_TASK_TRAJ_TRACKING;
+    const bool pre_ext = pre_rows && P.c.cost == SCG_COST_RL_REWARD && P.c.obs_goal_horizon == 1;
+    T ref_pre[D::NX], ext_pre[D::NX], ext_reset[D::NX];
+    if (pre_rows) {
+        const int last = P.c.goal_rows - 1;
+        int r1 = c0 + 1; r1 = r1 > last ? last : r1;
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) ref_pre[k] = goal[r1 * D::NX + k];
+        if (pre_ext) {
+            int r2 = c0 + 2; r2 = r2 > last ? last : r2;
+            const int r0 = 1 > last ? last : 1;
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) ext_pre[k] = goal[r2 * D::NX + k];
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) ext_reset[k] = goal[r0 * D::NX + k];
+        }
+    }
     T advv[D::DYN > D::NU ? D::DYN : D::NU];
     const T* advp = nullptr;
     if constexpr (DIST) {
@@ -185,58 +240,56 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
         }
     }
     T st[D::NX], noisy[D::NU];
-    const int32_t c0 = e.step;
-    typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy,
-                                           O.c_values ? O.c_values + i : nullptr, (size_t)N);
-    if (O.reward) O.reward[i] = r.reward;
-    if (O.done) O.done[i] = r.done ? 1 : 0;
-    if (O.flags) O.flags[i] = r.flags;
-    if (O.mse) O.mse[i] = r.mse;
-    if (O.noisy_action) {
+    typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, Q.c_values, (size_t)N,
+                                           pre_rows ? ref_pre : nullptr);
+    if (Q.reward) *Q.reward = r.reward;
+    if (Q.done) *Q.done = r.done ? 1 : 0;
+    if (Q.flags) *Q.flags = r.flags;
+    if (Q.mse) *Q.mse = r.mse;
+    if (Q.noisy_action) {
 #pragma unroll
-        for (int j = 0; j < D::NU; ++j) O.noisy_action[(size_t)j * N + i] = noisy[j];
+        for (int j = 0; j < D::NU; ++j) Q.noisy_action[(size_t)j * N] = noisy[j];
     }
     // columnar VecRecordEpisodeStatistics (record_episode_statistics.py:139-166)
-    if (O.ep_return) {
+    if (Q.ep_return) {
         const T acc = ep_ret + r.reward;
-        if (r.done && O.fin_return) O.fin_return[i] = acc;
-        O.ep_return[i] = r.done ? (T)0 : acc;
+        if (r.done && Q.fin_return) *Q.fin_return = acc;
+        *Q.ep_return = r.done ? (T)0 : acc;
     }
-    if (O.ep_length) {
+    if (Q.ep_length) {
         const int32_t acc = ep_len + 1;
-        if (r.done && O.fin_length) O.fin_length[i] = acc;
-        O.ep_length[i] = r.done ? 0 : acc;
+        if (r.done && Q.fin_length) *Q.fin_length = acc;
+        *Q.ep_length = r.done ? 0 : acc;
     }
-    if (O.ep_violation) {
+    if (Q.ep_violation) {
         const T acc = ep_viol + ((r.flags & FLAG_VIOLATION) ? (T)1 : (T)0);
-        if (r.done && O.fin_violation) O.fin_violation[i] = acc;
-        O.ep_violation[i] = r.done ? (T)0 : acc;
+        if (r.done && Q.fin_violation) *Q.fin_violation = acc;
+        *Q.ep_violation = r.done ? (T)0 : acc;
     }
-    if (O.ep_mse) {
+    if (Q.ep_mse) {
         const T acc = ep_mse + r.mse;
-        if (r.done && O.fin_mse) O.fin_mse[i] = acc;
-        O.ep_mse[i] = r.done ? (T)0 : acc;
+        if (r.done && Q.fin_mse) *Q.fin_mse = acc;
+        *Q.ep_mse = r.done ? (T)0 : acc;
     }
     // observation of the step: goes to terminal_observation where the env is about to auto-reset, else it is the
     // returned obs (two write_obs call sites only: the disturbance code is inlined into each)
     const bool do_reset = r.done && P.c.auto_reset;
     {
-        T* dst = do_reset ? (O.terminal_obs ? O.terminal_obs + (size_t)i * P.c.nobs : nullptr)
-                          : (O.obs ? O.obs + (size_t)i * P.c.nobs : nullptr);
-        if (dst) Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, dst);
-        if (r.done && !P.c.auto_reset && O.terminal_obs && O.obs) {
+        T* dst = do_reset ? Q.terminal_obs : Q.obs;
+        if (dst) Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, dst, pre_ext ? ext_pre : nullptr);
+        if (r.done && !P.c.auto_reset && Q.terminal_obs && Q.obs) {
             // single-env semantics (BenchmarkEnv.step): the terminal observation is also the returned one
-            for (int k = 0; k < P.c.nobs; ++k) O.terminal_obs[(size_t)i * P.c.nobs + k] = O.obs[(size_t)i * P.c.nobs + k];
+            for (int k = 0; k < P.c.nobs; ++k) Q.terminal_obs[k] = Q.obs[k];
         }
     }
     if (do_reset) {
         Ops::reset(P, i, e, key);               // auto-reset (dummy_vec_env.py:33-38)
         Ops::state_vector(e, st);
-        if (O.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, O.obs + (size_t)i * P.c.nobs);
+        if (Q.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs, pre_ext ? ext_reset : nullptr);
     }
-    if (O.state) {
+    if (Q.state) {
 #pragma unroll
-        for (int k = 0; k < D::NX; ++k) O.state[(size_t)k * N + i] = st[k];
+        for (int k = 0; k < D::NX; ++k) Q.state[(size_t)k * N] = st[k];
     }
     Ops::store(P, i, e, do_reset);
 }

@@ -442,7 +442,7 @@ static InstParams<T> inst_of(const scg_env* e) {
     I.param = (T*)e->d_param; I.step = e->d_step; I.episode = e->d_episode; I.oob_attr = e->d_oob;
     I.num_envs = e->cfg.num_envs; I.env_id_offset = e->cfg.env_id_offset;
     I.key0 = (uint32_t)(e->cfg.seed & 0xffffffffu); I.key1 = (uint32_t)(e->cfg.seed >> 32);
-    I.goal_lds16 = e->goal_lds16; I.pad = 0;
+    I.goal_lds16 = e->goal_lds16; I.obs_ext_rows = e->nobs / e->nx - 1;
     return I;
 }
 

@@ -155,7 +155,7 @@ struct InstParams {
     int32_t num_envs, env_id_offset;
     uint32_t key0, key1;
     int32_t goal_lds16;         // generic build: number of 16-byte chunks of x_goal staged into LDS (0 = read from global)
-    int32_t pad;
+    int32_t obs_ext_rows;       // obs_dim / state_dim - 1 (needed before the parameter block is staged)
 };
 
 // What the env code sees.

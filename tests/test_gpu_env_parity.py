@@ -268,13 +268,17 @@ def test_f64_kernels_replay_reference_fixtures(name):
         live = ~done
         np.testing.assert_allclose(_np(out.obs)[live], g['obs'][t][live], err_msg=msg, **tol)
         if g['c_values'].shape[-1]:
-            np.testing.assert_allclose(_np(out.c_values).T, g['c_values'][t], rtol=0, atol=2e-8, err_msg=msg)
+            np.testing.assert_allclose(_np(out.c_values).T, g['c_values'][t], err_msg=msg, **tol)
         d = np.nonzero(done)[0]
         if len(d):
             np.testing.assert_allclose(_np(out.terminal_obs)[d], g['terminal_obs'][t][d], err_msg=msg, **tol)
             np.testing.assert_allclose(_np(out.fin_return)[d], g['ep_return'][t][d], err_msg=msg, **tol)
             np.testing.assert_array_equal(_np(out.fin_length)[d], g['ep_length'][t][d], err_msg=msg)
             inject(g['state'][t], d)       # the reference's post-reset state
+        if t % 16 == 15 and cfg.get('done_on_out_of_bound', True):
+            # closed loops around unstable equilibria amplify 1e-16 rounding differences ~10x every few steps:
+            # re-synchronise to the reference state so that the comparison stays a semantics check
+            inject(g['state'][t], np.arange(n))
     gpu.close()
 
 
