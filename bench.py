@@ -102,10 +102,13 @@ def main():
     gen.manual_seed(1234 + rank)
     actions = (torch.rand(ring, N, nu, device=dev, dtype=dtype, generator=gen) * 2 - 1)
     env.reset_tensors()
+    # outputs a rollout collector consumes (obs, reward, done, flags, constraint values, mse, terminal obs,
+    # fused episode statistics); the optional debugging outputs (env.state copy, noisy action) are not bound
+    lean_out, lean_c = env.bind_outputs(state=None, noisy_action=None)
 
     def run_steps(k0, k):
         for t in range(k0, k0 + k):
-            env.step_tensors(actions[t % ring])
+            env.step_tensors(actions[t % ring], out=lean_out, c_out=lean_c)
 
     G = max(1, min(args.graph_len, args.steps))
     graph = None
@@ -150,7 +153,7 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     # sanity: the simulator really advanced (episodes finished, finite rewards)
-    ok = bool(torch.isfinite(env.out.reward).all().item())
+    ok = bool(torch.isfinite(lean_out.reward).all().item()) and int(lean_out.fin_length.max().item()) > 0
     total_env_steps = world * N * done_steps
     value = total_env_steps / elapsed
     if rank == 0:
@@ -158,6 +161,14 @@ def main():
         if dtype == torch.float64 and algo:
             algo = None
         achieved = (algo * N / (kernel_ms * 1e-3)) / 1e9 if algo else None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this very command
+        # (profiles/r01_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
+                traffic = json.load(f).get(f'{args.task}/{args.dtype}/{N}', {}).get('traffic_bytes_per_launch')
+        except OSError:
+            pass
         out = {
             'metric': 'env-steps/sec (whole node), Quadrotor2D-track', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': done_steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / done_steps,
@@ -168,9 +179,11 @@ def main():
                                    f'synthetic U(-1,1) actions resident in HBM, '
                                    f'{"HIP graph of %d steps" % G if graph is not None else "per-step Python launches"}',
                        'envs_per_gpu': N, 'task_yaml': f'safe_control_gym_amd/configs/{args.task}.yaml',
-                       'parallelism': f'env-shard x{world}', 'finite_outputs': ok},
+                       'parallelism': f'env-shard x{world}', 'finite_outputs': ok,
+                       'kernel_build': 'config-specialised' if env.specialized else 'generic'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
+                         'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc, bytes per launch)' if traffic else None,
                          'kernel': 'step_kernel<QUAD_2D,float>', 'avg_launch_us': kernel_ms * 1e3,
                          'algorithmic_bytes_per_env_step': algo},
         }

@@ -283,7 +283,7 @@ class HipVecEnv(VecEnv):
         rollout buffer) and whose other fields alias this env's default output buffers."""
         o = StepTensors()
         for k in StepTensors.__slots__:
-            setattr(o, k, tensors.get(k, getattr(self.out, k)))
+            setattr(o, k, tensors[k] if k in tensors else getattr(self.out, k))    # explicit None = not wanted
         return o, self._make_c_out(o)
 
     def rollout_random(self, k_steps):
