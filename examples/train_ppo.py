@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""PPO on Quadrotor2D trajectory tracking with the HIP rollout engine (BASELINE configs[2]/[3]).
+
+    python examples/train_ppo.py --envs 65536 --rollout-steps 32 --target-return 236
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ppo.py ...
+
+Prints one JSON line per training iteration and a final summary with the wall-clock until the deterministic-policy
+evaluation return (config init state, 250-step episode) reaches --target-return (reference reward).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--task', default='quadrotor_2D_track')
+    ap.add_argument('--envs', type=int, default=65536)
+    ap.add_argument('--rollout-steps', type=int, default=32)
+    ap.add_argument('--epochs', type=int, default=4)
+    ap.add_argument('--minibatch', type=int, default=131072)
+    ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--critic-lr', type=float, default=None)
+    ap.add_argument('--hidden', type=int, default=128)
+    ap.add_argument('--activation', default='tanh')
+    ap.add_argument('--target-kl', type=float, default=0.01)
+    ap.add_argument('--entropy', type=float, default=0.01)
+    ap.add_argument('--gamma', type=float, default=0.99)
+    ap.add_argument('--lam', type=float, default=0.95)
+    ap.add_argument('--max-env-steps', type=float, default=3e8)
+    ap.add_argument('--max-seconds', type=float, default=120.0)
+    ap.add_argument('--target-return', type=float, default=236.0)
+    ap.add_argument('--eval-envs', type=int, default=256)
+    ap.add_argument('--eval-every', type=int, default=2)
+    ap.add_argument('--seed', type=int, default=2)
+    ap.add_argument('--respect-yaml-init', action='store_true',
+                    help='honour init_state_randomization_info of the YAML (the reference class ignores it)')
+    ap.add_argument('--quiet', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from safe_control_gym_amd import parallel
+    from safe_control_gym_amd.ppo import PPO, PPOConfig, evaluate
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+
+    rank, world = parallel.init_distributed()
+    if world == 1:
+        torch.cuda.set_device(0)
+    env_id, cfg = load_task(args.task)
+    if args.respect_yaml_init:
+        cfg['respect_randomization_info'] = True
+    env = HipVecEnv(env_id, args.envs, seed=args.seed, env_id_offset=rank * args.envs, return_numpy=False, **cfg)
+    # evaluation: the config's init_state, no randomisation (how BASELINE.md's 236/250 reference reward is defined)
+    eval_cfg = dict(cfg, randomized_init=False)
+    eval_env = HipVecEnv(env_id, args.eval_envs, seed=args.seed * 111, return_numpy=False, **eval_cfg)
+    pcfg = PPOConfig(hidden_dim=args.hidden, activation=args.activation, gamma=args.gamma, use_gae=True, gae_lambda=args.lam,
+                     target_kl=args.target_kl, entropy_coef=args.entropy, opt_epochs=args.epochs,
+                     mini_batch_size=args.minibatch, actor_lr=args.lr, critic_lr=args.critic_lr or args.lr,
+                     rollout_batch_size=args.envs, rollout_steps=args.rollout_steps, max_env_steps=int(args.max_env_steps))
+    ppo = PPO(env, pcfg, seed=args.seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reached = None
+    it = 0
+    best = -1e30
+    while ppo.total_steps < args.max_env_steps and time.perf_counter() - t0 < args.max_seconds:
+        res = ppo.train_step()
+        it += 1
+        res.update(ppo.episode_stats())
+        if it % args.eval_every == 0:
+            ev = evaluate(ppo.agent.ac, eval_env)
+            res['eval_return'] = ev['ep_return']
+            res['eval_length'] = ev['ep_length']
+            best = max(best, ev['ep_return'])
+        torch.cuda.synchronize()
+        res['wall_clock'] = time.perf_counter() - t0
+        if rank == 0 and not args.quiet:
+            print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
+        if res.get('eval_return', -1e30) >= args.target_return:
+            reached = res['wall_clock']
+            break
+    total = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({'summary': True, 'task': args.task, 'n_gpus': world, 'envs_per_gpu': args.envs,
+                          'iterations': it, 'env_steps': ppo.total_steps, 'wall_clock_s': total,
+                          'env_steps_per_s_incl_learning': ppo.total_steps / total, 'best_eval_return': best,
+                          'target_return': args.target_return, 'wall_clock_to_target_s': reached,
+                          'hyper': vars(args)}), flush=True)
+    env.close()
+    eval_env.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,362 @@
+"""PPO on the HIP rollout engine.
+
+Mirrors the reference's PPO (paths relative to /root/reference/safe_control_gym):
+  controllers/ppo/ppo.py:259-303        train_step: rollout collector, truncated-episode bootstrap, advantage normalisation
+  controllers/ppo/ppo_utils.py:18-146   PPOAgent: two Adam optimisers, clipped surrogate, entropy bonus, approx-KL gate
+                                        (actor step skipped when approx_kl > 1.5 target_kl, epoch loop continues, no
+                                        gradient clipping), critic step always
+  controllers/ppo/ppo_utils.py:149-238  MLPActor (state-independent logstd = -0.5), MLPCritic, MLPActorCritic.step/act
+  controllers/ppo/ppo_utils.py:358-400  random_sample (permutation, drop last), compute_returns_and_advantages
+  math_and_models/neural_networks.py:18-54, distributions.py:9-33
+  controllers/ppo/ppo.yaml              hyper-parameter names
+
+What is different by construction (MI355X-first): the env batch lives on the GPU (HipVecEnv), the step kernel writes
+observations / rewards / done flags / terminal observations straight into the [T, N, .] rollout tensors, nothing crosses
+PCIe during a rollout, GAE runs as `scg_gae`, minibatches are gathered on device, and with several ranks (one process per
+GPU, env shards) ONE flat RCCL all-reduce per minibatch carries both networks' gradients plus the approx-KL so that
+every rank takes the same actor-gate branch.
+"""
+import math
+import time
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from safe_control_gym_amd import parallel
+
+
+# ------------------------------------------------------------------ networks
+class MLP(nn.Module):
+    """Linear stack with a named torch.nn.functional activation (neural_networks.py:18-54); PyTorch default init."""
+
+    def __init__(self, input_dim, output_dim, hidden_dims=(), act='relu', output_act=None):
+        super().__init__()
+        dims = [input_dim] + list(hidden_dims) + [output_dim]
+        self.fcs = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        self.act = getattr(F, act) if act else (lambda x: x)
+        self.output_act = getattr(F, output_act) if output_act else (lambda x: x)
+
+    def forward(self, x):
+        for fc in self.fcs[:-1]:
+            x = self.act(fc(x))
+        return self.output_act(self.fcs[-1](x))
+
+
+class MLPActor(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden_dims, activation):
+        super().__init__()
+        self.pi_net = MLP(obs_dim, act_dim, hidden_dims, activation)
+        self.logstd = nn.Parameter(-0.5 * torch.ones(act_dim))       # ppo_utils.py:166
+
+    def forward(self, obs):
+        return self.pi_net(obs), self.logstd
+
+
+class MLPCritic(nn.Module):
+    def __init__(self, obs_dim, hidden_dims, activation):
+        super().__init__()
+        self.v_net = MLP(obs_dim, 1, hidden_dims, activation)
+
+    def forward(self, obs):
+        return self.v_net(obs)
+
+
+LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def normal_log_prob(mean, logstd, act):
+    """Normal(mean, exp(logstd)).log_prob(act).sum(-1) (distributions.py:12-22)."""
+    z = (act - mean) * torch.exp(-logstd)
+    return (-0.5 * z * z - logstd - LOG_SQRT_2PI).sum(-1)
+
+
+def normal_entropy(logstd):
+    """Entropy summed over action dims (distributions.py:24-30); independent of the state."""
+    return (0.5 + LOG_SQRT_2PI + logstd).sum(-1)
+
+
+class MLPActorCritic(nn.Module):
+    """Same state_dict layout as the reference (actor.pi_net.fcs.N.*, actor.logstd, critic.v_net.fcs.N.*), so the
+    shipped checkpoints load directly."""
+
+    def __init__(self, obs_dim, act_dim, hidden_dims=(64, 64), activation='tanh'):
+        super().__init__()
+        self.actor = MLPActor(obs_dim, act_dim, list(hidden_dims), activation)
+        self.critic = MLPCritic(obs_dim, list(hidden_dims), activation)
+
+    @torch.no_grad()
+    def step(self, obs):
+        """Sampled action, value, log-prob (ppo_utils.py:224-231), all on device."""
+        mean, logstd = self.actor(obs)
+        act = mean + torch.exp(logstd) * torch.randn_like(mean)
+        return act, self.critic(obs).squeeze(-1), normal_log_prob(mean, logstd, act)
+
+    @torch.no_grad()
+    def act(self, obs):
+        """Deterministic action = distribution mode (ppo_utils.py:233-238)."""
+        return self.actor(obs)[0]
+
+
+# ------------------------------------------------------------------ hyper-parameters
+@dataclass
+class PPOConfig:
+    # names and defaults of controllers/ppo/ppo.yaml
+    hidden_dim: int = 64
+    activation: str = 'tanh'
+    gamma: float = 0.99
+    use_gae: bool = False
+    gae_lambda: float = 0.95
+    use_clipped_value: bool = False
+    clip_param: float = 0.2
+    target_kl: float = 0.01
+    entropy_coef: float = 0.01
+    opt_epochs: int = 10
+    mini_batch_size: int = 64
+    actor_lr: float = 0.0003
+    critic_lr: float = 0.001
+    max_grad_norm: float = 0.5          # configured but never applied upstream (ppo_utils.py:113-146)
+    max_env_steps: int = 1000000
+    rollout_batch_size: int = 4         # = number of envs (per rank)
+    rollout_steps: int = 100
+    eval_batch_size: int = 10
+    extra: dict = field(default_factory=dict)
+
+    @classmethod
+    def from_dict(cls, d):
+        known = {k: v for k, v in d.items() if k in cls.__dataclass_fields__}
+        return cls(**known, extra={k: v for k, v in d.items() if k not in cls.__dataclass_fields__})
+
+
+# ------------------------------------------------------------------ losses / update
+def policy_loss_terms(ac, batch, clip_param):
+    """ppo_utils.py:82-96."""
+    mean, logstd = ac.actor(batch['obs'])
+    logp = normal_log_prob(mean, logstd, batch['act'])
+    ratio = torch.exp(logp - batch['logp'])
+    adv = batch['adv']
+    clip_adv = torch.clamp(ratio, 1 - clip_param, 1 + clip_param) * adv
+    policy_loss = -torch.min(ratio * adv, clip_adv).mean()
+    entropy_loss = -normal_entropy(logstd).expand(logp.shape[0]).mean()
+    approx_kl = (batch['logp'] - logp).mean()
+    return policy_loss, entropy_loss, approx_kl
+
+
+def value_loss_term(ac, batch, clip_param, use_clipped_value):
+    """ppo_utils.py:98-111."""
+    v_cur = ac.critic(batch['obs']).squeeze(-1)
+    ret = batch['ret']
+    if use_clipped_value:
+        v_old = batch['v']
+        v_clipped = v_old + (v_cur - v_old).clamp(-clip_param, clip_param)
+        return 0.5 * torch.max((v_cur - ret).pow(2), (v_clipped - ret).pow(2)).mean()
+    return 0.5 * (v_cur - ret).pow(2).mean()
+
+
+class PPOAgent:
+    def __init__(self, obs_dim, act_dim, cfg: PPOConfig, device):
+        self.cfg = cfg
+        self.ac = MLPActorCritic(obs_dim, act_dim, [cfg.hidden_dim] * 2, cfg.activation).to(device)
+        self.actor_opt = torch.optim.Adam(self.ac.actor.parameters(), cfg.actor_lr)
+        self.critic_opt = torch.optim.Adam(self.ac.critic.parameters(), cfg.critic_lr)
+        parallel.broadcast_parameters([self.ac])
+        self._bucket = None
+
+    def state_dict(self):
+        return {'ac': self.ac.state_dict(), 'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.ac.load_state_dict(sd['ac'])
+        if 'actor_opt' in sd:
+            self.actor_opt.load_state_dict(sd['actor_opt'])
+            self.critic_opt.load_state_dict(sd['critic_opt'])
+
+    def update(self, data, generator=None):
+        """`data`: dict of flat [M, .] tensors (obs, act, logp, adv, ret, v).  Epochs x shuffled minibatches, drop last
+        (ppo_utils.py:113-146, :358-371).  Returns the reference's averaged loss statistics."""
+        cfg = self.cfg
+        M = data['obs'].shape[0]
+        mb = min(cfg.mini_batch_size, M)
+        n_mb = M // mb
+        assert n_mb != 0, 'num_mini_batch is 0'
+        if self._bucket is None:
+            params = list(self.ac.actor.parameters()) + list(self.ac.critic.parameters())
+            self._bucket = parallel.FlatBucket(params, n_scalars=1)
+        stats = torch.zeros(4, device=data['obs'].device)
+        n_actor_steps = 0
+        for _ in range(cfg.opt_epochs):
+            perm = torch.randperm(M, device=data['obs'].device, generator=generator)[:n_mb * mb].view(n_mb, mb)
+            for idx in perm:
+                batch = {k: v[idx] for k, v in data.items()}
+                policy_loss, entropy_loss, approx_kl = policy_loss_terms(self.ac, batch, cfg.clip_param)
+                value_loss = value_loss_term(self.ac, batch, cfg.clip_param, cfg.use_clipped_value)
+                self.actor_opt.zero_grad(set_to_none=False)
+                self.critic_opt.zero_grad(set_to_none=False)
+                (policy_loss + cfg.entropy_coef * entropy_loss).backward()
+                value_loss.backward()
+                if parallel.world_size() > 1:
+                    # one flat all-reduce: both networks' gradients + approx_kl, so every rank gates identically
+                    self._bucket.pack([approx_kl.detach()])
+                    self._bucket.all_reduce_mean()
+                    kl = self._bucket.unpack()[0]
+                else:
+                    kl = approx_kl.detach()
+                # update only when no KL constraint or the constraint is satisfied (ppo_utils.py:127-131)
+                if cfg.target_kl <= 0 or float(kl) <= 1.5 * cfg.target_kl:
+                    self.actor_opt.step()
+                    n_actor_steps += 1
+                self.critic_opt.step()
+                stats += torch.stack([policy_loss.detach(), value_loss.detach(), entropy_loss.detach(), kl])
+        stats = (stats / (cfg.opt_epochs * n_mb)).tolist()
+        return {'policy_loss': stats[0], 'value_loss': stats[1], 'entropy_loss': stats[2], 'approx_kl': stats[3],
+                'actor_steps': n_actor_steps, 'minibatches': cfg.opt_epochs * n_mb}
+
+
+# ------------------------------------------------------------------ collector + trainer
+class PPO:
+    """PPO.train_step / learn / run on a HipVecEnv (ppo.py:150-303)."""
+
+    def __init__(self, env, cfg: PPOConfig, seed=0):
+        from safe_control_gym_amd.rollout import gae_returns
+        self._gae = gae_returns
+        self.env, self.cfg = env, cfg
+        self.device, self.dtype = env.device, env.dtype
+        if self.dtype != torch.float32:
+            raise ValueError('the PPO collector runs on float32 environments')
+        self.N, self.T = env.num_envs, cfg.rollout_steps
+        spec = env.spec
+        self.obs_dim, self.act_dim = spec.obs_dim, spec.nu
+        rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
+        torch.manual_seed(seed + 7919 * rank)       # per-rank action-sampling stream; weights are broadcast from rank 0
+        self.agent = PPOAgent(self.obs_dim, self.act_dim, cfg, self.device)
+        T, N = self.T, self.N
+        f = dict(device=self.device, dtype=torch.float32)
+        # rollout storage, [T(+1), N, .]; the step kernel writes obs[t+1], rew[t], done[t], flags[t], term_obs[t] in place
+        self.obs = torch.zeros(T + 1, N, self.obs_dim, **f)
+        self.act = torch.zeros(T, N, self.act_dim, **f)
+        self.rew = torch.zeros(T, N, **f)
+        self.done = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+        self.flags = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+        self.term_obs = torch.zeros(T, N, self.obs_dim, **f)
+        self.v = torch.zeros(T, N, **f)
+        self.logp = torch.zeros(T, N, **f)
+        self._slots = [env.bind_outputs(obs=self.obs[t + 1], reward=self.rew[t], done=self.done[t], flags=self.flags[t],
+                                        terminal_obs=self.term_obs[t], state=None, noisy_action=None, c_values=None,
+                                        mse=None) for t in range(T)]
+        self.total_steps = 0
+        self.obs[0].copy_(env.reset_tensors())
+        # finished-episode statistics (VecRecordEpisodeStatistics), accumulated on device
+        self.ep_count = torch.zeros((), device=self.device)
+        self.ep_return_sum = torch.zeros((), device=self.device)
+        self.ep_length_sum = torch.zeros((), device=self.device)
+        self.ep_violation_sum = torch.zeros((), device=self.device)
+
+    # ---- rollout (ppo.py:266-284)
+    def collect(self):
+        ac, env = self.agent.ac, self.env
+        for t in range(self.T):
+            act, v, logp = ac.step(self.obs[t])
+            self.act[t], self.v[t], self.logp[t] = act, v, logp
+            out, c_out = self._slots[t]
+            env.step_tensors(self.act[t], out=out, c_out=c_out)
+            d = self.done[t].to(torch.float32)
+            self.ep_count += d.sum()
+            self.ep_return_sum += (out.fin_return * d).sum()
+            self.ep_length_sum += (out.fin_length.to(torch.float32) * d).sum()
+            self.ep_violation_sum += (out.fin_violation * d).sum()
+        self.total_steps += self.T * self.N * parallel.world_size()
+
+    # ---- returns / advantages / update (ppo.py:286-303)
+    def train_step(self):
+        cfg = self.cfg
+        t0 = time.perf_counter()
+        self.collect()
+        ac = self.agent.ac
+        with torch.no_grad():
+            last_val = ac.critic(self.obs[self.T]).squeeze(-1)
+            mask = 1.0 - self.done.to(torch.float32)
+            # time truncation is not termination: bootstrap with the critic's value of the terminal observation
+            terminal_v = torch.zeros_like(self.rew)
+            trunc = (self.flags & 1).bool() & self.done.bool()
+            idx = trunc.nonzero(as_tuple=False)
+            if idx.numel():
+                tv = ac.critic(self.term_obs[idx[:, 0], idx[:, 1]]).squeeze(-1)
+                terminal_v[idx[:, 0], idx[:, 1]] = tv
+            rew = self.rew.clone()
+            ret, adv = self._gae(rew, self.v, mask, terminal_v, last_val, cfg.gamma, cfg.gae_lambda, cfg.use_gae)
+            # global advantage normalisation (ppo.py:300): population std, +1e-6
+            moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)])
+            parallel.all_reduce_sum_(moments)
+            mean = moments[0] / moments[2]
+            std = torch.sqrt(torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0))
+            adv = (adv - mean) / (std + 1e-6)
+        M = self.T * self.N
+        data = {'obs': self.obs[:self.T].reshape(M, self.obs_dim), 'act': self.act.reshape(M, self.act_dim),
+                'logp': self.logp.reshape(M), 'adv': adv.reshape(M), 'ret': ret.reshape(M), 'v': self.v.reshape(M)}
+        t1 = time.perf_counter()
+        res = self.agent.update(data)
+        self.obs[0].copy_(self.obs[self.T])
+        res.update({'step': self.total_steps, 'collect_time': t1 - t0, 'elapsed_time': time.perf_counter() - t0})
+        return res
+
+    def episode_stats(self, reset=True):
+        s = torch.stack([self.ep_count, self.ep_return_sum, self.ep_length_sum, self.ep_violation_sum])
+        parallel.all_reduce_sum_(s)
+        n = max(float(s[0]), 1.0)
+        out = {'episodes': float(s[0]), 'ep_return': float(s[1]) / n, 'ep_length': float(s[2]) / n,
+               'ep_constraint_violation': float(s[3]) / n}
+        if reset:
+            for t in (self.ep_count, self.ep_return_sum, self.ep_length_sum, self.ep_violation_sum):
+                t.zero_()
+        return out
+
+    def learn(self, max_env_steps=None, log=None, target_return=None, eval_env=None, eval_every=1):
+        """Train until max_env_steps (or until the evaluation return reaches target_return)."""
+        max_env_steps = max_env_steps or self.cfg.max_env_steps
+        history = []
+        t_start = time.perf_counter()
+        it = 0
+        while self.total_steps < max_env_steps:
+            res = self.train_step()
+            it += 1
+            res.update(self.episode_stats())
+            res['wall_clock'] = time.perf_counter() - t_start
+            if eval_env is not None and it % eval_every == 0:
+                res['eval_return'] = evaluate(self.agent.ac, eval_env)['ep_return']
+            history.append(res)
+            if log:
+                log(res)
+            if target_return is not None and res.get('eval_return', -1e30) >= target_return:
+                break
+        return history
+
+
+@torch.no_grad()
+def evaluate(ac, env, episodes_per_env=1):
+    """Deterministic policy (action = mean, ppo_utils.py:233-238) on every env of `env` until each finished
+    `episodes_per_env` episodes; returns mean episode return / length / violations / mse (batched counterpart of
+    PPO.run, ppo.py:210-257)."""
+    obs = env.reset_tensors()
+    N = env.num_envs
+    count = torch.zeros(N, device=env.device)
+    ret = torch.zeros(N, device=env.device)
+    length = torch.zeros(N, device=env.device)
+    viol = torch.zeros(N, device=env.device)
+    mse = torch.zeros(N, device=env.device)
+    max_steps = int(env.spec.CTRL_STEPS) * episodes_per_env + 1
+    for _ in range(max_steps):
+        out = env.step_tensors(ac.act(obs))
+        obs = out.obs
+        d = out.done.bool() & (count < episodes_per_env)
+        df = d.to(torch.float32)
+        ret += out.fin_return * df
+        length += out.fin_length.to(torch.float32) * df
+        viol += out.fin_violation * df
+        mse += out.fin_mse * df
+        count += df
+        if bool((count >= episodes_per_env).all()):
+            break
+    n = count.sum().clamp(min=1.0)
+    return {'episodes': float(count.sum()), 'ep_return': float(ret.sum() / n), 'ep_length': float(length.sum() / n),
+            'ep_constraint_violation': float(viol.sum() / n), 'ep_mse': float(mse.sum() / n)}
