@@ -254,6 +254,8 @@ int scg_set_state(scg_env* env, const double* h_state, int first_env, int n, voi
 int scg_get_state(scg_env* env, double* h_state, int first_env, int n, void* stream);
 int scg_set_params(scg_env* env, const double* h_params, int first_env, int n, void* stream);
 int scg_get_params(scg_env* env, double* h_params, int first_env, int n, void* stream);
+/* BenchmarkEnv.seed (benchmark_env.py:193-214): new Philox key for subsequent draws. */
+int scg_set_seed(scg_env* env, uint64_t seed);
 /* ctrl_step_counter / episode index per env (benchmark_env.py:329-330). */
 int scg_set_counters(scg_env* env, const int32_t* h_step, const uint32_t* h_episode, int first_env, int n, void* stream);
 int scg_get_counters(scg_env* env, int32_t* h_step, uint32_t* h_episode, int first_env, int n, void* stream);

@@ -1,0 +1,232 @@
+"""Single-environment facade with the reference's `BenchmarkEnv` surface, backed by a batch-of-1 HIP env.
+
+Mirrors /root/reference/safe_control_gym/envs/benchmark_env.py:42-502 and the attributes controllers / the experiment
+harness read: `reset(seed) -> (obs, info)`, `step(action) -> (obs, reward, done, info)` (4-tuple, no
+auto-reset), `X_GOAL U_GOAL TASK COST NAME QUAD_TYPE CTRL_FREQ CTRL_TIMESTEP EPISODE_LEN_SEC action_space
+observation_space state_space physical_action_bounds symbolic constraints state current_*_action STATE_LABELS ...
+normalize_action denormalize_action set_adversary_control seed close`.
+"""
+from enum import Enum, IntEnum
+
+import numpy as np
+import torch
+
+from safe_control_gym_amd.symbolic import AnalyticModel
+from safe_control_gym_amd.vec_env import HipVecEnv
+
+
+class Cost(str, Enum):
+    RL_REWARD = 'rl_reward'
+    QUADRATIC = 'quadratic'
+
+
+class Task(str, Enum):
+    STABILIZATION = 'stabilization'
+    TRAJ_TRACKING = 'traj_tracking'
+
+
+class Environment(str, Enum):
+    CARTPOLE = 'cartpole'
+    QUADROTOR = 'quadrotor'
+
+
+class QuadType(IntEnum):
+    ONE_D = 1
+    TWO_D = 2
+    THREE_D = 3
+
+
+# default task configs: the YAML files next to the reference's env classes (cartpole.yaml / quadrotor.yaml)
+CARTPOLE_DEFAULT_CONFIG = dict(
+    ctrl_freq=50, pyb_freq=50, gui=False, normalized_rl_action_space=False, episode_len_sec=5, init_state=None,
+    randomized_init=True, init_state_randomization_info=None, inertial_prop=None, randomized_inertial_prop=False,
+    inertial_prop_randomization_info=None, task='stabilization', task_info=None, cost='rl_reward', disturbances=None,
+    adversary_disturbance=None, adversary_disturbance_offset=0.0, adversary_disturbance_scale=0.01, constraints=None,
+    done_on_violation=False, use_constraint_penalty=False, constraint_penalty=-1, verbose=False, obs_wrap_angle=False,
+    obs_goal_horizon=0, rew_state_weight=1.0, rew_act_weight=0.0001, rew_exponential=True, done_on_out_of_bound=True)
+QUADROTOR_DEFAULT_CONFIG = dict(
+    ctrl_freq=60, pyb_freq=240, physics='pyb', gui=False, quad_type=2, normalized_rl_action_space=False, episode_len_sec=5,
+    init_state=None, randomized_init=False, init_state_randomization_info=None, inertial_prop=None,
+    randomized_inertial_prop=False, inertial_prop_randomization_info=None, task='stabilization', task_info=None,
+    cost='rl_reward', disturbances=None, adversary_disturbance=None, adversary_disturbance_offset=0.0,
+    adversary_disturbance_scale=0.01, constraints=None, done_on_violation=False, use_constraint_penalty=False,
+    constraint_penalty=-1, verbose=False, norm_act_scale=0.1, obs_goal_horizon=0, rew_state_weight=1.0,
+    rew_act_weight=0.0001, rew_exponential=True, done_on_out_of_bound=True)
+
+
+class ConstraintView:
+    """What `env.constraints` exposes to callers that only read sizes / values (ConstraintList, constraints.py:473-636)."""
+
+    def __init__(self, env):
+        self._env = env
+        spec = env._venv.spec
+        self.num_constraints = len(spec.con_rows)
+        self.num_state_constraints = spec.n_state_con_rows
+        self.num_input_constraints = sum(1 for r in spec.con_rows if r['var'] == 1)
+        self.constraints = spec.con_meta
+        self.state_constraints = [m for m in spec.con_meta if m['var'] == 'state']
+        self.input_constraints = [m for m in spec.con_meta if m['var'] == 'input']
+
+    def __len__(self):
+        return len(self.constraints)
+
+    def get_values(self, env=None, only_state=False):
+        c = self._env._last_c_values
+        return c[:self.num_state_constraints] if only_state else c
+
+    def is_violated(self, env=None, c_value=None):
+        return bool(self._env._last_violation)
+
+
+class BenchmarkEnv:
+    NAME = 'base'
+
+    def __init__(self, seed=None, device=None, dtype=torch.float64, specialize='auto', output_dir=None, gui=False,
+                 verbose=False, **task_config):
+        if gui:
+            raise NotImplementedError('no GUI / rendering in the HIP simulator')
+        self.idx = 0
+        self.output_dir, self.GUI, self.VERBOSE = output_dir, gui, verbose
+        self._seed_value = 0 if seed is None else int(seed)
+        self._venv = HipVecEnv(self.NAME, 1, seed=self._seed_value, device=device, dtype=dtype, return_numpy=False,
+                               auto_reset=False, specialize=specialize, **task_config)
+        spec = self._venv.spec
+        for k in ('X_GOAL', 'U_GOAL', 'CTRL_FREQ', 'PYB_FREQ', 'CTRL_TIMESTEP', 'PYB_TIMESTEP', 'EPISODE_LEN_SEC', 'CTRL_STEPS',
+                  'PYB_STEPS_PER_CTRL', 'NORMALIZED_RL_ACTION_SPACE', 'action_space', 'observation_space', 'state_space',
+                  'physical_action_bounds', 'GRAVITY_ACC', 'TASK_INFO', 'obs_goal_horizon', 'rew_exponential',
+                  'rew_state_weight', 'rew_act_weight', 'Q', 'R', 'done_on_out_of_bound', 'info_mse_metric_state_weight',
+                  'DISTURBANCE_MODES', 'adversary_disturbance'):
+            setattr(self, k, getattr(spec, k))
+        self.TASK, self.COST = Task(spec.TASK), Cost(spec.COST)
+        self.STATE_LABELS, self.STATE_UNITS = spec.state_labels, spec.state_units
+        self.ACTION_LABELS, self.ACTION_UNITS = spec.action_labels, spec.action_units
+        self.state_dim, self.action_dim, self.obs_dim = spec.nx, spec.nu, spec.obs_dim
+        self.num_constraints = len(spec.con_rows)
+        self.constraints = ConstraintView(self) if spec.con_rows else None
+        self.DONE_ON_VIOLATION = bool(spec.kw['done_on_violation'])
+        self.use_constraint_penalty = bool(spec.kw['use_constraint_penalty'])
+        self.constraint_penalty = spec.kw['constraint_penalty']
+        if spec.adversary_disturbance is not None:
+            self.adversary_action_space = spec.adversary_action_space
+            self.adversary_observation_space = spec.observation_space
+        self.symbolic = AnalyticModel(self.NAME, spec, spec.kw.get('prior_prop') or {})
+        self.np_random = np.random.default_rng(seed)
+        self.action_space.seed(seed)
+        self.initial_reset = False
+        self.pyb_step_counter = self.ctrl_step_counter = 0
+        self.current_raw_action = self.current_physical_action = None
+        self.current_noisy_physical_action = self.current_clipped_action = None
+        self._last_c_values = np.zeros(self.num_constraints)
+        self._last_violation = False
+        self.state = None
+
+    # ---- seeding (benchmark_env.py:193-214)
+    def seed(self, seed=None):
+        self._seed_value = 0 if seed is None else int(seed)
+        self.np_random = np.random.default_rng(seed)
+        self.action_space.seed(seed)
+        self._venv.seed(self._seed_value)
+        return [seed]
+
+    def _info_common(self):
+        o = self._venv.out
+        self.state = o.state[:, 0].cpu().numpy().astype(np.float64)
+
+    def reset(self, seed=None):
+        if seed is not None:
+            self.seed(seed)
+        self.initial_reset = True
+        self.pyb_step_counter = self.ctrl_step_counter = 0
+        self.current_raw_action = self.current_physical_action = None
+        self.current_noisy_physical_action = self.current_clipped_action = None
+        obs = self._venv.reset_tensors()[0].cpu().numpy().astype(np.float64)
+        self._info_common()
+        info = dict(self._venv._reset_info({'c_values': self._host_c(), 'done': [False]}, 0, with_constraints=True))
+        info['symbolic_model'] = self.symbolic
+        if self.constraints is not None:
+            info['symbolic_constraints'] = [m['form'] for m in self._venv.spec.con_meta]
+        return obs, info
+
+    def _host_c(self):
+        c = self._venv.out.c_values
+        return None if c is None else c.t().cpu().numpy()
+
+    def step(self, action):
+        if not self.initial_reset:
+            raise RuntimeError('[ERROR] You must call env.reset() at least once before using env.step().')
+        action = np.atleast_1d(np.squeeze(action))
+        if action.ndim != 1:
+            raise ValueError('[ERROR]: The action returned by the controller must be 1 dimensional.')
+        self.current_raw_action = action
+        self.current_physical_action = self.denormalize_action(action)
+        a = torch.as_tensor(action.reshape(1, -1), dtype=self._venv.dtype, device=self._venv.device)
+        adv = self._venv._adv
+        self._venv._adv = None
+        out = self._venv.step_tensors(a, adv)
+        self.ctrl_step_counter += 1
+        self.pyb_step_counter += self.PYB_STEPS_PER_CTRL
+        self._info_common()
+        noisy = out.noisy_action[:, 0].cpu().numpy().astype(np.float64)
+        self.current_noisy_physical_action = noisy
+        self.current_clipped_action = np.clip(noisy, self.physical_action_bounds[0], self.physical_action_bounds[1])
+        flags = int(out.flags[0])
+        done = bool(out.done[0])
+        info = {'current_step': self.ctrl_step_counter, 'constraint_violation': int(bool(flags & 2)),
+                'mse': float(out.mse[0])}
+        if self.constraints is not None:
+            self._last_c_values = self._host_c()[0].astype(np.float64)
+            self._last_violation = bool(flags & 2)
+            info['constraint_values'] = self._last_c_values
+        if self.done_on_out_of_bound:
+            info['out_of_bounds'] = bool(flags & 4)
+        if self.TASK == Task.STABILIZATION and self.COST == Cost.QUADRATIC:
+            info['goal_reached'] = bool(flags & 8)
+        if self.ctrl_step_counter >= self.CTRL_STEPS:
+            info['TimeLimit.truncated'] = bool(flags & 1)
+        obs = out.obs[0].cpu().numpy().astype(np.float64)
+        return obs, float(out.reward[0]), done, info
+
+    def set_adversary_control(self, action):
+        self._venv.set_adversary_control(np.asarray(action, dtype=np.float64).reshape(1, -1))
+
+    def close(self):
+        self._venv.close()
+
+    def render(self, mode='human'):
+        raise NotImplementedError('no rendering in the HIP simulator')
+
+
+class CartPole(BenchmarkEnv):
+    NAME = 'cartpole'
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        s = self._venv.spec
+        self.EFFECTIVE_POLE_LENGTH, self.POLE_MASS, self.CART_MASS = s.EFFECTIVE_POLE_LENGTH, s.POLE_MASS, s.CART_MASS
+        self.action_scale = s.action_scale
+        self.x_threshold, self.theta_threshold_radians = s.x_threshold, s.theta_threshold_radians
+
+    def normalize_action(self, action):           # cartpole.py:504-516
+        return action / self.action_scale if self.NORMALIZED_RL_ACTION_SPACE else action
+
+    def denormalize_action(self, action):         # cartpole.py:518-530
+        return self.action_scale * action if self.NORMALIZED_RL_ACTION_SPACE else action
+
+
+class Quadrotor(BenchmarkEnv):
+    NAME = 'quadrotor'
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        s = self._venv.spec
+        self.QUAD_TYPE = QuadType(s.quad_type)
+        self.MASS, self.J, self.L, self.KF, self.KM = s.MASS, s.J, s.L, s.KF, s.KM
+        self.norm_act_scale, self.hover_thrust = s.norm_act_scale, s.hover_thrust
+        self.PWM2RPM_SCALE, self.PWM2RPM_CONST, self.MIN_PWM, self.MAX_PWM = s.PWM2RPM_SCALE, s.PWM2RPM_CONST, s.MIN_PWM, s.MAX_PWM
+        self.GROUND_PLANE_Z = s.GROUND_PLANE_Z
+
+    def normalize_action(self, action):           # quadrotor.py:749-761
+        return (action / self.hover_thrust - 1) / self.norm_act_scale if self.NORMALIZED_RL_ACTION_SPACE else action
+
+    def denormalize_action(self, action):         # quadrotor.py:763-775
+        return (1 + self.norm_act_scale * action) * self.hover_thrust if self.NORMALIZED_RL_ACTION_SPACE else action

@@ -656,6 +656,12 @@ extern "C" int scg_get_params(scg_env* env, double* h_params, int first_env, int
     return env->dtype == SCG_F64 ? copy_soa<double>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream)
                                  : copy_soa<float>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream);
 }
+extern "C" int scg_set_seed(scg_env* env, uint64_t seed) {
+    if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
+    env->cfg.seed = seed;
+    return SCG_OK;
+}
+
 extern "C" int scg_set_counters(scg_env* env, const int32_t* h_step, const uint32_t* h_episode, int first_env, int n, void* stream) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
     if (first_env < 0 || n < 0 || first_env + n > env->cfg.num_envs) return fail(SCG_ERR_INVALID, "env range out of bounds");

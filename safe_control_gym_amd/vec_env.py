@@ -383,6 +383,12 @@ class HipVecEnv(VecEnv):
                 self._h, sp.ctypes.data_as(C.POINTER(C.c_int32)) if sp is not None else None,
                 ep.ctypes.data_as(C.POINTER(C.c_uint32)) if ep is not None else None, 0, self.num_envs, self._stream()))
 
+    def seed(self, seed):
+        """New Philox key for every env of the batch (BenchmarkEnv.seed, benchmark_env.py:193-214)."""
+        self.seed_value = int(seed)
+        self._chk(self._lib.scg_set_seed(self._h, C.c_uint64(self.seed_value & 0xFFFFFFFFFFFFFFFF)))
+        return [seed]
+
     def _n_state_arrays(self):
         return {L.CARTPOLE: 4, L.QUAD_1D: 2, L.QUAD_2D: 6, L.QUAD_3D: 13}[self.spec.system]
 
