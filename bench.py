@@ -45,28 +45,45 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(task, cfg, env_id, budget_s):
-    """The float64 NumPy oracle (port of the reference's per-env Python + Bullet step) timed on the host:
-    batched over 4096 envs on one core, random actions, for ~budget_s seconds."""
+def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
+    """CPU path timed on this box's host cores, same workload (task config, env count, random actions):
+    oracle/scg_oracle.c — the double-precision C restatement of the control step (validated against the NumPy oracle,
+    which is pinned to the reference's own Python) — with OpenMP over all cores, for ~budget_s seconds."""
     import numpy as np
+    from oracle.c_port import CPort
     from oracle.envs import make_oracle_env, make_rng
     from oracle.vec import OracleVecEnv
-    n = 4096
-    env = OracleVecEnv(make_oracle_env(env_id, n, make_rng('philox', n, 42), **cfg))
-    env.reset()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault('OMP_NUM_THREADS', str(cores))
+    small = make_oracle_env(env_id, 8, make_rng('philox', 8, 42), **cfg)            # constants / tables only
+    small.num_envs = n_envs
+    port = CPort(small, seed=42)
+    port.reset()
     rng = np.random.default_rng(0)
-    nu = env.env.action_dim
+    acts = rng.uniform(-1, 1, size=(4, n_envs, small.action_dim))
+    port.step(acts[0])                                                              # warm-up (page faults, threads)
     steps = 0
     t0 = time.perf_counter()
     while True:
-        env.step(rng.uniform(-1, 1, size=(n, nu)))
+        port.step(acts[steps % 4])
         steps += 1
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    return {'value': n * steps / el, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'oracle/ (float64 NumPy restatement, batched over {n} envs), {steps} control steps of {task} '
-                      f'with random actions in {el:.1f} s on 1 host core; reference README (1 env, PyBullet, '
+    c_rate = n_envs * steps / el
+    # for scale: the NumPy oracle (the reference's per-env Python structure, batched), 1 core, 2 s
+    n_np = 1024
+    onp = OracleVecEnv(make_oracle_env(env_id, n_np, make_rng('philox', n_np, 42), **cfg))
+    onp.reset()
+    k, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0:
+        onp.step(rng.uniform(-1, 1, size=(n_np, small.action_dim)))
+        k += 1
+    np_rate = n_np * k / (time.perf_counter() - t1)
+    return {'value': c_rate, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/scg_oracle.c (float64 C restatement of the control step, gcc -O3 -fopenmp, {cores} threads), '
+                      f'{n_envs} envs x {steps} control steps of {task} with random actions in {el:.1f} s; '
+                      f'NumPy oracle on 1 core: {np_rate:.3g} env-steps/s; reference README (1 PyBullet env, '
                       f'i7-1068NG7): 381-464 env-steps/s'}
 
 
@@ -188,7 +205,7 @@ def main():
                          'algorithmic_bytes_per_env_step': algo},
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(args.task, cfg, env_id, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(args.task, cfg, env_id, args.cpu_seconds, N)
             out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
         print(json.dumps(out))
     env.close()

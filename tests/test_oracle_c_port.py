@@ -1,0 +1,35 @@
+"""The OpenMP C port used as bench.py's cpu_baseline must agree with the NumPy oracle (which is pinned to the
+reference's own Python by tests/golden)."""
+import numpy as np
+import pytest
+
+from oracle.c_port import CPort
+from oracle.envs import make_oracle_env, make_rng
+from oracle.vec import OracleVecEnv
+from safe_control_gym_amd.registration import load_task
+
+
+@pytest.mark.parametrize('task', ['quadrotor_2D_track', 'cartpole_stab', 'quadrotor_3D_track'])
+def test_c_port_matches_numpy_oracle(task):
+    env_id, cfg = load_task(task)
+    n, seed = 64, 9
+    oracle = make_oracle_env(env_id, n, make_rng('philox', n, seed), **cfg)
+    ovec = OracleVecEnv(oracle)
+    port = CPort(oracle, seed)
+    obs_o, _ = ovec.reset()
+    np.testing.assert_allclose(port.reset(), obs_o, rtol=1e-12, atol=1e-12)
+    rng = np.random.default_rng(0)
+    n_done = 0
+    for t in range(300):
+        act = rng.uniform(-1, 1, size=(n, oracle.action_dim))
+        obs_o, rew_o, done_o, info = ovec.step(act)
+        obs_c, rew_c, done_c = port.step(act)
+        np.testing.assert_array_equal(done_c, done_o, err_msg=f't={t}')
+        np.testing.assert_allclose(rew_c, rew_o, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(obs_c, obs_o, rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(port.mse, info['mse'], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(port.cvals[:, :port.cfg.n_rows], info['constraint_values'], rtol=0, atol=2e-8)
+        np.testing.assert_array_equal((port.flags & 2) != 0, info['constraint_violation'] != 0)
+        np.testing.assert_array_equal((port.flags & 1) != 0, info['truncated'])
+        n_done += int(done_o.sum())
+    assert n_done > 0
