@@ -70,6 +70,19 @@ __device__ __forceinline__ double m_floor(double x) { return floor(x); }
 __device__ __forceinline__ float m_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ double m_clamp(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 template <typename T> __device__ __forceinline__ T m_max(T a, T b) { return a > b ? a : b; }
+// x / c and sqrt(x) where the float path may use the 1-ulp hardware forms (v_rcp / v_sqrt, ~10 fewer VALU
+// each than the IEEE expansions); the double path keeps the exact operations the oracle performs.
+__device__ __forceinline__ float m_div_by(float x, float c) { return x * __builtin_amdgcn_rcpf(c); }
+__device__ __forceinline__ double m_div_by(double x, double c) { return x / c; }
+__device__ __forceinline__ float m_sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double m_sqrt_fast(double x) { return sqrt(x); }
+
+// Scheduling fences.  vmcnt retires in order and counts stores as well as loads, so a load whose first use
+// sits after a run of stores makes the wave wait for the store acknowledgements too; `vreg_fence` forces the
+// wait to the point where it is placed (before the stores).  `sreg_fence` does the same for kernel
+// arguments: every s_load is issued in the entry block, in one scalar-memory round.
+template <typename V> __device__ __forceinline__ void vreg_fence(const V& x) { asm volatile("" ::"v"(x)); }
+template <typename V> __device__ __forceinline__ void sreg_fence(const V& x) { asm volatile("" ::"s"(x)); }
 
 template <typename T> struct Const {
     static constexpr T PI = (T)3.14159265358979323846;
@@ -81,7 +94,7 @@ template <typename T> struct Const {
 template <typename T>
 __device__ __forceinline__ T normalize_angle(T x) {
     T y = x + Const<T>::PI;
-    y = y - Const<T>::TWO_PI * m_floor(y / Const<T>::TWO_PI);
+    y = y - Const<T>::TWO_PI * m_floor(m_div_by(y, Const<T>::TWO_PI));
     return y - Const<T>::PI;
 }
 
@@ -541,7 +554,8 @@ SCG_BOX_UNROLL
     __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,
                                                       T* st, T* noisy_out, T* c_out, size_t c_stride,
-                                                      const T* ref_pre = nullptr) {
+                                                      const T* ref_pre = nullptr, const T* ext_pre = nullptr,
+                                                      const T* ext_reset = nullptr) {
         const int32_t c0 = e.step;      // ctrl_step_counter before the increment
         // ---- _preprocess_control
         T noisy[D::NU], clipped[D::NU];
@@ -628,7 +642,7 @@ SCG_BOX_UNROLL
 #pragma unroll
             for (int j = 0; j < D::NU; ++j) {
                 T thr = m_max(clipped[j], (T)0);
-                pwm[j] = (m_sqrt(thr / (T)n_motor / P.c.kf) - P.c.pwm2rpm_const) / P.c.pwm2rpm_scale;
+                pwm[j] = m_div_by(m_sqrt_fast(m_div_by(thr / (T)n_motor, P.c.kf)) - P.c.pwm2rpm_const, P.c.pwm2rpm_scale);
             }
             if constexpr (D::NU == 1) { pwm[1] = pwm[0]; pwm[2] = pwm[0]; pwm[3] = pwm[0]; }
             if constexpr (D::NU == 2) { pwm[2] = pwm[1]; pwm[3] = pwm[0]; }
@@ -758,6 +772,19 @@ SCG_BOX_UNROLL
             }
         }
         state_vector(e, st);
+        // rows of X_GOAL requested before the integrator: retire them here, ahead of the first store
+        if (ref_pre) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) vreg_fence(ref_pre[k]);
+        }
+        if (ext_pre) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) vreg_fence(ext_pre[k]);
+        }
+        if (ext_reset) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) vreg_fence(ext_reset[k]);
+        }
 
         // ---- reference row for reward / mse (tracking: X_GOAL[min(c+1, L-1)])
         T ref[D::NX];
