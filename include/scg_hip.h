@@ -181,28 +181,28 @@ typedef struct {
 } scg_config;
 
 /* Outputs of one vectorised control step (dummy_vec_env.py:29-41 `step_wait` +
- * record_episode_statistics.py:139-166).  Any pointer may be NULL = output not wanted. */
+ * record_episode_statistics.py:139-166).  d_obs, d_reward, d_done, d_flags are always written; any other pointer
+ * may be NULL = output not wanted.  Row-major arrays; T = the env's dtype.  Per-env rows ([N][k]) must be 16-byte
+ * aligned.  The step kernel is fastest when all bound arrays lie within one 4 GiB window (e.g. carved from one
+ * allocation): it then addresses them through a single buffer resource. */
 typedef struct {
     void* d_obs;            /* [N][obs_dim]  observation AFTER auto-reset (post-reset obs where done) */
     void* d_reward;         /* [N] */
     uint8_t* d_done;        /* [N] 0/1 */
     uint8_t* d_flags;       /* [N] bit0 TimeLimit.truncated, bit1 constraint_violation, bit2 out_of_bounds,
                                    bit3 goal_reached */
-    void* d_c_values;       /* [N][n_con_rows]  info['constraint_values'] of the step (pre-reset) */
+    void* d_c_values;       /* [n_con_rows][N]  info['constraint_values'] of the step (pre-reset), one row per
+                                   constraint so that every wave stores contiguous 256-byte segments;
+                                   at reset: the state rows, densely in rows 0..n_state_con_rows-1 */
     void* d_mse;            /* [N] info['mse'] */
     void* d_terminal_obs;   /* [N][obs_dim]  written only where done: info['terminal_observation'] */
-    void* d_state;          /* [N][state_dim] env.state after the step and auto-reset */
-    void* d_noisy_action;   /* [N][action_dim] current_noisy_physical_action (pre-clip) */
-    /* columnar VecRecordEpisodeStatistics: accumulators are read-modify-written every step, the
-     * fin_* arrays are written where done with the finished episode's totals. */
-    void* d_ep_return;      /* [N] running return */
-    int32_t* d_ep_length;   /* [N] running length */
-    void* d_ep_violation;   /* [N] running sum of constraint_violation */
-    void* d_ep_mse;         /* [N] running sum of mse */
-    void* d_fin_return;     /* [N] */
-    int32_t* d_fin_length;  /* [N] */
-    void* d_fin_violation;  /* [N] */
-    void* d_fin_mse;        /* [N] */
+    void* d_state;          /* [state_dim][N] env.state after the step and auto-reset */
+    void* d_noisy_action;   /* [action_dim][N] current_noisy_physical_action (pre-clip) */
+    /* columnar VecRecordEpisodeStatistics, one 4-vector per env: (return, length, sum of constraint_violation,
+     * sum of mse), all of type T.  d_ep_stats is read-modify-written every step (zeroed where done);
+     * d_fin_stats receives the finished episode's totals where done. */
+    void* d_ep_stats;       /* [N][4] running totals */
+    void* d_fin_stats;      /* [N][4] */
 } scg_step_out;
 
 /* Totals of a fused K-step random-action rollout (config #2 of BASELINE.json). */

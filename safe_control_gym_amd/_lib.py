@@ -86,8 +86,7 @@ class Config(C.Structure):
 class StepOut(C.Structure):
     _fields_ = [(n, c_vp) for n in (
         'd_obs', 'd_reward', 'd_done', 'd_flags', 'd_c_values', 'd_mse', 'd_terminal_obs', 'd_state',
-        'd_noisy_action', 'd_ep_return', 'd_ep_length', 'd_ep_violation', 'd_ep_mse',
-        'd_fin_return', 'd_fin_length', 'd_fin_violation', 'd_fin_mse')]
+        'd_noisy_action', 'd_ep_stats', 'd_fin_stats')]
 
 
 class RolloutOut(C.Structure):

@@ -28,6 +28,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "scg_params.h"
 #include "scg_rng.h"
 
@@ -39,6 +41,21 @@
 #endif
 
 namespace scg {
+
+// In-kernel timeline probes (tools/timeline.py): a timing-only build records the shader clock of lane 0 of every
+// wave at a few marks.  Compiled out of every shipped library.
+#ifdef SCG_EXP_TIMELINE
+__device__ unsigned long long scg_timeline[4096 * 8];
+__device__ __forceinline__ void scg_tl_mark(int k) {
+    asm volatile("" ::: "memory");
+    const unsigned long long t = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) scg_timeline[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % 4096 * 8 + k] = t;
+    asm volatile("" ::: "memory");
+}
+#define SCG_TL(k) scg_tl_mark(k)
+#else
+#define SCG_TL(k)
+#endif
 
 // ------------------------------------------------------------------ math wrappers
 __device__ __forceinline__ float m_sin(float x) { return sinf(x); }
@@ -122,6 +139,124 @@ __device__ __forceinline__ void small_sinc_cos(T a2, T& sinc, T& ca) {
     }
 }
 
+// One lane's element of a device array, addressed the way the CDNA buffer instructions do it: a uniform resource
+// (4 SGPRs describing one allocation) + a uniform byte offset of the array / row inside it (SGPR soffset) + a 32-bit
+// per-lane byte offset (one VGPR).  `buffer_load/store ... offen` then needs no address arithmetic at all per access
+// (the flat/global forms cost a 64-bit VALU add or a quarter-rate v_mad_i64 each: ~110 of ~950 VALU instructions of
+// the step kernel).  With one wave per SIMD every instruction, scalar or vector, costs a 4-cycle issue slot, so the
+// resources are kept to TWO per kernel: the caller's workspace (all simulator arrays) and the output window (all
+// output arrays, when the caller placed them within 4 GiB of each other — HipVecEnv allocates them from one arena;
+// otherwise each output gets its own resource, 4 SALU more per array).
+// load(k) / store(v, k): element k uniform elements further (row r of an SoA [rows][N] array for k = r*N; component k
+// of an AoS [N][n] array when the lane offset was built with n).
+// The host rejects configurations whose arrays exceed the 32-bit offsets (validate() in scg_kernels.hip).
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0));
+}
+__device__ __forceinline__ int32_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, int32_t) {
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0);
+}
+__device__ __forceinline__ uint32_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint32_t) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0);
+}
+__device__ __forceinline__ uint8_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint8_t) {
+    return __builtin_amdgcn_raw_buffer_load_b8(r, v, s, 0);
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, v, s, 0));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), r, v, s, 0);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, int32_t x) {
+    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)x, r, v, s, 0);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint32_t x) {
+    __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, 0);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint8_t x) {
+    __builtin_amdgcn_raw_buffer_store_b8(x, r, v, s, 0);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, double x) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, v, s, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    // raw buffer (stride 0), no range limit, gfx9 32-bit data format word
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+}
+
+template <typename V>
+struct Slot {
+    using U = typename std::remove_const<V>::type;
+    __amdgpu_buffer_rsrc_t r;
+    uint32_t soff;  // uniform byte offset of the array inside the resource; SCG_NO_OFF = array not present
+    uint32_t off;   // per-lane byte offset
+    __device__ __forceinline__ explicit operator bool() const { return soff != SCG_NO_OFF; }
+    __device__ __forceinline__ U load(size_t k = 0) const { return buf_ld(r, off, soff + (uint32_t)(k * sizeof(V)), U()); }
+    __device__ __forceinline__ void store(U x, size_t k = 0) const { buf_st(r, off, soff + (uint32_t)(k * sizeof(V)), x); }
+    // element index only known per lane / from LDS (not provably uniform): folded into the lane offset
+    __device__ __forceinline__ void store_at(U x, uint32_t k) const { buf_st(r, off + k * (uint32_t)sizeof(V), soff, x); }
+
+    // N consecutive elements of this lane (an AoS row whose lane offset was built with elems_per_lane = N, base
+    // 16-byte aligned): moved in the widest pieces the row pitch allows (16, 8 or 4 bytes).
+    // N consecutive elements of this lane (an AoS row whose lane offset was built with elems_per_lane = N, base
+    // 16-byte aligned): moved in the widest pieces the row pitch allows (16, 8 or 4 bytes).  Vector payloads are
+    // converted with ONE whole-value bit_cast: indexing the builtin's vector result element-wise (v[1], v[2], ...)
+    // miscompiles to element 0 with this clang (ROCm 7.2), for loads of both widths.
+    template <int M> struct Pack { U e[M]; };
+    template <int N>
+    __device__ __forceinline__ void store_row(const U* x) const {
+        constexpr int bytes = N * (int)sizeof(U);
+        constexpr int W = bytes % 16 == 0 ? 16 : bytes % 8 == 0 ? 8 : (int)sizeof(U);
+        constexpr int per = W / (int)sizeof(U);
+#pragma unroll
+        for (int c = 0; c < bytes / W; ++c) {
+            Pack<per> p;
+#pragma unroll
+            for (int j = 0; j < per; ++j) p.e[j] = x[c * per + j];
+            if constexpr (W == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), r, off, soff + (uint32_t)(c * W), 0);
+            else if constexpr (W == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p), r, off, soff + (uint32_t)(c * W), 0);
+            else buf_st(r, off, soff + (uint32_t)(c * W), p.e[0]);
+        }
+    }
+    // chunk c (M elements = 16 bytes) of this lane's row
+    template <int M>
+    __device__ __forceinline__ void store_chunk(const U* x, int c) const {
+        static_assert(M * sizeof(U) == 16, "store_chunk moves 16 bytes");
+        Pack<M> p;
+#pragma unroll
+        for (int j = 0; j < M; ++j) p.e[j] = x[j];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), r, off, soff + (uint32_t)(c * 16), 0);
+    }
+    template <int N>
+    __device__ __forceinline__ void load_row(U* x) const {
+        constexpr int bytes = N * (int)sizeof(U);
+        constexpr int W = bytes % 16 == 0 ? 16 : bytes % 8 == 0 ? 8 : (int)sizeof(U);
+        constexpr int per = W / (int)sizeof(U);
+#pragma unroll
+        for (int c = 0; c < bytes / W; ++c) {
+            Pack<per> p;
+            if constexpr (W == 16) p = __builtin_bit_cast(Pack<per>, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff + (uint32_t)(c * W), 0));
+            else if constexpr (W == 8) p = __builtin_bit_cast(Pack<per>, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff + (uint32_t)(c * W), 0));
+            else p.e[0] = buf_ld(r, off, soff + (uint32_t)(c * W), U());
+#pragma unroll
+            for (int j = 0; j < per; ++j) x[c * per + j] = p.e[j];
+        }
+    }
+};
+// slot inside a shared resource (array at byte offset `soff`), and slot over a stand-alone array
+template <typename V>
+__device__ __forceinline__ Slot<V> slot_in(__amdgpu_buffer_rsrc_t r, uint32_t soff, int lane_index, int elems_per_lane = 1) {
+    return Slot<V>{r, soff, (uint32_t)lane_index * (uint32_t)(elems_per_lane * (int)sizeof(V))};
+}
+template <typename V>
+__device__ __forceinline__ Slot<V> slot(V* base, int lane_index, int elems_per_lane = 1) {
+    return Slot<V>{make_rsrc(base), base ? 0u : SCG_NO_OFF, (uint32_t)lane_index * (uint32_t)(elems_per_lane * (int)sizeof(V))};
+}
+
 // ------------------------------------------------------------------ per-system dimensions
 template <int SYS> struct Dims;
 template <> struct Dims<SCG_CARTPOLE> { enum { NX = 4, NU = 1, NS = 4, NP = 3, DYN = 2 }; };
@@ -147,11 +282,15 @@ struct GoalTab {
 };
 
 // Device view of scg_step_out with typed pointers.
-template <typename T>
-struct StepOut {
-    T* obs; T* reward; uint8_t* done; uint8_t* flags; T* c_values; T* mse; T* terminal_obs; T* state;
-    T* noisy_action; T* ep_return; int32_t* ep_length; T* ep_violation; T* ep_mse;
-    T* fin_return; int32_t* fin_length; T* fin_violation; T* fin_mse;
+// Output arrays of one reset / step call (scg_step_out).  one_base: every bound array lies within 4 GiB of `base`
+// (off[k] = byte offset, SCG_NO_OFF = not bound) and the kernel addresses them through ONE buffer resource; otherwise
+// ptr[k] holds each array's own address (nullptr = not bound).
+enum { OUT_OBS, OUT_REWARD, OUT_DONE, OUT_FLAGS, OUT_C_VALUES, OUT_MSE, OUT_TERMINAL_OBS, OUT_STATE, OUT_NOISY_ACTION,
+       OUT_EP_STATS, OUT_FIN_STATS, OUT_COUNT };
+struct OutTab {
+    char* base;
+    uint32_t off[OUT_COUNT];
+    char* ptr[OUT_COUNT];
 };
 
 enum : uint8_t { FLAG_TRUNCATED = 1, FLAG_VIOLATION = 2, FLAG_OOB = 4, FLAG_GOAL = 8 };
@@ -303,18 +442,19 @@ struct EnvOps {
     // the inertial parameters afterwards (P = LDS copy).
     __device__ static __forceinline__ void load_state(const PV<T>& P, int i, E& e) {
         const size_t N = (size_t)P.i.num_envs;
-        T* __restrict__ sp = P.i.state;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
+        const Slot<T> sp = slot_in<T>(ws, P.i.state_off, i);
 #pragma unroll
-        for (int k = 0; k < D::NS; ++k) e.s[k] = sp[k * N + i];
-        e.step = P.i.step[i];
-        e.episode = P.i.episode[i];
+        for (int k = 0; k < D::NS; ++k) e.s[k] = sp.load(k * N);
+        e.step = slot_in<int32_t>(ws, P.i.step_off, i).load();
+        e.episode = slot_in<uint32_t>(ws, P.i.episode_off, i).load();
         e.gid = (uint32_t)(P.i.env_id_offset + i);
     }
     __device__ static __forceinline__ void load_params(const PV<T>& P, int i, E& e) {
         const size_t N = (size_t)P.i.num_envs;
         if (P.c.per_env_params) {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k) e.par[k] = P.i.param[k * N + i];
+            for (int k = 0; k < D::NP; ++k) e.par[k] = slot_in<T>(make_rsrc(P.i.ws), P.i.param_off, i).load(k * N);
         } else {
 #pragma unroll
             for (int k = 0; k < D::NP; ++k) e.par[k] = P.c.base_param[k];
@@ -323,14 +463,15 @@ struct EnvOps {
 
     __device__ static __forceinline__ void store(const PV<T>& P, int i, const E& e, bool params_dirty) {
         const size_t N = (size_t)P.i.num_envs;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
 #pragma unroll
-        for (int k = 0; k < D::NS; ++k) P.i.state[k * N + i] = e.s[k];
+        for (int k = 0; k < D::NS; ++k) slot_in<T>(ws, P.i.state_off, i).store(e.s[k], k * N);
         if (P.c.per_env_params && params_dirty) {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k) P.i.param[k * N + i] = e.par[k];
+            for (int k = 0; k < D::NP; ++k) slot_in<T>(ws, P.i.param_off, i).store(e.par[k], k * N);
         }
-        P.i.step[i] = e.step;
-        P.i.episode[i] = e.episode;
+        slot_in<int32_t>(ws, P.i.step_off, i).store(e.step);
+        slot_in<uint32_t>(ws, P.i.episode_off, i).store(e.episode);
     }
 
     // env.state (the vector the reference exposes), from the raw simulator state.
@@ -416,10 +557,57 @@ struct EnvOps {
     //               benchmark_env.py:433-437, quadrotor.py:813-816)
     //   rng_step:   Philox step index of the observation (0 at reset, k after the k-th step)
     //   ctrl_step:  ctrl_step_counter seen by impulse/step disturbances (pre-increment value)
+    // True when the whole observation is one register row of NX or 2*NX elements (every case except trajectory
+    // tracking with a goal horizon > 1, whose rows are streamed from the X_GOAL table).
+    __device__ static __forceinline__ bool obs_is_row(const PV<T>& P) {
+        return !(P.c.cost == SCG_COST_RL_REWARD && P.c.task == SCG_TASK_TRAJ_TRACKING && P.c.obs_goal_horizon > 1);
+    }
+    // Builds that row in registers; returns its length (NX, or 2*NX with the goal row appended).
+    __device__ static __forceinline__ int obs_row(const PV<T>& P, const GoalTab<T>& goal_tab, const T* st,
+                                                  const E& e, RngKey key, int next_index, uint32_t rng_step,
+                                                  int32_t ctrl_step, int env_index, const T* ext_pre, T* row) {
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) row[k] = st[k];
+        if constexpr (DIST) {
+            if (P.c.n_dist[SCG_CH_OBSERVATION] > 0)
+                apply_disturbances<T, D::NX>(P, SCG_CH_OBSERVATION, row, D::NX, key, e.gid, e.episode, rng_step, ctrl_step, env_index);
+        }
+        if constexpr (SYS == SCG_CARTPOLE) {
+            if (P.c.obs_wrap_angle) row[2] = normalize_angle(row[2]);
+        }
+        if (!(P.c.obs_goal_horizon > 0 && P.c.cost == SCG_COST_RL_REWARD)) return D::NX;
+        if (ext_pre) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) row[D::NX + k] = ext_pre[k];
+        } else {
+            int r = 0;
+            if (P.c.task == SCG_TASK_TRAJ_TRACKING) { const int last = P.c.goal_rows - 1; r = next_index > last ? last : next_index; }
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) row[D::NX + k] = goal_tab[r * D::NX + k];
+        }
+        return 2 * D::NX;
+    }
+    // Row -> this env's slot of an [N][obs_dim] array (per-lane, strided by the row pitch).
+    __device__ static __forceinline__ void store_obs_row(const PV<T>& P, const T* row, int n, Slot<T> dst) {
+        if (n == P.c.nobs && n == 2 * D::NX) dst.template store_row<2 * D::NX>(row);
+        else if (n == P.c.nobs && n == D::NX) dst.template store_row<D::NX>(row);
+        else {
+            for (int k = 0; k < 2 * D::NX; ++k)
+                if (k < n) dst.store(row[k], k);
+        }
+    }
+
     __device__ static __forceinline__ void write_obs(const PV<T>& P, const GoalTab<T>& goal_tab, const T* st,
                                                      const E& e, RngKey key, int next_index, uint32_t rng_step,
-                                                     int32_t ctrl_step, int env_index, T* __restrict__ dst,
+                                                     int32_t ctrl_step, int env_index, Slot<T> dst,
                                                      const T* ext_pre = nullptr) {
+        if (obs_is_row(P)) {
+            T row[2 * D::NX];
+            const int n = obs_row(P, goal_tab, st, e, key, next_index, rng_step, ctrl_step, env_index, ext_pre, row);
+            store_obs_row(P, row, n, dst);
+            return;
+        }
+        // trajectory tracking, horizon > 1: state row, then `horizon` rows of X_GOAL
         T o[D::NX];
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) o[k] = st[k];
@@ -430,61 +618,34 @@ struct EnvOps {
         if constexpr (SYS == SCG_CARTPOLE) {
             if (P.c.obs_wrap_angle) o[2] = normalize_angle(o[2]);
         }
-        const int h = P.c.obs_goal_horizon;
-        if (h > 0 && P.c.cost == SCG_COST_RL_REWARD) {
-            // gather the goal rows into registers first: the table loads must not be interleaved with the
-            // stores below (the compiler has to assume they alias and would serialise load -> store -> load)
-            if (P.c.task == SCG_TASK_TRAJ_TRACKING) {
-                const int last = P.c.goal_rows - 1;
-                if (h == 1) {
-                    T g[D::NX];
-                    if (ext_pre) {
+        const int last = P.c.goal_rows - 1;
 #pragma unroll
-                        for (int k = 0; k < D::NX; ++k) g[k] = ext_pre[k];
-                    } else {
-                        int row = next_index; row = row > last ? last : row;
+        for (int k = 0; k < D::NX; ++k) dst.store(o[k], k);
+        for (int r = 0; r < P.c.obs_goal_horizon; ++r) {
+            int row = next_index + r; row = row > last ? last : row;
+            // gather the goal row into registers first: the table loads must not be interleaved with the stores
+            T g[D::NX];
 #pragma unroll
-                        for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[row * D::NX + k];
-                    }
+            for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[row * D::NX + k];
 #pragma unroll
-                    for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
-#pragma unroll
-                    for (int k = 0; k < D::NX; ++k) dst[D::NX + k] = g[k];
-                    return;
-                }
-#pragma unroll
-                for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
-                for (int r = 0; r < h; ++r) {
-                    int row = next_index + r; row = row > last ? last : row;
-                    T g[D::NX];
-#pragma unroll
-                    for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[row * D::NX + k];
-#pragma unroll
-                    for (int k = 0; k < D::NX; ++k) dst[D::NX * (1 + r) + k] = g[k];
-                }
-            } else {
-                T g[D::NX];
-#pragma unroll
-                for (int k = 0; k < D::NX; ++k) g[k] = goal_tab[k];
-#pragma unroll
-                for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
-#pragma unroll
-                for (int k = 0; k < D::NX; ++k) dst[D::NX + k] = g[k];
-            }
-            return;
+            for (int k = 0; k < D::NX; ++k) dst.store(g[k], D::NX * (1 + r) + k);
         }
-#pragma unroll
-        for (int k = 0; k < D::NX; ++k) dst[k] = o[k];
     }
 
-    // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset
-    // (written densely at rows 0..n_state-1).  c_out may be null; `stride` = distance between rows.
+    // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset (written
+    // densely at rows 0..n_state-1).  c_out: this env's column of the SoA [rows][N] output (row stride `stride`
+    // elements: every store of a wave is one contiguous 256-byte segment), or absent.
     __device__ static __forceinline__ bool constraints(const PV<T>& P, const T* st, const T* act,
-                                                       T* c_out, size_t stride, bool only_state) {
+                                                       Slot<T> c_out, size_t stride, bool only_state) {
         bool viol = false;
         // (1) box rows: flat, unrolled so the row loads are all in flight together; the constrained
         //     variable is picked from registers with a select chain (no dependent memory round trips)
         const int nb = only_state ? P.c.n_box_state_rows : P.c.n_box_rows;     // state slots come first
+#ifdef SCG_SPEC
+        // every index is a compile-time constant here: the values are kept in registers and stored in one
+        // straight-line run (one null check for the whole output, row offsets are scalar adds)
+        T cv[SCG_MAX_CON_ROWS];
+#endif
 SCG_BOX_UNROLL
         for (int r = 0; r < nb; ++r) {
             const BoxRow<T> br = P.c.box[r];
@@ -498,8 +659,22 @@ SCG_BOX_UNROLL
             T c = (fl & 2) ? (m_abs(val) - br.b) : (((fl & 4) ? -val : val) - br.b);
             if (P.c.box_round > (T)0) c = m_rint(c * P.c.box_round) * P.c.box_inv_round;
             viol = viol || ((fl & 1) ? (c >= (T)0) : (c > (T)0));
-            if (c_out) c_out[(size_t)(only_state ? ((br.packed >> 8) & 0xff) : (br.packed & 0xff)) * stride] = c;
+#ifdef SCG_SPEC
+            cv[r] = c;
+#else
+            // row index comes from the LDS table (not provably uniform): folded into the lane offset
+            if (c_out) c_out.store_at(c, (uint32_t)((only_state ? ((br.packed >> 8) & 0xff) : (br.packed & 0xff)) * stride));
+#endif
         }
+#ifdef SCG_SPEC
+        if (c_out) {
+SCG_BOX_UNROLL
+            for (int r = 0; r < nb; ++r) {
+                const BoxRow<T> br = P.c.box[r];
+                c_out.store(cv[r], (size_t)(only_state ? ((br.packed >> 8) & 0xff) : (br.packed & 0xff)) * stride);
+            }
+        }
+#endif
         // (2) dense / quadratic rows
         if (P.c.n_generic_rows > 0) {
             int state_pos = 0;
@@ -541,7 +716,7 @@ SCG_BOX_UNROLL
                 c -= row.b;
                 if (row.round_scale > (T)0) c = m_rint(c * row.round_scale) * row.inv_round_scale;
                 viol = viol || (row.strict ? (c >= (T)0) : (c > (T)0));
-                if (c_out) c_out[(size_t)(only_state ? my_state_pos : r) * stride] = c;
+                if (c_out) c_out.store_at(c, (uint32_t)((only_state ? my_state_pos : r) * stride));
             }
         }
         return viol;
@@ -553,7 +728,7 @@ SCG_BOX_UNROLL
     // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
     __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,
-                                                      T* st, T* noisy_out, T* c_out, size_t c_stride,
+                                                      T* st, T* noisy_out, Slot<T> c_out, size_t c_stride,
                                                       const T* ref_pre = nullptr, const T* ext_pre = nullptr,
                                                       const T* ext_reset = nullptr) {
         const int32_t c0 = e.step;      // ctrl_step_counter before the increment
@@ -785,6 +960,11 @@ SCG_BOX_UNROLL
 #pragma unroll
             for (int k = 0; k < D::NX; ++k) vreg_fence(ext_reset[k]);
         }
+#ifdef SCG_EXP_TIMELINE
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) vreg_fence(st[k]);
+#endif
+        SCG_TL(3);
 
         // ---- reference row for reward / mse (tracking: X_GOAL[min(c+1, L-1)])
         T ref[D::NX];
@@ -861,9 +1041,10 @@ SCG_BOX_UNROLL
             }
             if (!tracking) {
                 // stale `self.out_of_bounds` on goal_reached steps (see oracle/envs.py::_stale_oob)
-                const bool prev = P.i.oob_attr[env_index] != 0;
+                const Slot<uint8_t> attr = slot_in<uint8_t>(make_rsrc(P.i.ws), P.i.oob_off, env_index);
+                const bool prev = attr.load() != 0;
                 oob = goal ? prev : oob;
-                P.i.oob_attr[env_index] = oob ? 1 : 0;
+                attr.store(oob ? 1 : 0);
             }
             if (oob) flags |= FLAG_OOB;
             done = done || (oob && !goal);
@@ -882,6 +1063,10 @@ SCG_BOX_UNROLL
             mse += err * err;
         }
         // ---- after_step
+#ifdef SCG_EXP_TIMELINE
+        vreg_fence(rew); vreg_fence(mse);
+#endif
+        SCG_TL(4);
         e.step = c0 + 1;
         bool viol = false;
         if (P.c.n_con_rows > 0) {
@@ -898,6 +1083,7 @@ SCG_BOX_UNROLL
                 else rew -= P.c.constraint_penalty;
             }
         }
+        SCG_TL(5);
         if (e.step >= P.c.ctrl_steps) {
             if (!done) flags |= FLAG_TRUNCATED;
             done = true;

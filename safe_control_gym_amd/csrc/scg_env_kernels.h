@@ -88,9 +88,38 @@ __device__ __forceinline__ GoalTab<T> stage_commit(unsigned char* smem, const St
 #define SCG_CFG_REF(T) (scg_spec_cfg<T>())
 #endif
 
+// Per-lane output slots, built at kernel entry (see Slot / OutTab).
+template <typename T>
+struct OutPtrs {
+    Slot<T> obs, reward; Slot<uint8_t> done, flags; Slot<T> c_values, mse, terminal_obs, state, noisy_action, ep_stats, fin_stats;
+};
+
+template <typename V, bool ONE>
+__device__ __forceinline__ Slot<V> out_slot(const OutTab& O, int k, int i, int elems = 1) {
+    if constexpr (ONE) return slot_in<V>(make_rsrc(O.base), O.off[k], i, elems);
+    else return slot(reinterpret_cast<V*>(O.ptr[k]), i, elems);
+}
+
+template <typename T, bool ONE>
+__device__ __forceinline__ OutPtrs<T> out_ptrs(const OutTab& O, int i, int nobs) {
+    OutPtrs<T> p;
+    p.obs = out_slot<T, ONE>(O, OUT_OBS, i, nobs);
+    p.terminal_obs = out_slot<T, ONE>(O, OUT_TERMINAL_OBS, i, nobs);
+    p.reward = out_slot<T, ONE>(O, OUT_REWARD, i);
+    p.done = out_slot<uint8_t, ONE>(O, OUT_DONE, i);
+    p.flags = out_slot<uint8_t, ONE>(O, OUT_FLAGS, i);
+    p.c_values = out_slot<T, ONE>(O, OUT_C_VALUES, i);
+    p.mse = out_slot<T, ONE>(O, OUT_MSE, i);
+    p.state = out_slot<T, ONE>(O, OUT_STATE, i);
+    p.noisy_action = out_slot<T, ONE>(O, OUT_NOISY_ACTION, i);
+    p.ep_stats = out_slot<T, ONE>(O, OUT_EP_STATS, i, 4);
+    p.fin_stats = out_slot<T, ONE>(O, OUT_FIN_STATS, i, 4);
+    return p;
+}
+
 template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                      const uint8_t* __restrict__ mask, StepOut<T> O) {
+                                                      const uint8_t* __restrict__ mask, const OutTab OT) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,82 +149,88 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
     Ops::reset(P, i, e, key);
     T st[D::NX];
     Ops::state_vector(e, st);
-    if (O.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, O.obs + (size_t)i * P.c.nobs);
-    if (O.c_values && P.c.n_state_con_rows > 0) Ops::constraints(P, st, st, O.c_values + i, (size_t)N, true);
-    if (O.state) {
+    const OutPtrs<T> Q = out_ptrs<T, false>(OT, i, P.c.nobs);
+    if (Q.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs);
+    if (Q.c_values && P.c.n_state_con_rows > 0) Ops::constraints(P, st, st, Q.c_values, (size_t)N, true);
+    if (Q.state) {
 #pragma unroll
-        for (int k = 0; k < D::NX; ++k) O.state[(size_t)k * N + i] = st[k];
+        for (int k = 0; k < D::NX; ++k) Q.state.store(st[k], (size_t)k * N);
     }
-    if (O.ep_return) O.ep_return[i] = (T)0;
-    if (O.ep_length) O.ep_length[i] = 0;
-    if (O.ep_violation) O.ep_violation[i] = (T)0;
-    if (O.ep_mse) O.ep_mse[i] = (T)0;
-    if (I.oob_attr) I.oob_attr[i] = 0;
+    if (Q.ep_stats) {
+        const T zero4[4] = {(T)0, (T)0, (T)0, (T)0};
+        Q.ep_stats.template store_row<4>(zero4);
+    }
+    if (I.oob_off != SCG_NO_OFF) slot_in<uint8_t>(make_rsrc(I.ws), I.oob_off, i).store(0);
     Ops::store(P, i, e, true);
 }
 
-// Per-thread output addresses, computed at kernel entry so that every kernarg (pointer) is fetched in the
-// first scalar-load round instead of lazily at its first use deep inside the kernel.
-template <typename T>
-struct OutPtrs {
-    T* obs; T* reward; uint8_t* done; uint8_t* flags; T* c_values; T* mse; T* terminal_obs; T* state;
-    T* noisy_action; T* ep_return; int32_t* ep_length; T* ep_violation; T* ep_mse;
-    T* fin_return; int32_t* fin_length; T* fin_violation; T* fin_mse;
-};
-
-template <typename T>
-__device__ __forceinline__ OutPtrs<T> out_ptrs(const StepOut<T>& O, int i, int nobs) {
-    OutPtrs<T> p;
-    p.obs = O.obs ? O.obs + (size_t)i * nobs : nullptr;
-    p.terminal_obs = O.terminal_obs ? O.terminal_obs + (size_t)i * nobs : nullptr;
-    p.reward = O.reward ? O.reward + i : nullptr;
-    p.done = O.done ? O.done + i : nullptr;
-    p.flags = O.flags ? O.flags + i : nullptr;
-    p.c_values = O.c_values ? O.c_values + i : nullptr;
-    p.mse = O.mse ? O.mse + i : nullptr;
-    p.state = O.state ? O.state + i : nullptr;
-    p.noisy_action = O.noisy_action ? O.noisy_action + i : nullptr;
-    p.ep_return = O.ep_return ? O.ep_return + i : nullptr;
-    p.ep_length = O.ep_length ? O.ep_length + i : nullptr;
-    p.ep_violation = O.ep_violation ? O.ep_violation + i : nullptr;
-    p.ep_mse = O.ep_mse ? O.ep_mse + i : nullptr;
-    p.fin_return = O.fin_return ? O.fin_return + i : nullptr;
-    p.fin_length = O.fin_length ? O.fin_length + i : nullptr;
-    p.fin_violation = O.fin_violation ? O.fin_violation + i : nullptr;
-    p.fin_mse = O.fin_mse ? O.fin_mse + i : nullptr;
-    return p;
+// Observation rows of one full wave -> memory as fully coalesced 16-byte stores.  Each lane holds the row of its own
+// env (NROW elements, RB = row bytes, a multiple of 16); stored lane-by-lane that is a 16-byte piece every RB bytes —
+// 64 partial cache lines per instruction, which the write path handles at a fraction of the speed of full lines
+// (profiles/r01_store_layouts.md).  The wave's rows form one contiguous 64*RB block, so the rows are transposed through
+// LDS (wave-private region, no workgroup barrier) and piece p of the block is written by lane p % 64.
+template <typename T, int NROW>
+__device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T* row, unsigned char* lds_wave, int lane) {
+    constexpr int RB = NROW * (int)sizeof(T);
+    static_assert(RB % 16 == 0, "row pitch must be a multiple of 16 bytes");
+    constexpr int per = 16 / (int)sizeof(T);
+    struct Piece { T e[per]; };
+#pragma unroll
+    for (int c = 0; c < RB / 16; ++c) {
+        Piece p;
+#pragma unroll
+        for (int j = 0; j < per; ++j) p.e[j] = row[c * per + j];
+        *reinterpret_cast<Piece*>(lds_wave + lane * RB + c * 16) = p;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t block_off = dst.off - (uint32_t)(lane * RB);      // byte offset of the wave's first row
+#pragma unroll
+    for (int c = 0; c < RB / 16; ++c) {
+        const Piece p = *reinterpret_cast<const Piece*>(lds_wave + (c * 64 + lane) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), dst.r, block_off + (uint32_t)(lane * 16),
+                                               dst.soff + (uint32_t)(c * 1024), 0);
+    }
 }
 
-template <typename T>
-__device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* action, const T* adv, const StepOut<T>& O) {
-    sreg_fence(I.cold); sreg_fence(I.x_goal); sreg_fence(I.state); sreg_fence(I.param); sreg_fence(I.step); sreg_fence(I.episode);
-    sreg_fence(I.oob_attr); sreg_fence(I.num_envs); sreg_fence(I.env_id_offset); sreg_fence(I.key0); sreg_fence(I.key1);
+template <typename T, bool ONE>
+__device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* action, const T* adv, const OutTab& O) {
+    sreg_fence(I.cold); sreg_fence(I.x_goal); sreg_fence(I.ws); sreg_fence(I.state_off); sreg_fence(I.param_off);
+    sreg_fence(I.step_off); sreg_fence(I.episode_off); sreg_fence(I.oob_off); sreg_fence(I.num_envs);
+    sreg_fence(I.env_id_offset); sreg_fence(I.key0); sreg_fence(I.key1);
     sreg_fence(action); sreg_fence(adv);
-    sreg_fence(O.obs); sreg_fence(O.reward); sreg_fence(O.done); sreg_fence(O.flags); sreg_fence(O.c_values);
-    sreg_fence(O.mse); sreg_fence(O.terminal_obs); sreg_fence(O.state); sreg_fence(O.noisy_action);
-    sreg_fence(O.ep_return); sreg_fence(O.ep_length); sreg_fence(O.ep_violation); sreg_fence(O.ep_mse);
-    sreg_fence(O.fin_return); sreg_fence(O.fin_length); sreg_fence(O.fin_violation); sreg_fence(O.fin_mse);
+    if constexpr (ONE) {
+        sreg_fence(O.base);
+#pragma unroll
+        for (int k = 0; k < OUT_COUNT; ++k) sreg_fence(O.off[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < OUT_COUNT; ++k) sreg_fence(O.ptr[k]);
+    }
 }
 
-template <int SYS, typename T, bool DIST>
+template <int SYS, typename T, bool DIST, bool ONE>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                     const T* __restrict__ action, const T* __restrict__ adv, StepOut<T> O) {
+                                                     const T* __restrict__ action, const T* __restrict__ adv, const OutTab O) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int N = I.num_envs;
     const bool live = i < N;
     // ---- memory round 1: kernargs — every pointer is fetched in this block, one scalar-memory round
-    fence_kernargs(I, action, adv, O);
+    SCG_TL(0);
+    fence_kernargs<T, ONE>(I, action, adv, O);
+    SCG_TL(1);
     typename Ops::E e;
     T act[D::NU];
-    T ep_ret = (T)0, ep_viol = (T)0, ep_mse = (T)0;
-    int32_t ep_len = 0;
+    T ep[4] = {(T)0, (T)0, (T)0, (T)0};      // running (return, length, violations, mse) of the episode
 #ifdef SCG_SPEC
     constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();     // compile-time constants (see scg_spec.h)
     const PV<T> P{kcfg, I};
     const GoalTab<T> goal{nullptr, I.x_goal, false};
     if (!live) return;
+    const bool full_wave = __builtin_amdgcn_read_exec() == ~0ull;      // tail waves keep the per-lane store paths
     const PV<T>& Pg = P;
     const int nobs_early = kcfg.nobs;
 #else
@@ -204,19 +239,21 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     const PV<T> Pg{*Cg, I};
     const int nobs_early = D::NX * (1 + I.obs_ext_rows);
 #endif
-    const OutPtrs<T> Q = out_ptrs(O, live ? i : 0, nobs_early);
+    OutPtrs<T> Q = out_ptrs<T, ONE>(O, live ? i : 0, nobs_early);
+#ifdef SCG_EXP_NO_CVAL
+    Q.c_values.soff = SCG_NO_OFF;
+#endif
+#ifdef SCG_EXP_NO_OBS
+    Q.obs.soff = SCG_NO_OFF; Q.terminal_obs.soff = SCG_NO_OFF;
+#endif
     // ---- memory round 2: everything this thread needs from HBM, requested before the single wait
     if (live) {
         Ops::load_state(Pg, i, e);
 #pragma unroll
-        for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];
-        // unconditional loads (an unbound accumulator reads a valid dummy address): a branch per pointer
-        // would split the requests over several dependent rounds
-        const T* dummy_t = I.state + i;
-        ep_ret = *(Q.ep_return ? Q.ep_return : dummy_t);
-        ep_len = *(Q.ep_length ? Q.ep_length : I.step + i);
-        ep_viol = *(Q.ep_violation ? Q.ep_violation : dummy_t);
-        ep_mse = *(Q.ep_mse ? Q.ep_mse : dummy_t);
+        for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];     // caller's tensor: plain global load
+        // unconditional load (an unbound accumulator reads a valid dummy address): a branch would split the
+        // requests over two dependent rounds
+        (Q.ep_stats ? Q.ep_stats : slot_in<T>(make_rsrc(I.ws), I.state_off, 0, 4)).template load_row<4>(ep);
     }
 #ifndef SCG_SPEC
     const CfgParams<T>* cl;
@@ -227,6 +264,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     Ops::load_params(P, i, e);
     const RngKey key{I.key0, I.key1};
     const int32_t c0 = e.step;
+#ifdef SCG_EXP_TIMELINE
+#pragma unroll
+    for (int k = 0; k < D::NS; ++k) vreg_fence(e.s[k]);
+    vreg_fence(act[0]); vreg_fence(ep[3]); vreg_fence(e.episode);
+#endif
+    SCG_TL(2);
     // ---- memory round 3 (overlapped with the integrator): reference rows of X_GOAL for this step
     const bool pre_rows = P.c.task == SCG_TASK_TRAJ_TRACKING;
     const bool pre_ext = pre_rows && P.c.cost == SCG_COST_RL_REWARD && P.c.obs_goal_horizon == 1;
@@ -234,10 +277,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     if (pre_rows) {
         const int last = P.c.goal_rows - 1;
         int r1 = c0 + 1; r1 = r1 > last ? last : r1;
+#ifdef SCG_EXP_UNIFORM_GOAL
+        r1 = 1;
+#endif
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) ref_pre[k] = goal[r1 * D::NX + k];
         if (pre_ext) {
             int r2 = c0 + 2; r2 = r2 > last ? last : r2;
+#ifdef SCG_EXP_UNIFORM_GOAL
+            r2 = 2;
+#endif
             const int r0 = 1 > last ? last : 1;
 #pragma unroll
             for (int k = 0; k < D::NX; ++k) ext_pre[k] = goal[r2 * D::NX + k];
@@ -258,56 +307,74 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, Q.c_values, (size_t)N,
                                            pre_rows ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr,
                                            pre_ext ? ext_reset : nullptr);
-    if (Q.reward) *Q.reward = r.reward;
-    if (Q.done) *Q.done = r.done ? 1 : 0;
-    if (Q.flags) *Q.flags = r.flags;
-    if (Q.mse) *Q.mse = r.mse;
+    Q.reward.store(r.reward);           // obs / reward / done / flags are always bound (checked by scg_step)
+    Q.done.store(r.done ? 1 : 0);
+    Q.flags.store(r.flags);
+    if (Q.mse) Q.mse.store(r.mse);
     if (Q.noisy_action) {
 #pragma unroll
-        for (int j = 0; j < D::NU; ++j) Q.noisy_action[(size_t)j * N] = noisy[j];
+        for (int j = 0; j < D::NU; ++j) Q.noisy_action.store(noisy[j], (size_t)j * N);
     }
     // columnar VecRecordEpisodeStatistics (record_episode_statistics.py:139-166)
-    if (Q.ep_return) {
-        const T acc = ep_ret + r.reward;
-        if (r.done && Q.fin_return) *Q.fin_return = acc;
-        *Q.ep_return = r.done ? (T)0 : acc;
-    }
-    if (Q.ep_length) {
-        const int32_t acc = ep_len + 1;
-        if (r.done && Q.fin_length) *Q.fin_length = acc;
-        *Q.ep_length = r.done ? 0 : acc;
-    }
-    if (Q.ep_violation) {
-        const T acc = ep_viol + ((r.flags & FLAG_VIOLATION) ? (T)1 : (T)0);
-        if (r.done && Q.fin_violation) *Q.fin_violation = acc;
-        *Q.ep_violation = r.done ? (T)0 : acc;
-    }
-    if (Q.ep_mse) {
-        const T acc = ep_mse + r.mse;
-        if (r.done && Q.fin_mse) *Q.fin_mse = acc;
-        *Q.ep_mse = r.done ? (T)0 : acc;
+    if (Q.ep_stats) {
+        ep[0] += r.reward;
+        ep[1] += (T)1;
+        ep[2] += (r.flags & FLAG_VIOLATION) ? (T)1 : (T)0;
+        ep[3] += r.mse;
+        if (r.done && Q.fin_stats) Q.fin_stats.template store_row<4>(ep);
+        const T nxt[4] = {r.done ? (T)0 : ep[0], r.done ? (T)0 : ep[1], r.done ? (T)0 : ep[2], r.done ? (T)0 : ep[3]};
+        Q.ep_stats.template store_row<4>(nxt);
     }
     // observation of the step: goes to terminal_observation where the env is about to auto-reset, else it is the
     // returned obs (two write_obs call sites only: the disturbance code is inlined into each)
+#ifdef SCG_EXP_NO_RESET
+    const bool do_reset = false;
+#else
     const bool do_reset = r.done && P.c.auto_reset;
-    {
-        T* dst = do_reset ? Q.terminal_obs : Q.obs;
-        if (dst) Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, dst, pre_ext ? ext_pre : nullptr);
-        if (r.done && !P.c.auto_reset && Q.terminal_obs && Q.obs) {
-            // single-env semantics (BenchmarkEnv.step): the terminal observation is also the returned one
-            for (int k = 0; k < P.c.nobs; ++k) Q.terminal_obs[k] = Q.obs[k];
+#endif
+    if (Ops::obs_is_row(P)) {
+        // One register row per env: the step's observation; a lane that auto-resets copies it to
+        // terminal_observation and replaces it by the observation of the fresh episode; then ONE store of the rows.
+        T row[2 * D::NX];
+        int nrow = Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, pre_ext ? ext_pre : nullptr, row);
+        if (r.done && Q.terminal_obs) Ops::store_obs_row(P, row, nrow, Q.terminal_obs);   // (also the non-auto-reset case)
+        SCG_TL(6);
+        if (do_reset) {
+            Ops::reset(P, i, e, key);               // auto-reset (dummy_vec_env.py:33-38)
+            Ops::state_vector(e, st);
+            nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row);
         }
-    }
-    if (do_reset) {
-        Ops::reset(P, i, e, key);               // auto-reset (dummy_vec_env.py:33-38)
-        Ops::state_vector(e, st);
-        if (Q.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs, pre_ext ? ext_reset : nullptr);
+#ifdef SCG_SPEC
+        constexpr int kNobs = kcfg.nobs;
+        constexpr bool can_transpose = (kNobs * (int)sizeof(T)) % 16 == 0 && (kNobs == D::NX || kNobs == 2 * D::NX);
+        if constexpr (can_transpose) {
+            __shared__ __align__(16) unsigned char s_obs[BLOCK * kNobs * sizeof(T)];
+            const int lane = (int)(threadIdx.x & 63);
+            if (full_wave) store_rows_coalesced<T, kNobs>(Q.obs, row, s_obs + (threadIdx.x >> 6) * (64 * kNobs * (int)sizeof(T)), lane);
+            else Ops::store_obs_row(P, row, nrow, Q.obs);
+        } else {
+            Ops::store_obs_row(P, row, nrow, Q.obs);
+        }
+#else
+        Ops::store_obs_row(P, row, nrow, Q.obs);
+#endif
+    } else {
+        Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, Q.obs, nullptr);
+        if (r.done && Q.terminal_obs)
+            Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, Q.terminal_obs, nullptr);
+        SCG_TL(6);
+        if (do_reset) {
+            Ops::reset(P, i, e, key);
+            Ops::state_vector(e, st);
+            Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs, nullptr);
+        }
     }
     if (Q.state) {
 #pragma unroll
-        for (int k = 0; k < D::NX; ++k) Q.state[(size_t)k * N] = st[k];
+        for (int k = 0; k < D::NX; ++k) Q.state.store(st[k], (size_t)k * N);
     }
     Ops::store(P, i, e, do_reset);
+    SCG_TL(7);
 }
 
 template <int SYS, typename T, bool DIST>
@@ -350,7 +417,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
         T act[D::NU], noisy[D::NU];
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) act[j] = (T)-1 + (T)2 * u01<T>(u4_get(w, j));
-        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, nullptr, 0);
+        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, slot((T*)nullptr, 0), 0);
         rsum += r.reward;
         viols += (r.flags & FLAG_VIOLATION) ? 1 : 0;
         if (r.done) {
@@ -362,14 +429,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
             }
         }
     }
-    if (reward_sum) reward_sum[i] = rsum;
-    if (done_count) done_count[i] = dones;
-    if (violation_count) violation_count[i] = viols;
+    if (reward_sum) slot(reward_sum, i).store(rsum);
+    if (done_count) slot(done_count, i).store(dones);
+    if (violation_count) slot(violation_count, i).store(viols);
     if (last_obs) {
         const bool fresh = e.step == 0;
         const int32_t c0 = e.step - 1;
         Ops::write_obs(P, goal, st, e, key, fresh ? 1 : c0 + 2, fresh ? 0u : (uint32_t)(c0 + 1), fresh ? 0 : c0, i,
-                       last_obs + (size_t)i * P.c.nobs);
+                       slot(last_obs, i, P.c.nobs));
     }
     Ops::store(P, i, e, dirty);
 }

@@ -7,7 +7,9 @@
 //                                                             compile-time constants (see emit_spec_source below)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -37,6 +39,11 @@ static int fail(int code, const std::string& msg) { g_last_error = msg; return c
 
 extern "C" const char* scg_last_error(void) { return g_last_error.c_str(); }
 extern "C" int scg_abi_version(void) { return SCG_ABI_VERSION; }
+#ifdef SCG_EXP_TIMELINE
+extern "C" int scg_exp_timeline(unsigned long long* out, size_t n) {   // timing-only builds (tools/timeline.py)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scg::scg_timeline), n * sizeof(unsigned long long));
+}
+#endif
 extern "C" size_t scg_sizeof_config(void) { return sizeof(scg_config); }
 extern "C" size_t scg_sizeof_step_out(void) { return sizeof(scg_step_out); }
 
@@ -54,6 +61,7 @@ struct scg_env {
     void* d_cfg;             // CfgParams<T> on device (generic build: staged into LDS by every workgroup)
     void* d_goal;            // X_GOAL table on device
     // workspace partition (device pointers)
+    void* d_workspace;
     void* d_state;
     void* d_param;
     int32_t* d_step;
@@ -84,6 +92,9 @@ static int validate(const scg_config* c) {
     if (c->dtype != SCG_F32 && c->dtype != SCG_F64) return fail(SCG_ERR_INVALID, "unknown dtype");
     if (c->integrator != SCG_INT_PYB_EULER) return fail(SCG_ERR_INVALID, "only SCG_INT_PYB_EULER is implemented");
     if (c->num_envs <= 0) return fail(SCG_ERR_INVALID, "num_envs must be positive");
+    // kernels address each array as uniform base + 32-bit per-env byte offset (scg_env_core.h: Slot)
+    if ((uint64_t)c->num_envs * 8u * (uint64_t)(SCG_MAX_STATE * (1 + (c->obs_goal_horizon > 0 ? c->obs_goal_horizon : 0))) >= (1ull << 32))
+        return fail(SCG_ERR_INVALID, "num_envs too large: per-env byte offsets of the observation array must fit 32 bits");
     if (c->substeps <= 0 || c->ctrl_steps <= 0) return fail(SCG_ERR_INVALID, "substeps / ctrl_steps must be positive");
     if (c->obs_goal_horizon < 0 || c->obs_goal_horizon > SCG_MAX_GOAL_HORIZON) return fail(SCG_ERR_INVALID, "obs_goal_horizon out of range");
     if (c->goal_rows <= 0) return fail(SCG_ERR_INVALID, "goal_rows must be positive");
@@ -438,8 +449,11 @@ static int upload(scg_env* e, const double* h_x_goal) {
 template <typename T>
 static InstParams<T> inst_of(const scg_env* e) {
     InstParams<T> I;
-    I.cold = (const DevParams<T>*)e->d_params; I.x_goal = (const T*)e->d_goal; I.state = (T*)e->d_state;
-    I.param = (T*)e->d_param; I.step = e->d_step; I.episode = e->d_episode; I.oob_attr = e->d_oob;
+    I.cold = (const DevParams<T>*)e->d_params; I.x_goal = (const T*)e->d_goal;
+    I.ws = (char*)e->d_workspace;
+    auto off = [&](const void* q) { return q ? (uint32_t)((const char*)q - (const char*)e->d_workspace) : SCG_NO_OFF; };
+    I.state_off = off(e->d_state); I.param_off = off(e->d_param); I.step_off = off(e->d_step);
+    I.episode_off = off(e->d_episode); I.oob_off = off(e->d_oob);
     I.num_envs = e->cfg.num_envs; I.env_id_offset = e->cfg.env_id_offset;
     I.key0 = (uint32_t)(e->cfg.seed & 0xffffffffu); I.key1 = (uint32_t)(e->cfg.seed >> 32);
     I.goal_lds16 = e->goal_lds16; I.obs_ext_rows = e->nobs / e->nx - 1;
@@ -461,6 +475,7 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
 #endif
     const Layout L = layout_of(cfg);
     if (workspace_bytes < L.total) return fail(SCG_ERR_INVALID, "workspace too small (see scg_workspace_bytes)");
+    if (L.total >= 0xffff0000ull) return fail(SCG_ERR_INVALID, "num_envs too large: the workspace must stay below 4 GiB (32-bit array offsets)");
     if ((uintptr_t)d_workspace % 256 != 0) return fail(SCG_ERR_INVALID, "workspace must be 256-byte aligned");
     HIP_TRY(hipSetDevice(device));
     scg_env* e = new (std::nothrow) scg_env();
@@ -480,6 +495,7 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->lds_bytes = lds16(cfg_sz) + (size_t)e->goal_lds16 * 16;
 #endif
     unsigned char* w = (unsigned char*)d_workspace;
+    e->d_workspace = d_workspace;
     e->d_state = w + L.state; e->d_param = w + L.param; e->d_step = (int32_t*)(w + L.step);
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
@@ -514,16 +530,31 @@ extern "C" int scg_destroy(scg_env* env) {
 #else
 #define SCG_BY_DTYPE(env, fn, ...) ((env)->dtype == SCG_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
 #endif
+// scg_step_out -> kernel-side table.  When every bound array (with its extent) fits a 4 GiB window the kernel addresses
+// them through one buffer resource (base + 32-bit offsets); otherwise through one resource per array.
 template <typename T>
-static StepOut<T> typed_out(const scg_step_out* o) {
-    StepOut<T> t{};
+static OutTab out_tab(const scg_env* e, const scg_step_out* o, bool* one_base) {
+    OutTab t{};
+    for (int k = 0; k < OUT_COUNT; ++k) { t.off[k] = SCG_NO_OFF; t.ptr[k] = nullptr; }
+    *one_base = true;
     if (!o) return t;
-    t.obs = (T*)o->d_obs; t.reward = (T*)o->d_reward; t.done = o->d_done; t.flags = o->d_flags;
-    t.c_values = (T*)o->d_c_values; t.mse = (T*)o->d_mse; t.terminal_obs = (T*)o->d_terminal_obs;
-    t.state = (T*)o->d_state; t.noisy_action = (T*)o->d_noisy_action;
-    t.ep_return = (T*)o->d_ep_return; t.ep_length = o->d_ep_length; t.ep_violation = (T*)o->d_ep_violation;
-    t.ep_mse = (T*)o->d_ep_mse; t.fin_return = (T*)o->d_fin_return; t.fin_length = o->d_fin_length;
-    t.fin_violation = (T*)o->d_fin_violation; t.fin_mse = (T*)o->d_fin_mse;
+    const size_t N = (size_t)e->cfg.num_envs, sT = sizeof(T);
+    void* const p[OUT_COUNT] = {o->d_obs, o->d_reward, o->d_done, o->d_flags, o->d_c_values, o->d_mse, o->d_terminal_obs,
+                                o->d_state, o->d_noisy_action, o->d_ep_stats, o->d_fin_stats};
+    const size_t ext[OUT_COUNT] = {N * e->nobs * sT, N * sT, N, N, (size_t)(e->cfg.n_con_rows > 0 ? e->cfg.n_con_rows : 1) * N * sT, N * sT,
+                                   N * e->nobs * sT, (size_t)e->nx * N * sT, (size_t)e->nu * N * sT, 4 * N * sT, 4 * N * sT};
+    uintptr_t lo = UINTPTR_MAX, hi = 0;
+    for (int k = 0; k < OUT_COUNT; ++k) {
+        t.ptr[k] = (char*)p[k];
+        if (!p[k]) continue;
+        lo = std::min(lo, (uintptr_t)p[k]);
+        hi = std::max(hi, (uintptr_t)p[k] + ext[k]);
+    }
+    if (hi == 0) return t;
+    if (hi - lo >= 0xffff0000ull) { *one_base = false; return t; }
+    t.base = (char*)lo;
+    for (int k = 0; k < OUT_COUNT; ++k)
+        if (p[k]) t.off[k] = (uint32_t)((uintptr_t)p[k] - lo);
     return t;
 }
 
@@ -548,7 +579,8 @@ static StepOut<T> typed_out(const scg_step_out* o) {
 template <typename T>
 static int launch_reset(scg_env* env, const uint8_t* mask, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
-    StepOut<T> O = typed_out<T>(out);
+    bool one_base;
+    const OutTab O = out_tab<T>(env, out, &one_base);
     const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
     const InstParams<T> I = inst_of<T>(env);
     DISPATCH_SYS(env, T, (reset_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, mask, O)));
@@ -559,10 +591,15 @@ static int launch_reset(scg_env* env, const uint8_t* mask, const scg_step_out* o
 template <typename T>
 static int launch_step(scg_env* env, const void* action, const void* adv, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
-    StepOut<T> O = typed_out<T>(out);
+    bool one_base;
+    const OutTab O = out_tab<T>(env, out, &one_base);
     const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
     const InstParams<T> I = inst_of<T>(env);
-    DISPATCH_SYS(env, T, (step_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+    if (one_base) {
+        DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+    } else {
+        DISPATCH_SYS(env, T, (step_kernel<S, T, DD, false><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+    }
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 }
@@ -592,6 +629,10 @@ extern "C" int scg_reset(scg_env* env, const uint8_t* d_mask, const scg_step_out
 extern "C" int scg_step(scg_env* env, const void* d_action, const void* d_adv_action, const scg_step_out* out, void* stream) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
     if (!d_action) return fail(SCG_ERR_INVALID, "d_action is NULL");
+    if (!out || !out->d_obs || !out->d_reward || !out->d_done || !out->d_flags)
+        return fail(SCG_ERR_INVALID, "scg_step needs d_obs, d_reward, d_done and d_flags");
+    if (((uintptr_t)out->d_obs | (uintptr_t)out->d_terminal_obs | (uintptr_t)out->d_ep_stats | (uintptr_t)out->d_fin_stats) & 15)
+        return fail(SCG_ERR_INVALID, "per-env row outputs (obs, terminal_obs, ep/fin stats) must be 16-byte aligned");
     // benchmark_env.py:230-235: "You must call env.reset() at least once before using env.step()."
     if (!env->has_reset) return fail(SCG_ERR_STATE, "scg_reset (all envs) must be called before scg_step");
     HIP_TRY(hipSetDevice(env->device));

@@ -143,15 +143,16 @@ struct CfgParams {
     BoxRow<T> box[SCG_MAX_CON_ROWS];     // sorted by variable slot, state rows first
 };
 
+constexpr uint32_t SCG_NO_OFF = 0xffffffffu;
+
 template <typename T>
 struct InstParams {
     const DevParams<T>* cold;   // disturbance tables, generic constraint rows, choice lists
     const T* x_goal;            // [goal_rows][nx] in device memory
-    T* state;
-    T* param;
-    int32_t* step;
-    uint32_t* episode;
-    uint8_t* oob_attr;
+    // Per-env simulator arrays all live in the caller's workspace: ONE buffer resource (`ws`) and a 32-bit byte
+    // offset per array (SCG_NO_OFF = absent), see Slot in scg_env_core.h.
+    char* ws;
+    uint32_t state_off, param_off, step_off, episode_off, oob_off;
     int32_t num_envs, env_id_offset;
     uint32_t key0, key1;
     int32_t goal_lds16;         // generic build: number of 16-byte chunks of x_goal staged into LDS (0 = read from global)

@@ -87,8 +87,13 @@ class VecEnv(ABC):
 
 class StepTensors:
     """Device-resident outputs of one vectorised step (all torch tensors on the env's device)."""
-    __slots__ = ('obs', 'reward', 'done', 'flags', 'c_values', 'mse', 'terminal_obs', 'state', 'noisy_action',
-                 'fin_return', 'fin_length', 'fin_violation', 'fin_mse')
+    __slots__ = ('obs', 'reward', 'done', 'flags', 'c_values', 'mse', 'terminal_obs', 'state', 'noisy_action', 'fin_stats')
+
+    # finished-episode totals where done: columns of the packed [N, 4] array (return, length, violations, mse)
+    fin_return = property(lambda self: self.fin_stats[:, 0])
+    fin_length = property(lambda self: self.fin_stats[:, 1])
+    fin_violation = property(lambda self: self.fin_stats[:, 2])
+    fin_mse = property(lambda self: self.fin_stats[:, 3])
 
     @property
     def truncated(self):
@@ -120,8 +125,9 @@ class LazyInfoList(Sequence):
     def _fetch(self):
         if self._host is None:
             o = self._out
-            h = {k: getattr(o, k).cpu().numpy() for k in ('flags', 'mse', 'done', 'terminal_obs', 'fin_return',
-                                                           'fin_length', 'fin_violation', 'fin_mse')}
+            h = {k: getattr(o, k).cpu().numpy() for k in ('flags', 'mse', 'done', 'terminal_obs')}
+            fin = o.fin_stats.cpu().numpy()
+            h.update(fin_return=fin[:, 0], fin_length=fin[:, 1], fin_violation=fin[:, 2], fin_mse=fin[:, 3])
             h['c_values'] = o.c_values.t().cpu().numpy() if o.c_values is not None else None
             self._host = h
         return self._host
@@ -202,26 +208,31 @@ class HipVecEnv(VecEnv):
                                          self.device.index or 0, C.c_void_p(self._ws_ptr), nbytes.value, C.byref(handle)))
         self._h = handle
         N, spec = self.num_envs, self.spec
-        f = dict(dtype=dtype, device=self.device)
+        # Every default output is carved from ONE arena: the step kernel then reaches all of them through a single
+        # buffer resource (include/scg_hip.h, scg_step_out).
+        n_rows = len(spec.con_rows)
+        esz = torch.empty((), dtype=dtype).element_size()
+        shapes = [('obs', (N, spec.obs_dim), dtype), ('reward', (N,), dtype), ('done', (N,), torch.uint8),
+                  ('flags', (N,), torch.uint8), ('c_values', (max(n_rows, 1), N), dtype), ('mse', (N,), dtype),
+                  ('terminal_obs', (N, spec.obs_dim), dtype), ('state', (spec.nx, N), dtype),
+                  ('noisy_action', (spec.nu, N), dtype), ('fin_stats', (N, 4), dtype), ('ep_stats', (N, 4), dtype)]
+        offs, total = {}, 0
+        for name, shape, dt in shapes:
+            offs[name] = total
+            nbytes = int(np.prod(shape)) * (1 if dt == torch.uint8 else esz)
+            total += (nbytes + 255) // 256 * 256
+        self._arena = torch.zeros(total + 256, dtype=torch.uint8, device=self.device)
+        base = (-self._arena.data_ptr()) % 256
+        view = {}
+        for name, shape, dt in shapes:
+            nbytes = int(np.prod(shape)) * (1 if dt == torch.uint8 else esz)
+            view[name] = self._arena[base + offs[name]: base + offs[name] + nbytes].view(dt).view(*shape)
         o = StepTensors()
-        o.obs = torch.zeros(N, spec.obs_dim, **f)
-        o.reward = torch.zeros(N, **f)
-        o.done = torch.zeros(N, dtype=torch.uint8, device=self.device)
-        o.flags = torch.zeros(N, dtype=torch.uint8, device=self.device)
-        o.c_values = torch.zeros(len(spec.con_rows), N, **f) if spec.con_rows else None
-        o.mse = torch.zeros(N, **f)
-        o.terminal_obs = torch.zeros(N, spec.obs_dim, **f)
-        o.state = torch.zeros(spec.nx, N, **f)
-        o.noisy_action = torch.zeros(spec.nu, N, **f)
-        o.fin_return = torch.zeros(N, **f)
-        o.fin_length = torch.zeros(N, dtype=torch.int32, device=self.device)
-        o.fin_violation = torch.zeros(N, **f)
-        o.fin_mse = torch.zeros(N, **f)
+        for k in ('obs', 'reward', 'done', 'flags', 'mse', 'terminal_obs', 'state', 'noisy_action', 'fin_stats'):
+            setattr(o, k, view[k])
+        o.c_values = view['c_values'] if n_rows else None                # [n_con_rows, N]
         self.out = o
-        self.ep_return = torch.zeros(N, **f)
-        self.ep_length = torch.zeros(N, dtype=torch.int32, device=self.device)
-        self.ep_violation = torch.zeros(N, **f)
-        self.ep_mse = torch.zeros(N, **f)
+        self.ep_stats = view['ep_stats']
         self._c_out = self._make_c_out(o)
         self._actions = None
         self._adv = None
@@ -229,6 +240,12 @@ class HipVecEnv(VecEnv):
 
     def _chk(self, rc):
         L.check(rc, self._lib)
+
+    # running totals of the current episodes (columns of the packed accumulator)
+    ep_return = property(lambda self: self.ep_stats[:, 0])
+    ep_length = property(lambda self: self.ep_stats[:, 1])
+    ep_violation = property(lambda self: self.ep_stats[:, 2])
+    ep_mse = property(lambda self: self.ep_stats[:, 3])
 
     # ------------------------------------------------------------------ plumbing
     def _make_c_out(self, o, obs=None):
@@ -238,10 +255,7 @@ class HipVecEnv(VecEnv):
         s.d_reward, s.d_done, s.d_flags = p(o.reward), p(o.done), p(o.flags)
         s.d_c_values, s.d_mse, s.d_terminal_obs = p(o.c_values), p(o.mse), p(o.terminal_obs)
         s.d_state, s.d_noisy_action = p(o.state), p(o.noisy_action)
-        s.d_ep_return, s.d_ep_length = p(self.ep_return), p(self.ep_length)
-        s.d_ep_violation, s.d_ep_mse = p(self.ep_violation), p(self.ep_mse)
-        s.d_fin_return, s.d_fin_length = p(o.fin_return), p(o.fin_length)
-        s.d_fin_violation, s.d_fin_mse = p(o.fin_violation), p(o.fin_mse)
+        s.d_ep_stats, s.d_fin_stats = p(self.ep_stats), p(o.fin_stats)
         return s
 
     def _stream(self):

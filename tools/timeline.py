@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the specialised Q2-track step kernel (timing-only build with -DSCG_EXP_TIMELINE).
+
+  python tools/timeline.py build   # here: compile the variant next to the shipped specialised library
+  python tools/timeline.py run     # on the GPU box: run steps, read back the per-wave shader-clock marks
+"""
+import ctypes as C, os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H = 'ca5967b538e7d771'
+SPEC = os.path.join(ROOT, 'safe_control_gym_amd', 'spec')
+VARIANT = os.path.join(SPEC, 'exp', 'TIMELINE.so')
+MARKS = ['entry', 'kernargs', 'state loaded', 'integrated', 'reward/done', 'constraints', 'obs+stats stored', 'end']
+
+if sys.argv[1] == 'build':
+    os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-w', '-DSCG_SPEC',
+                           '-DSCG_EXP_TIMELINE'] + sys.argv[2:] + ['-include', f'{SPEC}/scg_spec_{H}.h', '-o', VARIANT,
+                           f'{ROOT}/safe_control_gym_amd/csrc/scg_kernels.hip'])
+else:
+    import shutil, numpy as np, torch
+    real = f'{SPEC}/libscg_spec_{H}.so'
+    shutil.copy(real, '/tmp/keep.so'); shutil.copy(VARIANT, real)
+    try:
+        from safe_control_gym_amd.registration import load_task
+        from safe_control_gym_amd.vec_env import HipVecEnv
+        env_id, cfg = load_task('quadrotor_2D_track')
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+        env = HipVecEnv(env_id, n, seed=1, return_numpy=False, **cfg)
+        env.bind_outputs(state=None, noisy_action=None)
+        env.reset_tensors()
+        acts = [torch.rand(n, 2, device='cuda') * 2 - 1 for _ in range(16)]
+        L = env._lib
+        L.scg_exp_timeline.argtypes = [C.c_void_p, C.c_size_t]
+        rows = []
+        for it in range(300):
+            env.step_tensors(acts[it % 16])
+            if it >= 100:
+                torch.cuda.synchronize()
+                buf = np.zeros(4096 * 8, dtype=np.uint64)
+                assert L.scg_exp_timeline(buf.ctypes.data, buf.size) == 0
+                t = buf.reshape(4096, 8)[:max(1, n // 64)].astype(np.int64)
+                rows.append(t)
+        t = np.stack(rows)                                # [iters][waves][marks]; XCD clocks are not mutually synchronised
+        d = np.diff(t, axis=2).reshape(-1, 7)             # per-wave phase durations
+        tot = (t[:, :, 7] - t[:, :, 0]).reshape(-1)
+        print(f'{n} envs, {t.shape[1]} waves, {t.shape[0]} launches; shader-clock ticks per phase (per wave)')
+        print(f'  {"phase":34s} {"mean":>7s} {"p10":>7s} {"p50":>7s} {"p90":>7s} {"share":>6s}')
+        for k in range(7):
+            col = d[:, k]
+            print(f'  {MARKS[k] + " -> " + MARKS[k + 1]:34s} {col.mean():7.0f} {np.percentile(col, 10):7.0f} {np.median(col):7.0f} '
+                  f'{np.percentile(col, 90):7.0f} {col.mean() / tot.mean():6.1%}')
+        print(f'  {"entry -> end":34s} {tot.mean():7.0f} {np.percentile(tot, 10):7.0f} {np.median(tot):7.0f} {np.percentile(tot, 90):7.0f}')
+        sys.stdout.flush(); os._exit(0)
+    finally:
+        shutil.copy('/tmp/keep.so', real)
