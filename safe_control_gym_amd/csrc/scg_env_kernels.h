@@ -94,32 +94,35 @@ struct OutPtrs {
     Slot<T> obs, reward; Slot<uint8_t> done, flags; Slot<T> c_values, mse, terminal_obs, state, noisy_action, ep_stats, fin_stats;
 };
 
-template <typename V, bool ONE>
-__device__ __forceinline__ Slot<V> out_slot(const OutTab& O, int k, int i, int elems = 1) {
-    if constexpr (ONE) return slot_in<V>(make_rsrc(O.base), O.off[k], i, elems);
-    else return slot(reinterpret_cast<V*>(O.ptr[k]), i, elems);
+template <typename V>
+__device__ __forceinline__ Slot<V> out_slot(const OutTabOne& O, int k, int i, int elems = 1) {
+    return slot_in<V>(make_rsrc(O.base), O.off[k], i, elems);
+}
+template <typename V>
+__device__ __forceinline__ Slot<V> out_slot(const OutTabPtr& O, int k, int i, int elems = 1) {
+    return slot(reinterpret_cast<V*>(O.ptr[k]), i, elems);
 }
 
-template <typename T, bool ONE>
-__device__ __forceinline__ OutPtrs<T> out_ptrs(const OutTab& O, int i, int nobs) {
+template <typename T, typename TAB>
+__device__ __forceinline__ OutPtrs<T> out_ptrs(const TAB& O, int i, int nobs) {
     OutPtrs<T> p;
-    p.obs = out_slot<T, ONE>(O, OUT_OBS, i, nobs);
-    p.terminal_obs = out_slot<T, ONE>(O, OUT_TERMINAL_OBS, i, nobs);
-    p.reward = out_slot<T, ONE>(O, OUT_REWARD, i);
-    p.done = out_slot<uint8_t, ONE>(O, OUT_DONE, i);
-    p.flags = out_slot<uint8_t, ONE>(O, OUT_FLAGS, i);
-    p.c_values = out_slot<T, ONE>(O, OUT_C_VALUES, i);
-    p.mse = out_slot<T, ONE>(O, OUT_MSE, i);
-    p.state = out_slot<T, ONE>(O, OUT_STATE, i);
-    p.noisy_action = out_slot<T, ONE>(O, OUT_NOISY_ACTION, i);
-    p.ep_stats = out_slot<T, ONE>(O, OUT_EP_STATS, i, 4);
-    p.fin_stats = out_slot<T, ONE>(O, OUT_FIN_STATS, i, 4);
+    p.obs = out_slot<T>(O, OUT_OBS, i, nobs);
+    p.terminal_obs = out_slot<T>(O, OUT_TERMINAL_OBS, i, nobs);
+    p.reward = out_slot<T>(O, OUT_REWARD, i);
+    p.done = out_slot<uint8_t>(O, OUT_DONE, i);
+    p.flags = out_slot<uint8_t>(O, OUT_FLAGS, i);
+    p.c_values = out_slot<T>(O, OUT_C_VALUES, i);
+    p.mse = out_slot<T>(O, OUT_MSE, i);
+    p.state = out_slot<T>(O, OUT_STATE, i);
+    p.noisy_action = out_slot<T>(O, OUT_NOISY_ACTION, i);
+    p.ep_stats = out_slot<T>(O, OUT_EP_STATS, i, 4);
+    p.fin_stats = out_slot<T>(O, OUT_FIN_STATS, i, 4);
     return p;
 }
 
 template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                      const uint8_t* __restrict__ mask, const OutTab OT) {
+                                                      const uint8_t* __restrict__ mask, const OutTabPtr OT) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
     Ops::reset(P, i, e, key);
     T st[D::NX];
     Ops::state_vector(e, st);
-    const OutPtrs<T> Q = out_ptrs<T, false>(OT, i, P.c.nobs);
+    const OutPtrs<T> Q = out_ptrs<T>(OT, i, P.c.nobs);
     if (Q.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs);
     if (Q.c_values && P.c.n_state_con_rows > 0) Ops::constraints(P, st, st, Q.c_values, (size_t)N, true);
     if (Q.state) {
@@ -194,25 +197,30 @@ __device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T
     }
 }
 
-template <typename T, bool ONE>
-__device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* action, const T* adv, const OutTab& O) {
+template <typename T>
+__device__ __forceinline__ void fence_out(const OutTabOne& O) {
+    sreg_fence(O.base);
+#pragma unroll
+    for (int k = 0; k < OUT_COUNT; ++k) sreg_fence(O.off[k]);
+}
+template <typename T>
+__device__ __forceinline__ void fence_out(const OutTabPtr& O) {
+#pragma unroll
+    for (int k = 0; k < OUT_COUNT; ++k) sreg_fence(O.ptr[k]);
+}
+template <typename T, typename TAB>
+__device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* action, const T* adv, const TAB& O) {
     sreg_fence(I.cold); sreg_fence(I.x_goal); sreg_fence(I.ws); sreg_fence(I.state_off); sreg_fence(I.param_off);
     sreg_fence(I.step_off); sreg_fence(I.episode_off); sreg_fence(I.oob_off); sreg_fence(I.num_envs);
     sreg_fence(I.env_id_offset); sreg_fence(I.key0); sreg_fence(I.key1);
     sreg_fence(action); sreg_fence(adv);
-    if constexpr (ONE) {
-        sreg_fence(O.base);
-#pragma unroll
-        for (int k = 0; k < OUT_COUNT; ++k) sreg_fence(O.off[k]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < OUT_COUNT; ++k) sreg_fence(O.ptr[k]);
-    }
+    fence_out<T>(O);
 }
 
 template <int SYS, typename T, bool DIST, bool ONE>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                     const T* __restrict__ action, const T* __restrict__ adv, const OutTab O) {
+                                                     const T* __restrict__ action, const T* __restrict__ adv,
+                                                     const typename OutTabOf<ONE>::type O) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     const bool live = i < N;
     // ---- memory round 1: kernargs — every pointer is fetched in this block, one scalar-memory round
     SCG_TL(0);
-    fence_kernargs<T, ONE>(I, action, adv, O);
+    fence_kernargs<T>(I, action, adv, O);
     SCG_TL(1);
     typename Ops::E e;
     T act[D::NU];
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     const PV<T> Pg{*Cg, I};
     const int nobs_early = D::NX * (1 + I.obs_ext_rows);
 #endif
-    OutPtrs<T> Q = out_ptrs<T, ONE>(O, live ? i : 0, nobs_early);
+    OutPtrs<T> Q = out_ptrs<T>(O, live ? i : 0, nobs_early);
 #ifdef SCG_EXP_NO_CVAL
     Q.c_values.soff = SCG_NO_OFF;
 #endif

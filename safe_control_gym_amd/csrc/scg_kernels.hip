@@ -533,11 +533,11 @@ extern "C" int scg_destroy(scg_env* env) {
 // scg_step_out -> kernel-side table.  When every bound array (with its extent) fits a 4 GiB window the kernel addresses
 // them through one buffer resource (base + 32-bit offsets); otherwise through one resource per array.
 template <typename T>
-static OutTab out_tab(const scg_env* e, const scg_step_out* o, bool* one_base) {
-    OutTab t{};
-    for (int k = 0; k < OUT_COUNT; ++k) { t.off[k] = SCG_NO_OFF; t.ptr[k] = nullptr; }
+static void out_tabs(const scg_env* e, const scg_step_out* o, OutTabOne* one, OutTabPtr* each, bool* one_base) {
+    one->base = nullptr;
+    for (int k = 0; k < OUT_COUNT; ++k) { one->off[k] = SCG_NO_OFF; each->ptr[k] = nullptr; }
     *one_base = true;
-    if (!o) return t;
+    if (!o) return;
     const size_t N = (size_t)e->cfg.num_envs, sT = sizeof(T);
     void* const p[OUT_COUNT] = {o->d_obs, o->d_reward, o->d_done, o->d_flags, o->d_c_values, o->d_mse, o->d_terminal_obs,
                                 o->d_state, o->d_noisy_action, o->d_ep_stats, o->d_fin_stats};
@@ -545,17 +545,16 @@ static OutTab out_tab(const scg_env* e, const scg_step_out* o, bool* one_base) {
                                    N * e->nobs * sT, (size_t)e->nx * N * sT, (size_t)e->nu * N * sT, 4 * N * sT, 4 * N * sT};
     uintptr_t lo = UINTPTR_MAX, hi = 0;
     for (int k = 0; k < OUT_COUNT; ++k) {
-        t.ptr[k] = (char*)p[k];
+        each->ptr[k] = (char*)p[k];
         if (!p[k]) continue;
         lo = std::min(lo, (uintptr_t)p[k]);
         hi = std::max(hi, (uintptr_t)p[k] + ext[k]);
     }
-    if (hi == 0) return t;
-    if (hi - lo >= 0xffff0000ull) { *one_base = false; return t; }
-    t.base = (char*)lo;
+    if (hi == 0) return;
+    if (hi - lo >= 0xffff0000ull) { *one_base = false; return; }
+    one->base = (char*)lo;
     for (int k = 0; k < OUT_COUNT; ++k)
-        if (p[k]) t.off[k] = (uint32_t)((uintptr_t)p[k] - lo);
-    return t;
+        if (p[k]) one->off[k] = (uint32_t)((uintptr_t)p[k] - lo);
 }
 
 #define DISPATCH_SYS_D(env, T, CALL)                                           \
@@ -580,7 +579,9 @@ template <typename T>
 static int launch_reset(scg_env* env, const uint8_t* mask, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
     bool one_base;
-    const OutTab O = out_tab<T>(env, out, &one_base);
+    OutTabOne O1;
+    OutTabPtr O;
+    out_tabs<T>(env, out, &O1, &O, &one_base);
     const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
     const InstParams<T> I = inst_of<T>(env);
     DISPATCH_SYS(env, T, (reset_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, mask, O)));
@@ -592,11 +593,13 @@ template <typename T>
 static int launch_step(scg_env* env, const void* action, const void* adv, const scg_step_out* out, hipStream_t st) {
     const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
     bool one_base;
-    const OutTab O = out_tab<T>(env, out, &one_base);
+    OutTabOne O1;
+    OutTabPtr O;
+    out_tabs<T>(env, out, &O1, &O, &one_base);
     const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
     const InstParams<T> I = inst_of<T>(env);
     if (one_base) {
-        DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+        DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
     } else {
         DISPATCH_SYS(env, T, (step_kernel<S, T, DD, false><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
     }
