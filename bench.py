@@ -97,10 +97,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # SCG_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices round-robin); the driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get('SCG_BENCH_BACKEND', 'nccl')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -165,7 +172,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / done_steps          # avg launch-to-launch period of the step kernel
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    el = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

@@ -20,15 +20,15 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--task', default='quadrotor_2D_track')
-    ap.add_argument('--envs', type=int, default=65536)
+    ap.add_argument('--envs', type=int, default=16384)
     ap.add_argument('--rollout-steps', type=int, default=32)
     ap.add_argument('--epochs', type=int, default=4)
-    ap.add_argument('--minibatch', type=int, default=131072)
-    ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--minibatch', type=int, default=65536)
+    ap.add_argument('--lr', type=float, default=2e-3)
     ap.add_argument('--critic-lr', type=float, default=None)
     ap.add_argument('--hidden', type=int, default=128)
     ap.add_argument('--activation', default='tanh')
-    ap.add_argument('--target-kl', type=float, default=0.01)
+    ap.add_argument('--target-kl', type=float, default=0.03)
     ap.add_argument('--entropy', type=float, default=0.01)
     ap.add_argument('--gamma', type=float, default=0.99)
     ap.add_argument('--lam', type=float, default=0.95)
@@ -36,11 +36,12 @@ def main():
     ap.add_argument('--max-seconds', type=float, default=120.0)
     ap.add_argument('--target-return', type=float, default=236.0)
     ap.add_argument('--eval-envs', type=int, default=256)
-    ap.add_argument('--eval-every', type=int, default=2)
+    ap.add_argument('--eval-every', type=int, default=4)
     ap.add_argument('--seed', type=int, default=2)
     ap.add_argument('--respect-yaml-init', action='store_true',
                     help='honour init_state_randomization_info of the YAML (the reference class ignores it)')
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='eager PyTorch update / rollout instead of HIP-graph replay')
     args = ap.parse_args()
 
     import torch
@@ -62,7 +63,8 @@ def main():
     pcfg = PPOConfig(hidden_dim=args.hidden, activation=args.activation, gamma=args.gamma, use_gae=True, gae_lambda=args.lam,
                      target_kl=args.target_kl, entropy_coef=args.entropy, opt_epochs=args.epochs,
                      mini_batch_size=args.minibatch, actor_lr=args.lr, critic_lr=args.critic_lr or args.lr,
-                     rollout_batch_size=args.envs, rollout_steps=args.rollout_steps, max_env_steps=int(args.max_env_steps))
+                     rollout_batch_size=args.envs, rollout_steps=args.rollout_steps, max_env_steps=int(args.max_env_steps),
+                     extra={'cuda_graphs': not args.no_graphs})
     ppo = PPO(env, pcfg, seed=args.seed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -157,24 +157,147 @@ def value_loss_term(ac, batch, clip_param, use_clipped_value):
 class PPOAgent:
     def __init__(self, obs_dim, act_dim, cfg: PPOConfig, device):
         self.cfg = cfg
+        self.device = torch.device(device)
         self.ac = MLPActorCritic(obs_dim, act_dim, [cfg.hidden_dim] * 2, cfg.activation).to(device)
         self.actor_opt = torch.optim.Adam(self.ac.actor.parameters(), cfg.actor_lr)
         self.critic_opt = torch.optim.Adam(self.ac.critic.parameters(), cfg.critic_lr)
         parallel.broadcast_parameters([self.ac])
         self._bucket = None
+        # HIP-graph replay of the minibatch step (launch-bound: ~100 tiny kernels on a 6->64->64->2 MLP); the
+        # eager path below stays the reference implementation and is what the CPU tests exercise
+        self.use_graphs = self.device.type == 'cuda' and bool(cfg.extra.get('cuda_graphs', True))
+        self._g = None
+        # flatten NOW: every graph captured later (rollout and update) must see the final parameter storage
+        self._flat = self._flatten() if self.use_graphs else None
+
+    # ---- graphed update -------------------------------------------------------------------------------------
+    def _flatten(self):
+        """Parameters and gradients of both networks as views of two flat buffers (+1 gradient slot for approx_kl, so
+        that one all-reduce carries everything), Adam moments next to them."""
+        actor, critic = list(self.ac.actor.parameters()), list(self.ac.critic.parameters())
+        params = actor + critic
+        n_a = sum(p.numel() for p in actor)
+        n = sum(p.numel() for p in params)
+        flat_p = torch.cat([p.data.reshape(-1) for p in params]).contiguous()
+        flat_g = torch.zeros(n + 1, device=self.device)
+        off = 0
+        for p in params:
+            k = p.numel()
+            p.data = flat_p[off:off + k].view_as(p)
+            p.grad = flat_g[off:off + k].view_as(p)
+            off += k
+        lr = torch.cat([torch.full((n_a,), float(self.cfg.actor_lr)), torch.full((n - n_a,), float(self.cfg.critic_lr))]).to(self.device)
+        is_critic = torch.cat([torch.zeros(n_a, dtype=torch.bool), torch.ones(n - n_a, dtype=torch.bool)]).to(self.device)
+        return {'p': flat_p, 'g': flat_g, 'm': torch.zeros(n, device=self.device), 'v': torch.zeros(n, device=self.device),
+                'lr': lr, 'is_critic': is_critic, 'n_a': n_a, 'n': n,
+                'steps': torch.zeros(2, device=self.device)}          # Adam step counts: actor, critic
+
+    def _build_graphs(self, data, mb):
+        cfg = self.cfg
+        G = dict(self._flat)
+        G['idx'] = torch.zeros(mb, dtype=torch.long, device=self.device)
+        G['data'] = data
+        G['stats'] = torch.zeros(5, device=self.device)              # policy, value, entropy, kl sums; actor steps
+        b1, b2, eps = 0.9, 0.999, 1e-8                               # torch.optim.Adam defaults, as upstream
+
+        def fwd_bwd():
+            batch = {k: v.index_select(0, G['idx']) for k, v in data.items()}
+            policy_loss, entropy_loss, approx_kl = policy_loss_terms(self.ac, batch, cfg.clip_param)
+            value_loss = value_loss_term(self.ac, batch, cfg.clip_param, cfg.use_clipped_value)
+            G['g'].zero_()
+            (policy_loss + cfg.entropy_coef * entropy_loss).backward()
+            value_loss.backward()
+            G['g'][-1] = approx_kl.detach()
+            G['losses'] = torch.stack([policy_loss.detach(), value_loss.detach(), entropy_loss.detach()])
+
+        def adam():
+            kl = G['g'][-1]
+            gate = (kl <= 1.5 * cfg.target_kl) if cfg.target_kl > 0 else torch.ones((), dtype=torch.bool, device=self.device)
+            G['steps'] += torch.stack([gate.to(torch.float32), torch.ones((), device=self.device)])
+            take = G['is_critic'] | gate                               # per element: does its optimiser step now?
+            g = G['g'][:-1]
+            m = torch.where(take, b1 * G['m'] + (1 - b1) * g, G['m'])
+            v = torch.where(take, b2 * G['v'] + (1 - b2) * g * g, G['v'])
+            t = torch.where(G['is_critic'], G['steps'][1], G['steps'][0]).clamp(min=1.0)
+            bc1 = 1 - torch.pow(b1, t)
+            bc2 = 1 - torch.pow(b2, t)
+            upd = G['lr'] / bc1 * m / (v.sqrt() / bc2.sqrt() + eps)
+            G['p'].sub_(torch.where(take, upd, torch.zeros_like(upd)))
+            G['m'].copy_(m)
+            G['v'].copy_(v)
+            G['stats'] += torch.cat([G['losses'], kl.reshape(1), gate.to(torch.float32).reshape(1)])
+
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        keep = {k: G[k].clone() for k in ('p', 'm', 'v', 'steps')}
+        with torch.cuda.stream(s):
+            for _ in range(3):                                           # warm-up (allocator, autograd), state restored below
+                fwd_bwd()
+                adam()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        for k, t in keep.items():
+            G[k].copy_(t)
+        G['stats'].zero_()
+        G['fb'], G['ad'] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(G['fb']):
+            fwd_bwd()
+        with torch.cuda.graph(G['ad'], pool=G['fb'].pool()):
+            adam()
+        for k, t in keep.items():
+            G[k].copy_(t)
+        G['stats'].zero_()
+        return G
+
+    def _update_graphed(self, data, generator=None):
+        cfg = self.cfg
+        M = data['obs'].shape[0]
+        mb = min(cfg.mini_batch_size, M)
+        n_mb = M // mb
+        assert n_mb != 0, 'num_mini_batch is 0'
+        if self._g is None or self._g['key'] != (M, mb):
+            # static copies of the per-iteration inputs (the rollout tensors keep their addresses already)
+            static = {k: (v if k in ('obs', 'act', 'logp', 'v') else torch.empty_like(v)) for k, v in data.items()}
+            self._g = self._build_graphs(static, mb)
+            self._g['key'] = (M, mb)
+        G = self._g
+        for k, v in data.items():
+            if G['data'][k].data_ptr() != v.data_ptr():
+                G['data'][k].copy_(v)
+        G['stats'].zero_()
+        world = parallel.world_size()
+        for _ in range(cfg.opt_epochs):
+            perm = torch.randperm(M, device=self.device, generator=generator)[:n_mb * mb].view(n_mb, mb)
+            for j in range(n_mb):
+                G['idx'].copy_(perm[j])
+                G['fb'].replay()
+                if world > 1:                                            # gradients of both networks + approx_kl, one collective
+                    parallel.all_reduce_sum_(G['g'])
+                    G['g'].div_(world)
+                G['ad'].replay()
+        st = (G['stats'] / (cfg.opt_epochs * n_mb)).tolist()
+        return {'policy_loss': st[0], 'value_loss': st[1], 'entropy_loss': st[2], 'approx_kl': st[3],
+                'actor_steps': int(round(st[4] * cfg.opt_epochs * n_mb)), 'minibatches': cfg.opt_epochs * n_mb}
 
     def state_dict(self):
-        return {'ac': self.ac.state_dict(), 'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict()}
+        sd = {'ac': self.ac.state_dict(), 'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict()}
+        if self._g is not None:
+            sd['flat_adam'] = {k: self._g[k].clone() for k in ('m', 'v', 'steps')}
+        return sd
 
     def load_state_dict(self, sd):
         self.ac.load_state_dict(sd['ac'])
         if 'actor_opt' in sd:
             self.actor_opt.load_state_dict(sd['actor_opt'])
             self.critic_opt.load_state_dict(sd['critic_opt'])
+        if 'flat_adam' in sd and self._g is not None:
+            for k, t in sd['flat_adam'].items():
+                self._g[k].copy_(t)
 
     def update(self, data, generator=None):
         """`data`: dict of flat [M, .] tensors (obs, act, logp, adv, ret, v).  Epochs x shuffled minibatches, drop last
         (ppo_utils.py:113-146, :358-371).  Returns the reference's averaged loss statistics."""
+        if self.use_graphs:
+            return self._update_graphed(data, generator)
         cfg = self.cfg
         M = data['obs'].shape[0]
         mb = min(cfg.mini_batch_size, M)
@@ -245,6 +368,7 @@ class PPO:
                                         terminal_obs=self.term_obs[t], state=None, noisy_action=None, c_values=None,
                                         mse=None) for t in range(T)]
         self.total_steps = 0
+        self._rollout_graph = None
         self.obs[0].copy_(env.reset_tensors())
         # finished-episode statistics (VecRecordEpisodeStatistics), accumulated on device
         self.ep_count = torch.zeros((), device=self.device)
@@ -253,7 +377,7 @@ class PPO:
         self.ep_violation_sum = torch.zeros((), device=self.device)
 
     # ---- rollout (ppo.py:266-284)
-    def collect(self):
+    def _collect_body(self):
         ac, env = self.agent.ac, self.env
         for t in range(self.T):
             act, v, logp = ac.step(self.obs[t])
@@ -265,28 +389,66 @@ class PPO:
             self.ep_return_sum += (out.fin_return * d).sum()
             self.ep_length_sum += (out.fin_length.to(torch.float32) * d).sum()
             self.ep_violation_sum += (out.fin_violation * d).sum()
+
+    def collect(self):
+        self._collect_body()
         self.total_steps += self.T * self.N * parallel.world_size()
+
+    @torch.no_grad()
+    def _returns_body(self, dense):
+        """Bootstrap values, returns, advantages (not yet normalised) and the advantage moments.  dense=True evaluates
+        the critic on every terminal-observation slot (static shapes, HIP-graph capturable) instead of gathering the
+        truncated ones; the values used are the same."""
+        cfg, ac = self.cfg, self.agent.ac
+        last_val = ac.critic(self.obs[self.T]).squeeze(-1)
+        mask = 1.0 - self.done.to(torch.float32)
+        # time truncation is not termination: bootstrap with the critic's value of the terminal observation
+        trunc = (self.flags & 1).bool() & self.done.bool()
+        if dense:
+            tv = ac.critic(self.term_obs.reshape(self.T * self.N, self.obs_dim)).reshape(self.T, self.N)
+            terminal_v = torch.where(trunc, tv, torch.zeros_like(tv))
+        else:
+            terminal_v = torch.zeros_like(self.rew)
+            idx = trunc.nonzero(as_tuple=False)
+            if idx.numel():
+                terminal_v[idx[:, 0], idx[:, 1]] = ac.critic(self.term_obs[idx[:, 0], idx[:, 1]]).squeeze(-1)
+        rew = self.rew.clone()
+        ret, adv = self._gae(rew, self.v, mask, terminal_v, last_val, cfg.gamma, cfg.gae_lambda, cfg.use_gae)
+        moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])
+        return ret, adv, moments
+
+    def _build_rollout_graph(self):
+        """One HIP graph for the whole iteration front end: T x (policy forward, sampling, value, log-prob, env step
+        kernel, episode statistics), then bootstrap values, scg_gae and the advantage moments."""
+        dev = self.device
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(3):                  # warm up the torch ops only (no env step: the simulation must not advance)
+                self.agent.ac.step(self.obs[0])
+                self._returns_body(dense=True)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._collect_body()
+            out = self._returns_body(dense=True)
+        return g, out
 
     # ---- returns / advantages / update (ppo.py:286-303)
     def train_step(self):
-        cfg = self.cfg
         t0 = time.perf_counter()
-        self.collect()
-        ac = self.agent.ac
+        if self.agent.use_graphs:
+            if self._rollout_graph is None:       # capture records the launches without running them
+                self._rollout_graph, self._rollout_out = self._build_rollout_graph()
+            self._rollout_graph.replay()
+            self.total_steps += self.T * self.N * parallel.world_size()
+            ret, adv, moments = self._rollout_out
+            moments = moments.clone()
+        else:
+            self.collect()
+            ret, adv, moments = self._returns_body(dense=False)
         with torch.no_grad():
-            last_val = ac.critic(self.obs[self.T]).squeeze(-1)
-            mask = 1.0 - self.done.to(torch.float32)
-            # time truncation is not termination: bootstrap with the critic's value of the terminal observation
-            terminal_v = torch.zeros_like(self.rew)
-            trunc = (self.flags & 1).bool() & self.done.bool()
-            idx = trunc.nonzero(as_tuple=False)
-            if idx.numel():
-                tv = ac.critic(self.term_obs[idx[:, 0], idx[:, 1]]).squeeze(-1)
-                terminal_v[idx[:, 0], idx[:, 1]] = tv
-            rew = self.rew.clone()
-            ret, adv = self._gae(rew, self.v, mask, terminal_v, last_val, cfg.gamma, cfg.gae_lambda, cfg.use_gae)
             # global advantage normalisation (ppo.py:300): population std, +1e-6
-            moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)])
             parallel.all_reduce_sum_(moments)
             mean = moments[0] / moments[2]
             std = torch.sqrt(torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0))
@@ -294,6 +456,8 @@ class PPO:
         M = self.T * self.N
         data = {'obs': self.obs[:self.T].reshape(M, self.obs_dim), 'act': self.act.reshape(M, self.act_dim),
                 'logp': self.logp.reshape(M), 'adv': adv.reshape(M), 'ret': ret.reshape(M), 'v': self.v.reshape(M)}
+        if self.agent.use_graphs:
+            torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
         res = self.agent.update(data)
         self.obs[0].copy_(self.obs[self.T])
