@@ -19,12 +19,15 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # SCG_DIST_BACKEND=gloo exercises the multi-rank control flow on a box with fewer GPUs than ranks
+            backend = os.environ.get('SCG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
         if backend == 'nccl':
-            local = int(os.environ.get('LOCAL_RANK', '0'))
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device('cuda', local))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local % torch.cuda.device_count())
             dist.init_process_group(backend)
     return rank, world
 
