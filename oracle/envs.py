@@ -142,9 +142,12 @@ class OracleBenchmarkEnv:
                    randomized_inertial_prop=False, inertial_prop_randomization_info=None,
                    constraints=None, done_on_violation=False, use_constraint_penalty=False,
                    constraint_penalty=1.0, disturbances=None, adversary_disturbance=None,
-                   adversary_disturbance_offset=0.0, adversary_disturbance_scale=0.01, **unused):
+                   adversary_disturbance_offset=0.0, adversary_disturbance_scale=0.01,
+                   integrator='pyb_euler', rk4_substeps=1, **unused):
         # benchmark_env.py:125-191
         self.num_envs = num_envs
+        # extension (not a reference key): 'rk4' integrates the prior model instead of the PyBullet step (oracle/symbolic.py)
+        self.integrator, self.rk4_substeps = integrator, int(rk4_substeps)
         self.TASK = str(getattr(task, 'value', task))
         if task_info is not None:
             self.TASK_INFO = task_info
@@ -632,12 +635,16 @@ class OracleQuadrotor(OracleBenchmarkEnv):
         torques = rpm ** 2 * self.KM
         z_torque = -torques[:, 0] + torques[:, 1] - torques[:, 2] + torques[:, 3]
         pos, quat, vel, ang_v = self.pos, self.quat, self.vel, self.ang_v
-        # base_aviary.py:272 — posObj is the position cached at the START of the control step.
-        dist_point = None if disturb is None else self.pos.copy()
-        for _ in range(self.PYB_STEPS_PER_CTRL):
-            pos, quat, vel, ang_v = bullet.quadrotor_substep(
-                pos, quat, vel, ang_v, forces, z_torque, disturb, self.mass_env, self.J_env,
-                self.PROP_OFFSET, self.GRAVITY_ACC, self.PYB_TIMESTEP, dist_point)
+        if self.integrator == 'rk4':
+            assert disturb is None, 'the rk4 mode integrates the disturbance-free prior model'
+            pos, quat, vel, ang_v = self._rk4_step()
+        else:
+            # base_aviary.py:272 — posObj is the position cached at the START of the control step.
+            dist_point = None if disturb is None else self.pos.copy()
+            for _ in range(self.PYB_STEPS_PER_CTRL):
+                pos, quat, vel, ang_v = bullet.quadrotor_substep(
+                    pos, quat, vel, ang_v, forces, z_torque, disturb, self.mass_env, self.J_env,
+                    self.PROP_OFFSET, self.GRAVITY_ACC, self.PYB_TIMESTEP, dist_point)
         self.pos, self.quat, self.vel, self.ang_v = pos, quat, vel, ang_v
         self.rpy = bullet.euler_from_quaternion(quat)
         all_idx = np.arange(self.num_envs)
@@ -649,6 +656,32 @@ class OracleQuadrotor(OracleBenchmarkEnv):
         rew, done, info = self._after_step(rew, done)
         info.update(info_step)
         return obs, rew, done, info
+
+    def _rk4_step(self):
+        """One control period of the prior model (quadrotor.py:485-563) with the clipped thrusts as input."""
+        from oracle import symbolic
+        u = self.current_clipped_action
+        h = self.CTRL_TIMESTEP / self.rk4_substeps
+        arm, g, m = self.L / np.sqrt(2.0), self.GRAVITY_ACC, self.mass_env
+        x = self.state.copy()
+        N = self.num_envs
+        z = np.zeros(N)
+        if self.QUAD_TYPE == 1:
+            x = symbolic.rk4(lambda a, b: symbolic.f_quad1d(a, b, m, g), x, u, h, self.rk4_substeps)
+            pos = np.stack([self.pos[:, 0], self.pos[:, 1], x[:, 0]], axis=1)
+            vel = np.stack([z, z, x[:, 1]], axis=1)
+            return pos, self.quat, vel, self.ang_v
+        if self.QUAD_TYPE == 2:
+            x = symbolic.rk4(lambda a, b: symbolic.f_quad2d(a, b, m, self.J_env[:, 1], arm, g), x, u, h, self.rk4_substeps)
+            pos = np.stack([x[:, 0], z, x[:, 2]], axis=1)
+            vel = np.stack([x[:, 1], z, x[:, 3]], axis=1)
+            quat = bullet.quaternion_from_euler(np.stack([z, x[:, 4], z], axis=1))
+            return pos, quat, vel, np.stack([z, x[:, 5], z], axis=1)
+        x = symbolic.rk4(lambda a, b: symbolic.f_quad3d(a, b, m, self.J_env, arm, self.KM / self.KF, g), x, u, h, self.rk4_substeps)
+        pos, vel = x[:, [0, 2, 4]], x[:, [1, 3, 5]]
+        quat = bullet.quaternion_from_euler(x[:, 6:9])
+        R = bullet.matrix_from_quaternion(quat)
+        return pos, quat, vel, np.einsum('nij,nj->ni', R, x[:, 9:12])
 
     # quadrotor.py:819-862
     def _get_reward(self):
@@ -924,11 +957,20 @@ class OracleCartPole(OracleBenchmarkEnv):
             tab = tab + self.adv_action
             self.adv_action = None
         x, xd, th, thd = (self.state[:, i] for i in range(4))
-        ip = bullet.pole_inertia(self.pole_mass_env, self.pole_length_env, self.pole_inertia_mode)
-        for _ in range(self.PYB_STEPS_PER_CTRL):
-            x, xd, th, thd = bullet.cartpole_substep(x, xd, th, thd, force, tab, self.cart_mass_env,
-                                                     self.pole_mass_env, self.pole_length_env, ip,
-                                                     self.GRAVITY_ACC, self.PYB_TIMESTEP)
+        if self.integrator == 'rk4':
+            from oracle import symbolic
+            assert tab is None, 'the rk4 mode integrates the disturbance-free prior model'
+            xs = symbolic.rk4(lambda a, b: symbolic.f_cartpole(a, b, self.pole_length_env, self.cart_mass_env,
+                                                               self.pole_mass_env, self.GRAVITY_ACC),
+                              self.state.copy(), force.reshape(self.num_envs, 1), self.CTRL_TIMESTEP / self.rk4_substeps,
+                              self.rk4_substeps)
+            x, xd, th, thd = (xs[:, i] for i in range(4))
+        else:
+            ip = bullet.pole_inertia(self.pole_mass_env, self.pole_length_env, self.pole_inertia_mode)
+            for _ in range(self.PYB_STEPS_PER_CTRL):
+                x, xd, th, thd = bullet.cartpole_substep(x, xd, th, thd, force, tab, self.cart_mass_env,
+                                                         self.pole_mass_env, self.pole_length_env, ip,
+                                                         self.GRAVITY_ACC, self.PYB_TIMESTEP)
         self.state = np.stack([x, xd, th, thd], axis=1)
         all_idx = np.arange(self.num_envs)
         obs = self._get_observation(all_idx, at_reset=False)

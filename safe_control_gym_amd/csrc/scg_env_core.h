@@ -721,6 +721,95 @@ SCG_BOX_UNROLL
         return viol;
     }
 
+    // ---- prior-model integrator (SCG_INT_RK4): the continuous-time dynamics the reference hands to CasADi
+    // (cartpole.py:412-414; quadrotor.py:490, :506-509, :552-562), x in env.state order, u = clipped thrusts / force,
+    // integrated with classical RK4 like rk_discrete (controllers/mpc/mpc_utils.py:42-64).
+    __device__ static __forceinline__ void sym_f(const PV<T>& P, const E& e, const T* x, const T* u, T* dx) {
+        const T g = P.c.gravity;
+        if constexpr (SYS == SCG_CARTPOLE) {
+            const T l = e.par[0], M = e.par[1], m = e.par[2];
+            const T Mm = m + M, ml = m * l;
+            T sn, cs;
+            m_sincos(x[2], &sn, &cs);
+            const T tmp = (u[0] + ml * x[3] * x[3] * sn) / Mm;
+            const T thdd = (g * sn - cs * tmp) / (l * ((T)(4.0 / 3.0) - m * cs * cs / Mm));
+            dx[0] = x[1]; dx[1] = tmp - ml * thdd * cs / Mm; dx[2] = x[3]; dx[3] = thdd;
+        } else if constexpr (SYS == SCG_QUAD_1D) {
+            dx[0] = x[1]; dx[1] = u[0] / e.par[0] - g;
+        } else if constexpr (SYS == SCG_QUAD_2D) {
+            const T m = e.par[0], iyy = e.par[2];
+            T sn, cs;
+            m_sincos(x[4], &sn, &cs);
+            const T th = u[0] + u[1];
+            dx[0] = x[1]; dx[1] = sn * th / m; dx[2] = x[3]; dx[3] = cs * th / m - g; dx[4] = x[5];
+            dx[5] = P.c.arm * (u[1] - u[0]) / iyy;                       // arm = L / sqrt(2) in this mode
+        } else {
+            const T m = e.par[0], J0 = e.par[1], J1 = e.par[2], J2 = e.par[3];
+            T sphi, cphi, sth, cth, spsi, cpsi;
+            m_sincos(x[6], &sphi, &cphi); m_sincos(x[7], &sth, &cth); m_sincos(x[8], &spsi, &cpsi);
+            const T thrust = (u[0] + u[1] + u[2] + u[3]) / m;
+            // third column of Rz Ry Rx
+            const T r02 = cpsi * sth * cphi + spsi * sphi, r12 = spsi * sth * cphi - cpsi * sphi, r22 = cth * cphi;
+            const T pb = x[9], qb = x[10], rb = x[11];
+            const T lsq = P.c.arm, gam = P.c.km / P.c.kf;
+            const T mb0 = lsq * (u[0] + u[1] - u[2] - u[3]), mb1 = lsq * (-u[0] + u[1] + u[2] - u[3]);
+            const T mb2 = gam * (-u[0] + u[1] - u[2] + u[3]);
+            const T jw0 = J0 * pb, jw1 = J1 * qb, jw2 = J2 * rb;
+            const T tth = sth / cth;
+            dx[0] = x[1]; dx[1] = r02 * thrust; dx[2] = x[3]; dx[3] = r12 * thrust; dx[4] = x[5]; dx[5] = r22 * thrust - g;
+            dx[6] = pb + sphi * tth * qb + cphi * tth * rb;
+            dx[7] = cphi * qb - sphi * rb;
+            dx[8] = (sphi * qb + cphi * rb) / cth;
+            dx[9] = (mb0 - (qb * jw2 - rb * jw1)) / J0;
+            dx[10] = (mb1 - (rb * jw0 - pb * jw2)) / J1;
+            dx[11] = (mb2 - (pb * jw1 - qb * jw0)) / J2;
+        }
+    }
+
+    // `substeps` RK4 steps of size pyb_dt (= control period / substeps) on env.state; raw state rebuilt afterwards.
+    __device__ static __forceinline__ void rk4_advance(const PV<T>& P, E& e, const T* u) {
+        T x[D::NX];
+        state_vector_raw(e, x);
+        const T h = P.c.pyb_dt;
+        for (int s = 0; s < P.c.substeps; ++s) {
+            T k1[D::NX], k2[D::NX], k3[D::NX], k4[D::NX], y[D::NX];
+            sym_f(P, e, x, u, k1);
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) y[k] = x[k] + (T)0.5 * h * k1[k];
+            sym_f(P, e, y, u, k2);
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) y[k] = x[k] + (T)0.5 * h * k2[k];
+            sym_f(P, e, y, u, k3);
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) y[k] = x[k] + h * k3[k];
+            sym_f(P, e, y, u, k4);
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) x[k] += h * (T)(1.0 / 6.0) * (k1[k] + (T)2 * k2[k] + (T)2 * k3[k] + k4[k]);
+        }
+        if constexpr (SYS != SCG_QUAD_3D) {
+#pragma unroll
+            for (int k = 0; k < D::NS; ++k) e.s[k] = x[k];
+        } else {
+            e.s[0] = x[0]; e.s[1] = x[2]; e.s[2] = x[4];
+            e.s[7] = x[1]; e.s[8] = x[3]; e.s[9] = x[5];
+            euler_to_quat(x[6], x[7], x[8], &e.s[3]);
+            T R[3][3];
+            quat_to_mat(&e.s[3], R);
+            e.s[10] = R[0][0] * x[9] + R[0][1] * x[10] + R[0][2] * x[11];      // world rates = R * body rates
+            e.s[11] = R[1][0] * x[9] + R[1][1] * x[10] + R[1][2] * x[11];
+            e.s[12] = R[2][0] * x[9] + R[2][1] * x[10] + R[2][2] * x[11];
+        }
+    }
+    // env.state with the UNWRAPPED planar pitch (what the prior model integrates); equals state_vector otherwise
+    __device__ static __forceinline__ void state_vector_raw(const E& e, T* st) {
+        if constexpr (SYS == SCG_QUAD_2D) {
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) st[k] = e.s[k];
+        } else {
+            state_vector(e, st);
+        }
+    }
+
     struct StepResult { T reward; T mse; bool done; uint8_t flags; };
 
     // One control step, no auto-reset.  `act_in` = raw controller action; `adv` = adversary action or null.
@@ -768,6 +857,9 @@ SCG_BOX_UNROLL
             if (noisy_out) noisy_out[j] = noisy[j];
         }
         // ---- physics
+        if (P.c.integrator == SCG_INT_RK4) {
+            rk4_advance(P, e, clipped);
+        } else {
         const T h = P.c.pyb_dt;
         const T vmax = P.c.vmax;
         // Taylor rotations are exact to < 1 ulp below 0.125 rad.  Planar systems rotate by d = h*w with
@@ -977,6 +1069,7 @@ SCG_BOX_UNROLL
                 e.s[10] = w[0]; e.s[11] = w[1]; e.s[12] = w[2];
             }
         }
+        }   // integrator
         state_vector(e, st);
         // rows of X_GOAL requested before the integrator: retire them here, ahead of the first store
         if (ref_pre) {

@@ -90,7 +90,9 @@ static int validate(const scg_config* c) {
     if (c->abi_version != SCG_ABI_VERSION) return fail(SCG_ERR_INVALID, "scg_config.abi_version mismatch");
     if (c->system < SCG_CARTPOLE || c->system > SCG_QUAD_3D) return fail(SCG_ERR_INVALID, "unknown system");
     if (c->dtype != SCG_F32 && c->dtype != SCG_F64) return fail(SCG_ERR_INVALID, "unknown dtype");
-    if (c->integrator != SCG_INT_PYB_EULER) return fail(SCG_ERR_INVALID, "only SCG_INT_PYB_EULER is implemented");
+    if (c->integrator != SCG_INT_PYB_EULER && c->integrator != SCG_INT_RK4) return fail(SCG_ERR_INVALID, "unknown integrator");
+    if (c->integrator == SCG_INT_RK4 && (c->n_dist[SCG_CH_DYNAMICS] > 0 || c->adversary_channel == SCG_CH_DYNAMICS))
+        return fail(SCG_ERR_INVALID, "SCG_INT_RK4 integrates the disturbance-free prior model: no dynamics disturbance / adversary");
     if (c->num_envs <= 0) return fail(SCG_ERR_INVALID, "num_envs must be positive");
     // kernels address each array as uniform base + 32-bit per-env byte offset (scg_env_core.h: Slot)
     if ((uint64_t)c->num_envs * 8u * (uint64_t)(SCG_MAX_STATE * (1 + (c->obs_goal_horizon > 0 ? c->obs_goal_horizon : 0))) >= (1ull << 32))
@@ -244,6 +246,7 @@ static void build_cfg(const scg_config& c, CfgParams<double>& h) {
     std::memset(&h, 0, sizeof(h));
     int32_t nx, nu, nobs, ns, np;
     scg_dims(&c, &nx, &nu, &nobs, &ns, &np);
+    h.integrator = c.integrator;
     h.substeps = c.substeps; h.ctrl_steps = c.ctrl_steps; h.task = c.task; h.cost = c.cost;
     h.obs_goal_horizon = c.obs_goal_horizon; h.goal_rows = c.goal_rows; h.nobs = nobs; h.nx = nx;
     h.rew_exponential = c.rew_exponential; h.done_on_oob = c.done_on_out_of_bound;

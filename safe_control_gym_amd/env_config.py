@@ -72,7 +72,8 @@ QUAD_DEFAULTS = dict(quad_type=2, norm_act_scale=0.1, obs_goal_horizon=0, rew_st
 CARTPOLE_DEFAULTS = dict(obs_goal_horizon=0, obs_wrap_angle=False, rew_state_weight=1.0, rew_act_weight=0.0001,
                          rew_exponential=True, done_on_out_of_bound=True, info_mse_metric_state_weight=None)
 # extensions that are NOT reference keys (documented in DESIGN.md)
-EXTENSION_DEFAULTS = dict(respect_randomization_info=False, pole_inertia='box', engine_arm='pybullet')
+EXTENSION_DEFAULTS = dict(respect_randomization_info=False, pole_inertia='box', engine_arm=None, integrator='pyb_euler',
+                          rk4_substeps=1)
 
 
 def _enum_str(v):
@@ -361,6 +362,8 @@ class EnvSpec:
         self.obs_wrap_angle = False
         self.x_threshold, self.theta_threshold_radians = 0.0, 0.0
         self.pole_box_width = 0.0
+        if kw['engine_arm'] is None:     # the prior-model integrator uses the prior model's arm
+            kw['engine_arm'] = 'symbolic' if kw['integrator'] == 'rk4' else 'pybullet'
         if kw['engine_arm'] == 'pybullet':
             self.engine_arm = c['prop_offset']            # cf2x.urdf:42-78 (what Bullet integrates)
         elif kw['engine_arm'] == 'symbolic':
@@ -601,10 +604,17 @@ class EnvSpec:
         kw = self.kw
         c = L.Config()
         c.auto_reset = int(bool(auto_reset))
-        c.abi_version, c.system, c.dtype, c.integrator = L.SCG_ABI_VERSION, self.system, dtype, L.INT_PYB_EULER
+        if self.kw['integrator'] not in ('pyb_euler', 'rk4'):
+            raise ValueError("integrator must be 'pyb_euler' or 'rk4'")
+        rk4 = self.kw['integrator'] == 'rk4'
+        c.abi_version, c.system, c.dtype = L.SCG_ABI_VERSION, self.system, dtype
+        c.integrator = L.INT_RK4 if rk4 else L.INT_PYB_EULER
         c.num_envs, c.env_id_offset, c.seed = int(num_envs), int(env_id_offset), int(seed) & 0xFFFFFFFFFFFFFFFF
         c.substeps, c.ctrl_steps = self.PYB_STEPS_PER_CTRL, int(self.CTRL_STEPS)
         c.pyb_dt, c.ctrl_dt = self.PYB_TIMESTEP, self.CTRL_TIMESTEP
+        if rk4:     # `rk4_substeps` RK4 steps of the prior model per control period (mpc_utils.py:42-64 uses one)
+            c.substeps = int(self.kw['rk4_substeps'])
+            c.pyb_dt = self.CTRL_TIMESTEP / c.substeps
         c.task = L.TASK_TRAJ_TRACKING if self.TASK == 'traj_tracking' else L.TASK_STABILIZATION
         c.cost = L.COST_QUADRATIC if self.COST == 'quadratic' else L.COST_RL_REWARD
         c.obs_goal_horizon = self.obs_goal_horizon

@@ -83,8 +83,14 @@ def test_invalid_config_is_reported_not_aborted(lib):
     assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == -1
     assert b'abi_version' in lib.scg_last_error()
     c.abi_version = L.SCG_ABI_VERSION
-    c.integrator = L.INT_RK4
+    c.integrator = 7
     assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == -1
+    assert b'integrator' in lib.scg_last_error()
+    c.integrator = L.INT_RK4                      # the prior-model integrator refuses dynamics disturbances
+    assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == 0
+    c.adversary_channel = 1
+    assert lib.scg_workspace_bytes(C.byref(c), C.byref(nb)) == -1
+    assert b'prior model' in lib.scg_last_error()
     assert lib.scg_step(None, None, None, None, None) == -1
     assert lib.scg_gae(L.F32, None, None, None, None, None, None, None, 4, 4, 0.99, 0.95, 1, None) == -1
 
@@ -122,3 +128,28 @@ def test_hip_vec_env_fails_loudly_without_a_gpu():
     from safe_control_gym_amd.vec_env import HipVecEnv
     with pytest.raises(L.ScgError):
         HipVecEnv('cartpole', 4)
+
+
+def test_rk4_mode_of_the_oracle_is_the_analytic_prior_model():
+    """oracle/symbolic.py (checker of the SCG_INT_RK4 kernels) == safe_control_gym_amd.symbolic.AnalyticModel.fd_func
+    (the product's NumPy prior model handed to model-based controllers), one RK4 step per control period."""
+    import numpy as np
+    from oracle.envs import make_oracle_env, make_rng
+    from safe_control_gym_amd.env_config import EnvSpec
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.symbolic import AnalyticModel
+    for task in ('quadrotor_2D_track', 'cartpole_stab', 'quadrotor_3D_track'):
+        env_id, cfg = load_task(task)
+        cfg = dict(cfg, integrator='rk4')
+        env = make_oracle_env(env_id, 4, make_rng('philox', 4, 3), **cfg)
+        env.reset()
+        x0 = env.state.copy()
+        env.step(np.random.default_rng(1).uniform(-1, 1, (4, env.action_dim)))
+        am = AnalyticModel(env_id, EnvSpec(env_id, cfg))
+        u = env.current_clipped_action.reshape(4, -1)
+        xf = np.stack([am.fd_func(x0[i], u[i], substeps=1)['xf'].reshape(-1) for i in range(4)])
+        # (envs that terminated were not reset: the oracle env has no auto-reset)
+        np.testing.assert_allclose(env.state, xf, rtol=1e-12, atol=1e-13)
+        spec = EnvSpec(env_id, cfg)
+        c, _ = spec.to_c_config(4, 1, 0)
+        assert c.integrator == 1 and c.substeps == 1 and abs(c.pyb_dt - spec.CTRL_TIMESTEP) < 1e-15

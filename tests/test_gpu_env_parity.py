@@ -347,3 +347,40 @@ def test_step_before_reset_is_an_error():
     with pytest.raises(L.ScgError):
         env.step_tensors(torch.zeros(4, 1, device=env.device))
     env.close()
+
+
+RK4_CASES = ['cartpole_stab', 'quadrotor_1D_track', 'quadrotor_2D_track', 'quadrotor_3D_track']
+
+
+@pytest.mark.parametrize('specialize', [False, True], ids=['generic', 'specialised'])
+@pytest.mark.parametrize('name', RK4_CASES)
+def test_rk4_prior_model_integrator_matches_oracle(name, specialize):
+    """`integrator: rk4` (SCG_INT_RK4): one classical RK4 step of the reference's prior-model equations per control
+    period instead of the PyBullet substeps.  float64 kernels, free-running against oracle/symbolic.py (which equals the
+    product's NumPy AnalyticModel, see tests/test_capi_cpu.py), plus a float32 one-step check."""
+    g, meta, cfg = _load(name)
+    cfg = dict(cfg, integrator='rk4')
+    oracle, ovec, gpu = _make_pair(meta, cfg, torch.float64, specialize=specialize)
+    tol = dict(rtol=1e-9, atol=1e-10)
+    obs_o, _ = ovec.reset()
+    np.testing.assert_allclose(_np(gpu.reset_tensors()), obs_o, **tol)
+    for t in range(min(meta['n_steps'], 120)):
+        act = g['actions'][t]
+        obs_o, rew_o, done_o, info = ovec.step(act)
+        out = gpu.step_tensors(torch.as_tensor(act, dtype=torch.float64, device=gpu.device))
+        msg = f'rk4 {name} t={t}'
+        np.testing.assert_array_equal(_np(out.done).astype(bool), done_o, err_msg=msg)
+        np.testing.assert_allclose(_np(out.reward), rew_o, err_msg=msg, **tol)
+        np.testing.assert_allclose(_np(out.obs), obs_o, err_msg=msg, **tol)
+        np.testing.assert_allclose(_np(out.state).T, oracle.state, err_msg=msg, **tol)
+        np.testing.assert_allclose(gpu.get_raw_state(), _raw_state(oracle), err_msg=msg, **tol)
+    gpu.close()
+    # the two integrators are different discretisations of (nearly) the same model: close, not equal
+    from oracle.envs import make_oracle_env, make_rng
+    n = meta['n_envs']
+    o_e = make_oracle_env(meta['task'], n, make_rng('philox', n, 1), **dict(cfg, integrator='pyb_euler'))
+    o_r = make_oracle_env(meta['task'], n, make_rng('philox', n, 1), **cfg)
+    o_e.reset(); o_r.reset()
+    o_e.step(g['actions'][0]); o_r.step(g['actions'][0])          # (the bare oracle envs do not auto-reset)
+    d = np.abs(o_e.state - o_r.state).max()
+    assert 0 < d < 2e-2, d

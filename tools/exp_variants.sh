@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build timing-only variants of the specialised Q2-track f32 library (tools/exp_variants.sh build), then on the GPU box
 # time each one through bench.py (tools/exp_variants.sh run).  Variants change results; they only attribute time.
-H=ca5967b538e7d771
+H=$(python tools/timeline.py hash)
 SPEC=safe_control_gym_amd/spec
 case "$1" in
 build)

@@ -7,12 +7,25 @@
 import ctypes as C, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-H = 'ca5967b538e7d771'
 SPEC = os.path.join(ROOT, 'safe_control_gym_amd', 'spec')
+
+
+def spec_hash():
+    from safe_control_gym_amd import _lib as L
+    from safe_control_gym_amd.env_config import EnvSpec
+    from safe_control_gym_amd.registration import load_task
+    env_id, cfg = load_task('quadrotor_2D_track')
+    c, _ = EnvSpec(env_id, cfg).to_c_config(64, L.F32, 1)
+    return '%016x' % L.spec_source(c)[1]
+
+
+H = spec_hash()
 VARIANT = os.path.join(SPEC, 'exp', 'TIMELINE.so')
 MARKS = ['entry', 'kernargs', 'state loaded', 'integrated', 'reward/done', 'constraints', 'obs+stats stored', 'end']
 
-if sys.argv[1] == 'build':
+if sys.argv[1] == 'hash':
+    print(H)
+elif sys.argv[1] == 'build':
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-w', '-DSCG_SPEC',
                            '-DSCG_EXP_TIMELINE'] + sys.argv[2:] + ['-include', f'{SPEC}/scg_spec_{H}.h', '-o', VARIANT,
