@@ -884,7 +884,7 @@ SCG_BOX_UNROLL
                 if constexpr (DIST) {
                     if (has_dyn) { b1 += fd[0]; b2 += l * (fd[0] * cs - fd[1] * sn); }
                 }
-                const T inv_det = (T)1 / (a11 * a22 - a12 * a12);
+                const T inv_det = m_div_by((T)1, a11 * a22 - a12 * a12);      // float: v_rcp (1 ulp), double: exact
                 const T xdd = (a22 * b1 - a12 * b2) * inv_det;
                 const T thdd = (a11 * b2 - a12 * b1) * inv_det;
                 xd = m_clamp(xd + h * xdd, -vmax, vmax);

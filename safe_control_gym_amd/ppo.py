@@ -464,6 +464,29 @@ class PPO:
         res.update({'step': self.total_steps, 'collect_time': t1 - t0, 'elapsed_time': time.perf_counter() - t0})
         return res
 
+    # ---- checkpoint / resume (ppo.py:112-148: same keys; the env's "random state" is the whole simulator workspace)
+    def save(self, path, training=True):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        state = {'agent': self.agent.state_dict()}
+        if training:
+            state.update({'total_steps': self.total_steps, 'obs': self.obs[0].cpu(),
+                          'random_state': {'torch': torch.get_rng_state(),
+                                           'torch_cuda': torch.cuda.get_rng_state(self.device) if self.device.type == 'cuda' else None},
+                          'env_random_state': self.env.get_env_random_state()})
+        torch.save(state, path)
+
+    def load(self, path, training=True):
+        state = torch.load(path, map_location='cpu', weights_only=False)
+        self.agent.load_state_dict(state['agent'])
+        if training and 'total_steps' in state:
+            self.total_steps = state['total_steps']
+            self.obs[0].copy_(state['obs'].to(self.device))
+            torch.set_rng_state(state['random_state']['torch'])
+            if state['random_state'].get('torch_cuda') is not None and self.device.type == 'cuda':
+                torch.cuda.set_rng_state(state['random_state']['torch_cuda'], self.device)
+            self.env.set_env_random_state(state['env_random_state'])
+
     def episode_stats(self, reset=True):
         s = torch.stack([self.ep_count, self.ep_return_sum, self.ep_length_sum, self.ep_violation_sum])
         parallel.all_reduce_sum_(s)

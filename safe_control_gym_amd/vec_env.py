@@ -411,13 +411,15 @@ class HipVecEnv(VecEnv):
     def get_env_random_state(self):
         step, ep = self.get_counters()
         return [{'seed': self.seed_value, 'env_id_offset': self.env_id_offset, 'step': step, 'episode': ep,
-                 'workspace': self.workspace.cpu()}]
+                 'workspace': self.workspace.cpu(), 'ep_stats': self.ep_stats.cpu()}]
 
     def set_env_random_state(self, worker_random_states):
         st = worker_random_states[0]
         if st['seed'] != self.seed_value or st['env_id_offset'] != self.env_id_offset:
             raise ValueError('random state belongs to a different seed / env shard')
         self.workspace.copy_(st['workspace'].to(self.device))
+        if 'ep_stats' in st:
+            self.ep_stats.copy_(st['ep_stats'].to(self.device))
 
     # ------------------------------------------------------------------ attribute access
     def get_attr(self, attr_name, indices=None):
