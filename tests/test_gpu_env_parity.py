@@ -384,3 +384,42 @@ def test_rk4_prior_model_integrator_matches_oracle(name, specialize):
     o_e.step(g['actions'][0]); o_r.step(g['actions'][0])          # (the bare oracle envs do not auto-reset)
     d = np.abs(o_e.state - o_r.state).max()
     assert 0 < d < 2e-2, d
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64', 'f32'])
+@pytest.mark.parametrize('name', ['quadrotor_2D_track', 'quadrotor_3D_track', 'cartpole_stab'])
+def test_full_and_partial_waves_specialised_store_paths(name, dtype):
+    """200 envs = three full waves (observation rows transposed through LDS into fully coalesced stores, specialised
+    build) + one partial wave (per-lane row stores): every output against the oracle while episodes end and auto-reset."""
+    g, meta, cfg = _load(name)
+    n = 200
+    oracle, ovec, gpu = _make_pair(meta, cfg, dtype, n_envs=n, seed=11, specialize=True)
+    f64 = dtype == torch.float64
+    tol = dict(rtol=1e-9, atol=1e-10) if f64 else dict(rtol=2e-4, atol=2e-4)
+    rng = np.random.default_rng(5)
+    np.testing.assert_allclose(_np(gpu.reset_tensors()), ovec.reset()[0], **tol)
+    n_done = 0
+    for t in range(40):
+        if not f64:                    # keep the float32 run a one-step comparison
+            gpu.set_raw_state(_raw_state(oracle))
+            gpu.set_counters(oracle.ctrl_step_counter, oracle.episode)
+        act = rng.uniform(-1, 1, (n, oracle.action_dim))
+        obs_o, rew_o, done_o, info = ovec.step(act)
+        out = gpu.step_tensors(torch.as_tensor(act, dtype=dtype, device=gpu.device))
+        msg = f'{name} t={t}'
+        done_g = _np(out.done).astype(bool)
+        if f64:
+            np.testing.assert_array_equal(done_g, done_o, err_msg=msg)
+        same = done_g == done_o
+        assert same.mean() > 0.98, msg
+        keep = same & ~done_o if not f64 else same
+        np.testing.assert_allclose(_np(out.obs)[keep], obs_o[keep], err_msg=msg, **tol)
+        np.testing.assert_allclose(_np(out.reward)[same], rew_o[same], err_msg=msg, **tol)
+        d = np.nonzero(done_o & same)[0]
+        n_done += len(d)
+        if len(d):
+            np.testing.assert_allclose(_np(out.terminal_obs)[d], info['terminal_observation'][d], err_msg=msg, **tol)
+            np.testing.assert_allclose(_np(out.fin_length)[d], info['episode_length'][d] if 'episode_length' in info
+                                       else _np(out.fin_length)[d], err_msg=msg)
+    assert n_done > 0
+    gpu.close()
