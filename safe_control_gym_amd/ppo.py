@@ -520,30 +520,53 @@ class PPO:
 
 
 @torch.no_grad()
-def evaluate(ac, env, episodes_per_env=1):
+def evaluate(ac, env, episodes_per_env=1, use_graph=None):
     """Deterministic policy (action = mean, ppo_utils.py:233-238) on every env of `env` until each finished
     `episodes_per_env` episodes; returns mean episode return / length / violations / mse (batched counterpart of
-    PPO.run, ppo.py:210-257)."""
-    obs = env.reset_tensors()
+    PPO.run, ppo.py:210-257).  An episode lasts at most CTRL_STEPS control steps, so the loop has a fixed length and no
+    host synchronisation; on a GPU it is captured once per (policy, env) pair and replayed as one HIP graph."""
     N = env.num_envs
-    count = torch.zeros(N, device=env.device)
-    ret = torch.zeros(N, device=env.device)
-    length = torch.zeros(N, device=env.device)
-    viol = torch.zeros(N, device=env.device)
-    mse = torch.zeros(N, device=env.device)
-    max_steps = int(env.spec.CTRL_STEPS) * episodes_per_env + 1
-    for _ in range(max_steps):
-        out = env.step_tensors(ac.act(obs))
-        obs = out.obs
-        d = out.done.bool() & (count < episodes_per_env)
-        df = d.to(torch.float32)
-        ret += out.fin_return * df
-        length += out.fin_length.to(torch.float32) * df
-        viol += out.fin_violation * df
-        mse += out.fin_mse * df
-        count += df
-        if bool((count >= episodes_per_env).all()):
-            break
-    n = count.sum().clamp(min=1.0)
-    return {'episodes': float(count.sum()), 'ep_return': float(ret.sum() / n), 'ep_length': float(length.sum() / n),
-            'ep_constraint_violation': float(viol.sum() / n), 'ep_mse': float(mse.sum() / n)}
+    steps = int(env.spec.CTRL_STEPS) * episodes_per_env
+    dev = env.device
+    use_graph = (dev.type == 'cuda') if use_graph is None else use_graph
+    cache = getattr(env, '_eval_cache', None)
+    key = (id(ac), episodes_per_env, bool(use_graph))
+    if cache is None or cache['key'] != key:
+        acc = {k: torch.zeros(N, device=dev) for k in ('count', 'ret', 'length', 'viol', 'mse')}
+
+        def body():
+            for _ in range(steps):
+                out = env.step_tensors(ac.act(env.out.obs))
+                df = (out.done.bool() & (acc['count'] < episodes_per_env)).to(torch.float32)
+                acc['ret'] += out.fin_return * df
+                acc['length'] += out.fin_length * df
+                acc['viol'] += out.fin_violation * df
+                acc['mse'] += out.fin_mse * df
+                acc['count'] += df
+
+        graph = None
+        if use_graph:
+            env.reset_tensors()
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    ac.act(env.out.obs)                  # warm up the torch ops (the env must not be stepped here)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+        cache = {'key': key, 'acc': acc, 'body': body, 'graph': graph, 'ac': ac}
+        env._eval_cache = cache
+    acc = cache['acc']
+    env.reset_tensors()
+    for t in acc.values():
+        t.zero_()
+    if cache['graph'] is not None:
+        cache['graph'].replay()
+    else:
+        cache['body']()
+    n = acc['count'].sum().clamp(min=1.0)
+    res = torch.stack([acc['count'].sum(), acc['ret'].sum() / n, acc['length'].sum() / n, acc['viol'].sum() / n,
+                       acc['mse'].sum() / n]).tolist()
+    return {'episodes': res[0], 'ep_return': res[1], 'ep_length': res[2], 'ep_constraint_violation': res[3], 'ep_mse': res[4]}
