@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--generic', action='store_true', help='use libscg_hip.so (any config, parameters via LDS) instead of the config-specialised build')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU oracle baseline')
     ap.add_argument('--graph-len', type=int, default=1000, help='steps captured per HIP graph')
     return ap.parse_args()
@@ -118,7 +119,8 @@ def main():
     if os.environ.get('SCG_BENCH_OVERRIDE'):      # dev only: ablations of the task config
         cfg.update(json.loads(os.environ['SCG_BENCH_OVERRIDE']))
     N = args.envs
-    env = HipVecEnv(env_id, N, seed=1337, dtype=dtype, env_id_offset=rank * N, return_numpy=False, **cfg)
+    env = HipVecEnv(env_id, N, seed=1337, dtype=dtype, env_id_offset=rank * N, return_numpy=False,
+                    specialize=False if args.generic else 'auto', **cfg)
     nu = env.spec.nu
     # synthetic actions resident in HBM: a ring of pre-generated batches
     ring = 64

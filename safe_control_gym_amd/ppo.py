@@ -105,6 +105,10 @@ class PPOConfig:
     # names and defaults of controllers/ppo/ppo.yaml
     hidden_dim: int = 64
     activation: str = 'tanh'
+    norm_obs: bool = False
+    norm_reward: bool = False
+    clip_obs: float = 10.0
+    clip_reward: float = 10.0
     gamma: float = 0.99
     use_gae: bool = False
     gae_lambda: float = 0.95
@@ -369,7 +373,15 @@ class PPO:
                                         mse=None) for t in range(T)]
         self.total_steps = 0
         self._rollout_graph = None
-        self.obs[0].copy_(env.reset_tensors())
+        # running normalisers (ppo.py:71-76); with several ranks their moment all-reduce cannot sit inside a captured
+        # graph, so that combination collects eagerly
+        from safe_control_gym_amd.normalization import BaseNormalizer, MeanStdNormalizer, RewardStdNormalizer
+        self.obs_normalizer = MeanStdNormalizer((self.obs_dim,), self.device, clip=cfg.clip_obs) if cfg.norm_obs else BaseNormalizer()
+        self.reward_normalizer = (RewardStdNormalizer(cfg.gamma, self.device, clip=cfg.clip_reward) if cfg.norm_reward
+                                  else BaseNormalizer())
+        self._normalise = cfg.norm_obs or cfg.norm_reward
+        self._graph_rollout = self.agent.use_graphs and not (self._normalise and parallel.world_size() > 1)
+        self.obs[0].copy_(self.obs_normalizer(env.reset_tensors()))
         # finished-episode statistics (VecRecordEpisodeStatistics), accumulated on device
         self.ep_count = torch.zeros((), device=self.device)
         self.ep_return_sum = torch.zeros((), device=self.device)
@@ -384,6 +396,9 @@ class PPO:
             self.act[t], self.v[t], self.logp[t] = act, v, logp
             out, c_out = self._slots[t]
             env.step_tensors(self.act[t], out=out, c_out=c_out)
+            if self._normalise:         # ppo.py:270-271 (the terminal observation stays raw, as upstream)
+                self.obs[t + 1].copy_(self.obs_normalizer(self.obs[t + 1]))
+                self.rew[t].copy_(self.reward_normalizer(self.rew[t], self.done[t]))
             d = self.done[t].to(torch.float32)
             self.ep_count += d.sum()
             self.ep_return_sum += (out.fin_return * d).sum()
@@ -437,7 +452,7 @@ class PPO:
     # ---- returns / advantages / update (ppo.py:286-303)
     def train_step(self):
         t0 = time.perf_counter()
-        if self.agent.use_graphs:
+        if self._graph_rollout:
             if self._rollout_graph is None:       # capture records the launches without running them
                 self._rollout_graph, self._rollout_out = self._build_rollout_graph()
             self._rollout_graph.replay()
@@ -468,7 +483,13 @@ class PPO:
     def save(self, path, training=True):
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        state = {'agent': self.agent.state_dict()}
+        state = {'agent': self.agent.state_dict(), 'obs_normalizer': self.obs_normalizer.state_dict(),
+                 'reward_normalizer': self.reward_normalizer.state_dict()}
+        if getattr(self.reward_normalizer, 'ret', None) is not None:
+            state['reward_normalizer_ret'] = self.reward_normalizer.ret.cpu()
+        for name, nz in (('obs', self.obs_normalizer), ('reward', self.reward_normalizer)):
+            if hasattr(nz, 'rms'):
+                state[f'{name}_normalizer_count'] = float(nz.rms.count)
         if training:
             state.update({'total_steps': self.total_steps, 'obs': self.obs[0].cpu(),
                           'random_state': {'torch': torch.get_rng_state(),
@@ -479,6 +500,13 @@ class PPO:
     def load(self, path, training=True):
         state = torch.load(path, map_location='cpu', weights_only=False)
         self.agent.load_state_dict(state['agent'])
+        for name, nz in (('obs', self.obs_normalizer), ('reward', self.reward_normalizer)):
+            if state.get(f'{name}_normalizer'):
+                nz.load_state_dict(state[f'{name}_normalizer'])
+                if f'{name}_normalizer_count' in state:
+                    nz.rms.count.fill_(state[f'{name}_normalizer_count'])
+        if 'reward_normalizer_ret' in state and hasattr(self.reward_normalizer, 'rms'):
+            self.reward_normalizer.ret = state['reward_normalizer_ret'].to(self.device)
         if training and 'total_steps' in state:
             self.total_steps = state['total_steps']
             self.obs[0].copy_(state['obs'].to(self.device))
@@ -510,7 +538,7 @@ class PPO:
             res.update(self.episode_stats())
             res['wall_clock'] = time.perf_counter() - t_start
             if eval_env is not None and it % eval_every == 0:
-                res['eval_return'] = evaluate(self.agent.ac, eval_env)['ep_return']
+                res['eval_return'] = evaluate(self.agent.ac, eval_env, obs_normalizer=self.obs_normalizer if self.cfg.norm_obs else None)['ep_return']
             history.append(res)
             if log:
                 log(res)
@@ -520,7 +548,7 @@ class PPO:
 
 
 @torch.no_grad()
-def evaluate(ac, env, episodes_per_env=1, use_graph=None):
+def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None):
     """Deterministic policy (action = mean, ppo_utils.py:233-238) on every env of `env` until each finished
     `episodes_per_env` episodes; returns mean episode return / length / violations / mse (batched counterpart of
     PPO.run, ppo.py:210-257).  An episode lasts at most CTRL_STEPS control steps, so the loop has a fixed length and no
@@ -530,13 +558,22 @@ def evaluate(ac, env, episodes_per_env=1, use_graph=None):
     dev = env.device
     use_graph = (dev.type == 'cuda') if use_graph is None else use_graph
     cache = getattr(env, '_eval_cache', None)
-    key = (id(ac), episodes_per_env, bool(use_graph))
+    key = (id(ac), episodes_per_env, bool(use_graph), id(obs_normalizer))
     if cache is None or cache['key'] != key:
         acc = {k: torch.zeros(N, device=dev) for k in ('count', 'ret', 'length', 'viol', 'mse')}
 
+        def policy_obs():
+            if obs_normalizer is None:
+                return env.out.obs
+            frozen = obs_normalizer.read_only       # evaluation never updates the statistics (ppo.py:218)
+            obs_normalizer.set_read_only()
+            o = obs_normalizer(env.out.obs)
+            obs_normalizer.read_only = frozen
+            return o
+
         def body():
             for _ in range(steps):
-                out = env.step_tensors(ac.act(env.out.obs))
+                out = env.step_tensors(ac.act(policy_obs()))
                 df = (out.done.bool() & (acc['count'] < episodes_per_env)).to(torch.float32)
                 acc['ret'] += out.fin_return * df
                 acc['length'] += out.fin_length * df
@@ -551,7 +588,7 @@ def evaluate(ac, env, episodes_per_env=1, use_graph=None):
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 for _ in range(3):
-                    ac.act(env.out.obs)                  # warm up the torch ops (the env must not be stepped here)
+                    ac.act(policy_obs())                 # warm up the torch ops (the env must not be stepped here)
             torch.cuda.current_stream(dev).wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
