@@ -26,7 +26,8 @@ if ROOT not in sys.path:
 # SURVEY.md §8d algorithmic bytes per env-step (fp32): read state 24 + action 8 + counter 4;
 # write state 24 + obs 48 + reward 4 + done 1 + flags 1 (trunc+violation+oob packed; survey counts 1+1)
 # + counter 4 + c_values 64 + mse 4  => 187 B with the survey's accounting.
-ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'quadrotor_3D_track': 363}
+ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'quadrotor_3D_track': 363,
+                           'quadrotor_3D_track_disturbed': 379}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
