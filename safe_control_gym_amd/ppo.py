@@ -410,11 +410,20 @@ class PPO:
         self.total_steps += self.T * self.N * parallel.world_size()
 
     @torch.no_grad()
-    def _returns_body(self, dense):
+    def _returns_body(self, dense, critic=None, rew_buf=None, v_buf=None):
         """Bootstrap values, returns, advantages (not yet normalised) and the advantage moments.  dense=True evaluates
         the critic on every terminal-observation slot (static shapes, HIP-graph capturable) instead of gathering the
-        truncated ones; the values used are the same."""
-        cfg, ac = self.cfg, self.agent.ac
+        truncated ones; the values used are the same.  critic / rew_buf / v_buf: another agent's view of the same
+        rollout (RARL's adversary)."""
+        cfg = self.cfg
+        critic = critic or self.agent.ac.critic
+        rew_buf = self.rew if rew_buf is None else rew_buf
+        v_buf = self.v if v_buf is None else v_buf
+
+        class _AC:           # (keeps the body below identical for both callers)
+            pass
+        ac = _AC()
+        ac.critic = critic
         last_val = ac.critic(self.obs[self.T]).squeeze(-1)
         mask = 1.0 - self.done.to(torch.float32)
         # time truncation is not termination: bootstrap with the critic's value of the terminal observation
@@ -423,12 +432,12 @@ class PPO:
             tv = ac.critic(self.term_obs.reshape(self.T * self.N, self.obs_dim)).reshape(self.T, self.N)
             terminal_v = torch.where(trunc, tv, torch.zeros_like(tv))
         else:
-            terminal_v = torch.zeros_like(self.rew)
+            terminal_v = torch.zeros_like(rew_buf)
             idx = trunc.nonzero(as_tuple=False)
             if idx.numel():
                 terminal_v[idx[:, 0], idx[:, 1]] = ac.critic(self.term_obs[idx[:, 0], idx[:, 1]]).squeeze(-1)
-        rew = self.rew.clone()
-        ret, adv = self._gae(rew, self.v, mask, terminal_v, last_val, cfg.gamma, cfg.gae_lambda, cfg.use_gae)
+        rew = rew_buf.clone()
+        ret, adv = self._gae(rew, v_buf, mask, terminal_v, last_val, cfg.gamma, cfg.gae_lambda, cfg.use_gae)
         moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])
         return ret, adv, moments
 
@@ -606,4 +615,28 @@ def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None):
     n = acc['count'].sum().clamp(min=1.0)
     res = torch.stack([acc['count'].sum(), acc['ret'].sum() / n, acc['length'].sum() / n, acc['viol'].sum() / n,
                        acc['mse'].sum() / n]).tolist()
-    return {'episodes': res[0], 'ep_return': res[1], 'ep_length': res[2], 'ep_constraint_violation': res[3], 'ep_mse': res[4]}
+    out = {'episodes': res[0], 'ep_return': res[1], 'ep_length': res[2], 'ep_constraint_violation': res[3], 'ep_mse': res[4]}
+    if episodes_per_env == 1:
+        out['metrics'] = episode_metrics(acc['ret'], acc['length'], acc['viol'], acc['mse'], acc['count'] > 0)
+    return out
+
+
+@torch.no_grad()
+def episode_metrics(ep_return, ep_length, ep_violation_steps, ep_mse_sum, valid=None):
+    """MetricExtractor.compute_metrics (experiments/base_experiment.py:392-421) from per-episode totals on the device:
+    rmse = sqrt(mean of the step mse), failure = any violation in the episode, CVaR = mean of the worst half of the rmse
+    (math_and_models/metrics/performance_metrics.py:6-31, alpha 0.5, upper range)."""
+    if valid is not None:
+        ep_return, ep_length, ep_violation_steps, ep_mse_sum = (t[valid] for t in (ep_return, ep_length, ep_violation_steps, ep_mse_sum))
+    n = ep_return.numel()
+    if n == 0:
+        return {}
+    rmse = torch.sqrt(ep_mse_sum.to(torch.float64) / ep_length.to(torch.float64).clamp(min=1.0))
+    k = int(0.5 * n)
+    worst = torch.sort(rmse).values[-k:].mean() if k > 0 else torch.sort(rmse).values.mean()     # [-0:] is the whole array upstream
+    v = ep_violation_steps.to(torch.float64)
+    vals = torch.stack([ep_length.to(torch.float64).mean(), ep_return.to(torch.float64).mean(), rmse.mean(),
+                        rmse.std(unbiased=False), worst, (v > 0).to(torch.float64).mean(), v.mean(), v.std(unbiased=False)]).tolist()
+    keys = ('average_length', 'average_return', 'average_rmse', 'rmse_std', 'worst_case_rmse_at_0.5', 'failure_rate',
+            'average_constraint_violation', 'constraint_violation_std')
+    return dict(zip(keys, vals))

@@ -193,3 +193,32 @@ def test_ppo_with_running_normalisers_graphed_and_eager():
         env.close()
     # positions dominate the first moments; both paths saw statistically identical data (different action noise streams)
     assert np.allclose(stats[0][[0, 2]], stats[1][[0, 2]], atol=0.2)
+
+
+def test_rarl_alternates_protagonist_and_adversary_on_the_adversary_channel():
+    """rarl.py:267-281,349-428: both policies act every step, the adversary through set_adversary_control into the
+    kernel's dynamics channel; protagonist learns from +reward, adversary from -reward."""
+    from safe_control_gym_amd.ppo import PPOConfig
+    from safe_control_gym_amd.rarl import RARL
+    env = _env('quadrotor_2D_track', 512, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05)
+    cfg = PPOConfig(hidden_dim=16, use_gae=True, opt_epochs=1, mini_batch_size=2048, rollout_steps=8, actor_lr=1e-3, critic_lr=1e-3)
+    r = RARL(env, cfg, seed=1, agent_iterations=2, adversary_iterations=1)
+    w_ag = {k: v.clone() for k, v in r.agent.ac.state_dict().items()}
+    w_ad = {k: v.clone() for k, v in r.adversary.ac.state_dict().items()}
+    res = r.train_step()
+    assert res['step'] == 3 * 8 * 512 and 'value_loss' in res and 'value_loss_adv' in res
+    assert r.act_adv.shape == (8, 512, 2) and float(r.act_adv.abs().sum()) > 0
+    assert any(not torch.equal(v, w_ag[k]) for k, v in r.agent.ac.state_dict().items())
+    assert any(not torch.equal(v, w_ad[k]) for k, v in r.adversary.ac.state_dict().items())
+    # the adversary really reaches the dynamics: the same seed without it gives a different rollout
+    env2 = _env('quadrotor_2D_track', 512, adversary_disturbance='dynamics', adversary_disturbance_scale=0.0)
+    r2 = RARL(env2, PPOConfig(hidden_dim=16, use_gae=True, opt_epochs=1, mini_batch_size=2048, rollout_steps=8), seed=1)
+    r2.collect()
+    env3 = _env('quadrotor_2D_track', 512, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05)
+    r3 = RARL(env3, PPOConfig(hidden_dim=16, use_gae=True, opt_epochs=1, mini_batch_size=2048, rollout_steps=8), seed=1)
+    r3.collect()
+    assert not torch.allclose(r2.obs[1], r3.obs[1])
+    for e in (env, env2, env3):
+        e.close()
+    with pytest.raises(ValueError):
+        RARL(_env('quadrotor_2D_track', 64), cfg)

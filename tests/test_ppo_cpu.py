@@ -156,3 +156,24 @@ def test_device_normalizers_match_the_reference_restatement():
     o2 = dev.MeanStdNormalizer((5,))
     o2.load_state_dict(sd)
     assert torch.equal(o2.rms.mean, o_dev.rms.mean) and torch.equal(o2.rms.var, o_dev.rms.var)
+
+
+def test_episode_metrics_follow_the_metric_extractor_definitions():
+    """ppo.episode_metrics vs a direct restatement of experiments/base_experiment.py:392-421 on per-step data."""
+    import numpy as np
+    import torch
+    from safe_control_gym_amd.ppo import episode_metrics
+    rng = np.random.default_rng(2)
+    lengths = rng.integers(5, 40, 9)
+    mse = [rng.random(n) for n in lengths]
+    viol = [(rng.random(n) < 0.1).astype(float) for n in lengths]
+    rew = [rng.random(n) for n in lengths]
+    rmse = np.array([np.sqrt(np.mean(m)) for m in mse])
+    ref = {'average_length': lengths.mean(), 'average_return': np.mean([r.sum() for r in rew]), 'average_rmse': rmse.mean(),
+           'rmse_std': rmse.std(), 'worst_case_rmse_at_0.5': np.sort(rmse)[-int(0.5 * 9):].mean(),
+           'failure_rate': np.mean([float(any(v)) for v in viol]), 'average_constraint_violation': np.mean([v.sum() for v in viol]),
+           'constraint_violation_std': np.std([v.sum() for v in viol])}
+    got = episode_metrics(torch.tensor([r.sum() for r in rew]), torch.tensor(lengths, dtype=torch.float32),
+                          torch.tensor([v.sum() for v in viol]), torch.tensor([m.sum() for m in mse]))
+    for k, v in ref.items():
+        assert abs(got[k] - v) < 1e-6 * max(1.0, abs(v)), (k, got[k], v)
