@@ -36,7 +36,7 @@ def main():
     ap.add_argument('--max-seconds', type=float, default=120.0)
     ap.add_argument('--target-return', type=float, default=236.0)
     ap.add_argument('--eval-envs', type=int, default=256)
-    ap.add_argument('--eval-every', type=int, default=4)
+    ap.add_argument('--eval-every', type=int, default=1)
     ap.add_argument('--seed', type=int, default=2)
     ap.add_argument('--respect-yaml-init', action='store_true',
                     help='honour init_state_randomization_info of the YAML (the reference class ignores it)')
