@@ -460,11 +460,16 @@ struct EnvOps {
         }
     }
 
-    __device__ static __forceinline__ void store(const PV<T>& P, int i, const E& e, bool params_dirty) {
+    __device__ static __forceinline__ void store_state(const PV<T>& P, int i, const E& e) {
         const size_t N = (size_t)P.i.num_envs;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
 #pragma unroll
         for (int k = 0; k < D::NS; ++k) slot_in<T>(ws, P.i.state_off, i).store(e.s[k], k * N);
+    }
+    __device__ static __forceinline__ void store(const PV<T>& P, int i, const E& e, bool params_dirty, bool with_state = true) {
+        const size_t N = (size_t)P.i.num_envs;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
+        if (with_state) store_state(P, i, e);
         if (P.c.per_env_params && params_dirty) {
 #pragma unroll
             for (int k = 0; k < D::NP; ++k) slot_in<T>(ws, P.i.param_off, i).store(e.par[k], k * N);

@@ -6,8 +6,9 @@ SPEC=safe_control_gym_amd/spec
 case "$1" in
 build)
   mkdir -p $SPEC/exp
-  for v in BASE UNIFORM_GOAL NO_RESET NO_CVAL NO_OBS "NO_CVAL -DSCG_EXP_NO_OBS" "NO_CVAL -DSCG_EXP_NO_OBS -DSCG_EXP_NO_RESET -DSCG_EXP_UNIFORM_GOAL"; do
-    name=$(echo "$v" | sed 's/ -DSCG_EXP_/+/g')
+  rm -f $SPEC/exp/*.so
+  for v in BASE NO_RESET NO_CVAL NO_OBS "BASE -DSCG_BLOCK=128" "BASE -DSCG_BLOCK=256" ${EXTRA_VARIANTS}; do
+    name=$(echo "$v" | sed 's/ -DSCG_EXP_/+/g; s/ -DSCG_/+/g; s/=/_/g')
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -DSCG_SPEC -DSCG_EXP_$v -include $SPEC/scg_spec_$H.h \
       -o "$SPEC/exp/$name.so" safe_control_gym_amd/csrc/scg_kernels.hip &
   done; wait; ls $SPEC/exp ;;
