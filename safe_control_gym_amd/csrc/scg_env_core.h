@@ -962,6 +962,9 @@ SCG_BOX_UNROLL
                         const f2 fm = {fxm, fzm};
                         const f2 c1 = {(float)(1.0 / 120), (float)(-1.0 / 720)}, c0 = {(float)(-1.0 / 6), (float)(1.0 / 24)};
                         const f2 cone = {1.0f, -0.5f};
+#ifdef SCG_SPEC
+#pragma unroll          // constant trip count: straight-line code, no loop branches (a taken branch costs ~25 clocks)
+#endif
                         for (; k0 < P.c.substeps; ++k0) {
                             w = m_clamp(w + dwk, -vmax, vmax);
                             const float d = h * w, d2 = d * d;

@@ -7,7 +7,7 @@ case "$1" in
 build)
   mkdir -p $SPEC/exp
   rm -f $SPEC/exp/*.so
-  for v in BASE NO_RESET NO_CVAL NO_OBS "BASE -DSCG_BLOCK=128" "BASE -DSCG_BLOCK=256" ${EXTRA_VARIANTS}; do
+  for v in BASE NO_RESET NO_CVAL NO_OBS ${EXTRA_VARIANTS}; do
     name=$(echo "$v" | sed 's/ -DSCG_EXP_/+/g; s/ -DSCG_/+/g; s/=/_/g')
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -DSCG_SPEC -DSCG_EXP_$v -include $SPEC/scg_spec_$H.h \
       -o "$SPEC/exp/$name.so" safe_control_gym_amd/csrc/scg_kernels.hip &
