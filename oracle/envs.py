@@ -31,9 +31,11 @@ from oracle.rng import (CH_ACTION, CH_DYNAMICS, CH_OBSERVATION, CH_RESET, NumpyE
 from oracle.trajectory import generate_trajectory, transform_trajectory
 
 CHANNEL_OF_MODE = {'action': CH_ACTION, 'dynamics': CH_DYNAMICS, 'observation': CH_OBSERVATION}
-# Philox reset-draw groups (must match scg_rng.h): item = group; variable j of the group uses block
-# j // 2 and the word pair (2*(j%2), 2*(j%2)+1).  j = INIT_STATE_LABELS index | inertial parameter index |
-# 4 * (channel - 1) + list index for disturbance offsets.
+# Philox reset-draw groups (must match scg_rng.h): item = group; j = INIT_STATE_LABELS index | inertial parameter
+# index | 4 * (channel - 1) + list index for disturbance offsets.  Variable j of a group whose randomised variables all
+# need ONE word (uniform / choice) uses word j % 4 of block j // 4 ("compact"); as soon as one of them is a normal draw
+# (two words) every variable of the group uses block j // 2 and the word pair (2*(j%2), 2*(j%2)+1); disturbance offsets
+# always use the pair layout.
 GROUP_INIT, GROUP_INERTIAL, GROUP_DISTURB = 0, 1, 2
 
 
@@ -68,15 +70,15 @@ class Draws:
         tag = make_tag(CH_RESET, GROUP_DISTURB, j // 2)
         return self.rng.integer_below(idx, self.env.episode, 0, tag, bound, word=2 * (j % 2))
 
-    def reset_scalar(self, idx, group, j, spec):
+    def reset_scalar(self, idx, group, j, spec, compact=False):
         """One draw per env in ``idx`` from a {distrib, args, **kwargs} spec (variable j of ``group``)."""
         spec = copy.deepcopy(spec)
         distrib = spec.pop('distrib')
         d_args = spec.pop('args', [])
         if self.rng.kind == 'numpy':
             return np.array([getattr(self.rng.gens[i], distrib)(*d_args, **spec) for i in idx], dtype=np.float64)
-        tag = make_tag(CH_RESET, group, j // 2)
-        w0 = 2 * (j % 2)
+        tag = make_tag(CH_RESET, group, j // 4 if compact else j // 2)
+        w0 = j % 4 if compact else 2 * (j % 2)
         if distrib == 'uniform':
             low = d_args[0] if len(d_args) > 0 else spec.get('low', 0.0)
             high = d_args[1] if len(d_args) > 1 else spec.get('high', 1.0)
@@ -217,10 +219,11 @@ class OracleBenchmarkEnv:
     # benchmark_env.py:237-268 — additive randomisation, keys in ``original_values`` order.
     def _randomize_values_by_info(self, idx, names, base_values, info, group):
         out = {}
+        compact = all(info[name]['distrib'] != 'normal' for name in names if name in info)
         for j, name in enumerate(names):
             val = np.full(len(idx), float(base_values[name]))
             if name in info:
-                val = val + self.draws.reset_scalar(idx, group, j, info[name])
+                val = val + self.draws.reset_scalar(idx, group, j, info[name], compact)
             out[name] = val
         return out
 

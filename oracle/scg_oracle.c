@@ -124,11 +124,14 @@ static void reset_env(const oc_cfg* c, int i, double* s, int32_t* step, uint32_t
     double iv[OC_MAX_STATE];
     for (int k = 0; k < c->nx; ++k) iv[k] = c->init_state[k];
     if (c->randomized_init) {
-        for (int b = 0; b < c->nx / 2; ++b) {
+        /* uniform draws only: the compact layout of scg_rng.h (variable j = word j % 4 of block j / 4) */
+        for (int b = 0; b < (c->nx + 3) / 4; ++b) {
             uint32_t ctr[4] = {(uint32_t)(c->env_id_offset + i), *episode, 0u, (0u << 16) | (0u << 8) | (uint32_t)b};
             philox(ctr, (uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32));
-            if (c->init_rand[2 * b]) iv[2 * b] += c->init_lo[2 * b] + (c->init_hi[2 * b] - c->init_lo[2 * b]) * u01(ctr[0]);
-            if (c->init_rand[2 * b + 1]) iv[2 * b + 1] += c->init_lo[2 * b + 1] + (c->init_hi[2 * b + 1] - c->init_lo[2 * b + 1]) * u01(ctr[2]);
+            for (int k = 0; k < 4 && 4 * b + k < c->nx; ++k) {
+                const int j = 4 * b + k;
+                if (c->init_rand[j]) iv[j] += c->init_lo[j] + (c->init_hi[j] - c->init_lo[j]) * u01(ctr[k]);
+            }
         }
     }
     if (c->system == 3) {

@@ -305,7 +305,8 @@ struct Env {
 };
 
 // ------------------------------------------------------------------ random helpers
-// Reset-time draws: variable j of group g uses Philox block j/2 of item g, words 2*(j&1) and 2*(j&1)+1.
+// Reset-time draws: variable j of group g uses Philox block j/2 of item g, words 2*(j&1) and 2*(j&1)+1 — or, when no
+// variable of the group is a normal draw, word j%4 of block j/4 (scg_rng.h).
 template <typename T>
 __device__ __forceinline__ T rand_value(const HotRand<T>& r, const DevRand<T>& full, uint32_t w0, uint32_t w1) {
     if (r.kind == SCG_RAND_UNIFORM) return r.p0 + (r.p1 - r.p0) * u01<T>(w0);
@@ -520,7 +521,17 @@ struct EnvOps {
                 }
             }
         }
-        if (P.c.per_env_params) {
+        if (P.c.per_env_params && P.c.param_compact) {
+            // one-word distributions only: four variables per Philox block (see scg_rng.h)
+#pragma unroll
+            for (int b = 0; b < (D::NP + 3) / 4; ++b) {
+                U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_PARAM, (uint32_t)b));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * b + k < D::NP)
+                        e.par[4 * b + k] = P.c.base_param[4 * b + k] + rand_value(P.c.param_rand[4 * b + k], P.i.cold->param_rand[4 * b + k], u4_get(w, k), 0u);
+            }
+        } else if (P.c.per_env_params) {
 #pragma unroll
             for (int b = 0; b < (D::NP + 1) / 2; ++b) {
                 U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_PARAM, (uint32_t)b));
@@ -531,7 +542,16 @@ struct EnvOps {
         T iv[D::NX];
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) iv[k] = P.c.init_state[k];
-        if (P.c.randomized_init) {
+        if (P.c.randomized_init && P.c.init_compact) {
+#pragma unroll
+            for (int b = 0; b < (D::NX + 3) / 4; ++b) {
+                U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * b + k < D::NX)
+                        iv[4 * b + k] += rand_value(P.c.init_rand[4 * b + k], P.i.cold->init_rand[4 * b + k], u4_get(w, k), 0u);
+            }
+        } else if (P.c.randomized_init) {
 #pragma unroll
             for (int b = 0; b < D::NX / 2; ++b) {
                 U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));

@@ -255,6 +255,10 @@ static void build_cfg(const scg_config& c, CfgParams<double>& h) {
     h.info_goal_reached = c.info_goal_reached;
     h.goal_in_lds = (size_t)c.goal_rows * nx * elem_size(c.dtype) <= LDS_GOAL_LIMIT;
     h.per_env_params = c.randomized_inertial_prop; h.randomized_init = c.randomized_init;
+    // compact Philox word layout (scg_rng.h) for a group without two-word (normal) draws
+    h.init_compact = 1; h.param_compact = 1;
+    for (int k = 0; k < SCG_MAX_STATE; ++k) if (c.init_rand[k].kind == SCG_RAND_NORMAL) h.init_compact = 0;
+    for (int k = 0; k < SCG_MAX_PARAM; ++k) if (c.param_rand[k].kind == SCG_RAND_NORMAL) h.param_compact = 0;
     h.auto_reset = c.auto_reset; h.adversary_channel = c.adversary_channel;
     h.n_con_rows = c.n_con_rows; h.n_state_con_rows = c.n_state_con_rows;
     for (int k = 0; k < 3; ++k) h.n_dist[k] = c.n_dist[k];

@@ -112,7 +112,7 @@ struct HotRand {
     X(rew_exponential) X(done_on_oob) X(done_on_violation) X(use_penalty) X(obs_wrap_angle)            \
     X(normalized_action) X(info_goal_reached) X(goal_in_lds) X(per_env_params) X(randomized_init)      \
     X(auto_reset) X(adversary_channel) X(n_con_rows) X(n_state_con_rows) X(n_generic_rows)             \
-    X(n_box_rows) X(n_box_state_rows) X(integrator)
+    X(n_box_rows) X(n_box_state_rows) X(integrator) X(init_compact) X(param_compact)
 #define SCG_CFG_INT_ARRAYS(X) X(n_dist, 3)
 #define SCG_CFG_T_FIELDS(X)                                                                            \
     X(box_round) X(box_inv_round) X(pyb_dt) X(goal_tolerance) X(constraint_penalty) X(x_threshold)     \

@@ -6,8 +6,11 @@
 //   tag     = (channel << 16) | (item << 8) | block
 //   channel: 0 reset, 1 action, 2 dynamics, 3 observation, 4 random-action
 //   reset draws (channel 0, step 0): item = group (0 initial state, 1 inertial parameters, 2 disturbance
-//                offsets); variable j of a group uses block j/2 and the word pair (2*(j&1), 2*(j&1)+1):
-//                uniform / choice / integer draws consume the first word, normal draws both.
+//                offsets).  Pair layout: variable j of a group uses block j/2 and the word pair (2*(j&1), 2*(j&1)+1):
+//                uniform / choice / integer draws consume the first word, normal draws both.  Compact layout, used
+//                for groups 0 and 1 when none of the group's randomised variables is a normal draw: variable j uses
+//                word j%4 of block j/4 (a Philox block costs ~20 quarter-rate 32x32 multiplies; the auto-reset path
+//                of the step kernel is its Philox blocks).
 //                j = INIT_STATE_LABELS index | inertial parameter index | 4 * scg_channel + list index
 //   u01(word)    = ((word >> 8) + 0.5) * 2^-24     (exact in fp32)
 //   normal(w0,w1)= sqrt(-2 ln u01(w0)) * cos(2 pi u01(w1))

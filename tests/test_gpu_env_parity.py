@@ -423,3 +423,33 @@ def test_full_and_partial_waves_specialised_store_paths(name, dtype):
                                        else _np(out.fin_length)[d], err_msg=msg)
     assert n_done > 0
     gpu.close()
+
+
+@pytest.mark.parametrize('with_normal', [False, True], ids=['compact-words', 'pair-words'])
+def test_reset_draw_word_layouts(with_normal):
+    """Philox addressing of the reset draws (scg_rng.h): four one-word variables per block when no variable of the group is
+    a normal draw, otherwise two variables per block — kernels and oracle must pick the same layout."""
+    from oracle.envs import make_oracle_env, make_rng
+    from oracle.vec import OracleVecEnv
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    info = {'init_x': {'distrib': 'uniform', 'low': -1.0, 'high': 1.0},
+            'init_z': {'distrib': 'choice', 'a': [0.8, 1.0, 1.2]},
+            'init_theta': {'distrib': 'uniform', 'low': -0.1, 'high': 0.1},
+            'init_theta_dot': {'distrib': 'uniform', 'low': -0.5, 'high': 0.5}}
+    if with_normal:
+        info['init_x_dot'] = {'distrib': 'normal', 'loc': 0.0, 'scale': 0.3}
+    prop = {'M': {'distrib': 'uniform', 'low': -0.002, 'high': 0.002}, 'Iyy': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}}
+    if with_normal:
+        prop['Iyy'] = {'distrib': 'normal', 'loc': 0.0, 'scale': 3e-7}
+    g, meta, cfg = _load('quadrotor_2D_track')
+    cfg = dict(cfg, respect_randomization_info=True, init_state_randomization_info=info, randomized_inertial_prop=True,
+               inertial_prop_randomization_info=prop)
+    n = 96
+    for specialize in (False, True):
+        oracle = make_oracle_env('quadrotor', n, make_rng('philox', n, 9), **cfg)
+        gpu = HipVecEnv('quadrotor', n, seed=9, dtype=torch.float64, return_numpy=False, specialize=specialize, **cfg)
+        obs_o, _ = OracleVecEnv(oracle).reset()
+        np.testing.assert_allclose(_np(gpu.reset_tensors()), obs_o, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(gpu.get_params(), _params(oracle), rtol=1e-12)
+        assert len(np.unique(np.round(oracle.state[:, 2], 6))) == 3           # the choice draw
+        gpu.close()
