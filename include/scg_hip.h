@@ -260,6 +260,16 @@ int scg_set_seed(scg_env* env, uint64_t seed);
 int scg_set_counters(scg_env* env, const int32_t* h_step, const uint32_t* h_episode, int first_env, int n, void* stream);
 int scg_get_counters(scg_env* env, int32_t* h_step, uint32_t* h_episode, int first_env, int n, void* stream);
 
+/* Batched prior-model services for model-based controllers (math_and_models/symbolic_systems.py:68-121 fc_func / df_func /
+ * fd_func; controllers/lqr/lqr_utils.py, controllers/mpc/mpc_utils.py:42-64 rk_discrete): for n samples (x [n][state_dim],
+ * u [n][action_dim], env dtype, device pointers) writes, where the pointer is not NULL, f(x,u) [n][nx], the continuous-time
+ * Jacobians A = df/dx [n][nx][nx] and B = df/du [n][nx][nu] (central differences with step eps, as df_func does
+ * numerically here since CasADi is not available) and the state after one RK4 step of the control period [n][nx].
+ * Equations and inertial parameters: the env's config (prior-model arm L/sqrt(2) when integrator = SCG_INT_RK4 or
+ * engine_arm = symbolic). */
+int scg_prior_model(scg_env* env, const void* d_x, const void* d_u, int n, double eps, void* d_f, void* d_A, void* d_B,
+                    void* d_xnext, void* stream);
+
 /* Replaces controllers/ppo/ppo_utils.py:374-400 compute_returns_and_advantages on [T][N] buffers:
  *   rew += gamma * terminal_v;  ret_t = rew_t + gamma m_t ret_{t+1};
  *   GAE: adv_t = delta_t + gamma lambda m_t adv_{t+1}  else adv_t = ret_t - v_t.

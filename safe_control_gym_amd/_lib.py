@@ -95,7 +95,7 @@ class RolloutOut(C.Structure):
 
 EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step',
            'scg_rollout_random', 'scg_set_state', 'scg_get_state', 'scg_set_params', 'scg_get_params',
-           'scg_set_counters', 'scg_get_counters', 'scg_set_seed', 'scg_gae', 'scg_last_error', 'scg_abi_version',
+           'scg_set_counters', 'scg_get_counters', 'scg_set_seed', 'scg_gae', 'scg_prior_model', 'scg_last_error', 'scg_abi_version',
            'scg_sizeof_config', 'scg_sizeof_step_out', 'scg_spec_source', 'scg_spec_hash']
 
 
@@ -154,6 +154,7 @@ def _bind(path):
         fn.argtypes = [c_vp, C.POINTER(c_f64), C.c_int, C.c_int, c_vp]
     L.scg_set_counters.argtypes = [c_vp, C.POINTER(c_i32), C.POINTER(C.c_uint32), C.c_int, C.c_int, c_vp]
     L.scg_get_counters.argtypes = [c_vp, C.POINTER(c_i32), C.POINTER(C.c_uint32), C.c_int, C.c_int, c_vp]
+    L.scg_prior_model.argtypes = [c_vp, c_vp, c_vp, C.c_int, C.c_double, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.scg_gae.argtypes = [C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int,
                           c_f64, c_f64, C.c_int, c_vp]
     L.scg_spec_source.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(c_u64)]

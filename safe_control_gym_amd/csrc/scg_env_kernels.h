@@ -460,4 +460,78 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
     Ops::store(P, i, e, dirty);
 }
 
+// Batched prior-model services (symbolic_systems.py:68-121: fc_func, df_func, fd_func) for model-based controllers that
+// linearise / roll out the prior at many points (LQR/iLQR gains along a trajectory, GP-MPC data collection): one thread
+// per sample (x, u) evaluates f(x, u), the Jacobians df/dx, df/du by central differences of the SAME device function
+// the RK4 integrator mode uses (step eps), and one RK4 step of the control period.  Inertial parameters: the config's.
+// Layouts: x [n][nx], u [n][nu], f [n][nx], A [n][nx][nx], B [n][nx][nu], xnext [n][nx] (row-major, any may be null).
+template <int SYS, typename T, bool DIST>
+__global__ __launch_bounds__(256) void prior_model_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I, int n,
+                                                           const T* __restrict__ xs, const T* __restrict__ us, T eps,
+                                                           T* __restrict__ f_out, T* __restrict__ A_out, T* __restrict__ B_out,
+                                                           T* __restrict__ xnext_out) {
+    using Ops = EnvOps<SYS, T, DIST>;
+    using D = Dims<SYS>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#ifdef SCG_SPEC
+    constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();
+    const PV<T> P{kcfg, I};
+#else
+    const PV<T> P{*Cg, I};              // service kernel: parameters straight from global memory
+#endif
+    typename Ops::E e;
+#pragma unroll
+    for (int k = 0; k < D::NP; ++k) e.par[k] = P.c.base_param[k];
+    T x[D::NX], u[D::NU], f0[D::NX];
+#pragma unroll
+    for (int k = 0; k < D::NX; ++k) x[k] = xs[(size_t)i * D::NX + k];
+#pragma unroll
+    for (int k = 0; k < D::NU; ++k) u[k] = us[(size_t)i * D::NU + k];
+    Ops::sym_f(P, e, x, u, f0);
+    if (f_out) {
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) f_out[(size_t)i * D::NX + k] = f0[k];
+    }
+    const T inv2 = (T)0.5 / eps;
+    if (A_out) {
+        for (int c = 0; c < D::NX; ++c) {
+            T xp[D::NX], xm[D::NX], fp[D::NX], fm[D::NX];
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) { xp[k] = x[k] + (k == c ? eps : (T)0); xm[k] = x[k] - (k == c ? eps : (T)0); }
+            Ops::sym_f(P, e, xp, u, fp);
+            Ops::sym_f(P, e, xm, u, fm);
+#pragma unroll
+            for (int r = 0; r < D::NX; ++r) A_out[((size_t)i * D::NX + r) * D::NX + c] = (fp[r] - fm[r]) * inv2;
+        }
+    }
+    if (B_out) {
+        for (int c = 0; c < D::NU; ++c) {
+            T up[D::NU], um[D::NU], fp[D::NX], fm[D::NX];
+#pragma unroll
+            for (int k = 0; k < D::NU; ++k) { up[k] = u[k] + (k == c ? eps : (T)0); um[k] = u[k] - (k == c ? eps : (T)0); }
+            Ops::sym_f(P, e, x, up, fp);
+            Ops::sym_f(P, e, x, um, fm);
+#pragma unroll
+            for (int r = 0; r < D::NX; ++r) B_out[((size_t)i * D::NX + r) * D::NU + c] = (fp[r] - fm[r]) * inv2;
+        }
+    }
+    if (xnext_out) {
+        const T h = P.c.ctrl_dt;
+        T k1[D::NX], k2[D::NX], k3[D::NX], k4[D::NX], y[D::NX];
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) { k1[k] = f0[k]; y[k] = x[k] + (T)0.5 * h * k1[k]; }
+        Ops::sym_f(P, e, y, u, k2);
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) y[k] = x[k] + (T)0.5 * h * k2[k];
+        Ops::sym_f(P, e, y, u, k3);
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k) y[k] = x[k] + h * k3[k];
+        Ops::sym_f(P, e, y, u, k4);
+#pragma unroll
+        for (int k = 0; k < D::NX; ++k)
+            xnext_out[(size_t)i * D::NX + k] = x[k] + h * (T)(1.0 / 6.0) * (k1[k] + (T)2 * k2[k] + (T)2 * k3[k] + k4[k]);
+    }
+}
+
 }  // namespace scg

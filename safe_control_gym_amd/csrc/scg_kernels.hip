@@ -262,7 +262,7 @@ static void build_cfg(const scg_config& c, CfgParams<double>& h) {
     h.auto_reset = c.auto_reset; h.adversary_channel = c.adversary_channel;
     h.n_con_rows = c.n_con_rows; h.n_state_con_rows = c.n_state_con_rows;
     for (int k = 0; k < 3; ++k) h.n_dist[k] = c.n_dist[k];
-    h.pyb_dt = c.pyb_dt; h.goal_tolerance = c.goal_tolerance; h.constraint_penalty = c.constraint_penalty;
+    h.pyb_dt = c.pyb_dt; h.ctrl_dt = c.ctrl_dt; h.goal_tolerance = c.goal_tolerance; h.constraint_penalty = c.constraint_penalty;
     h.x_threshold = c.x_threshold; h.theta_threshold = c.theta_threshold; h.act_scale = c.act_scale;
     h.hover_thrust = c.hover_thrust; h.kf = c.kf; h.km = c.km; h.pwm2rpm_scale = c.pwm2rpm_scale;
     h.pwm2rpm_const = c.pwm2rpm_const; h.pwm_min = c.pwm_min; h.pwm_max = c.pwm_max; h.gravity = c.gravity;
@@ -748,6 +748,27 @@ static int launch_gae(void* rew, const void* v, const void* mask, const void* te
     }
     HIP_TRY(hipGetLastError());
     return SCG_OK;
+}
+
+template <typename T>
+static int launch_prior(scg_env* env, const void* x, const void* u, int n, double eps, void* f, void* A, void* B, void* xn,
+                        hipStream_t st) {
+    const int grid = (n + 255) / 256;
+    const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
+    const InstParams<T> I = inst_of<T>(env);
+    DISPATCH_SYS(env, T, (prior_model_kernel<S, T, DD><<<dim3(grid), dim3(256), 0, st>>>(C, I, n, (const T*)x, (const T*)u, (T)eps,
+                                                                                        (T*)f, (T*)A, (T*)B, (T*)xn)));
+    HIP_TRY(hipGetLastError());
+    return SCG_OK;
+}
+
+extern "C" int scg_prior_model(scg_env* env, const void* d_x, const void* d_u, int n, double eps, void* d_f, void* d_A,
+                               void* d_B, void* d_xnext, void* stream) {
+    if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
+    if (!d_x || !d_u || n <= 0) return fail(SCG_ERR_INVALID, "scg_prior_model needs d_x, d_u and n > 0");
+    if (eps <= 0.0) return fail(SCG_ERR_INVALID, "eps must be positive");
+    HIP_TRY(hipSetDevice(env->device));
+    return SCG_BY_DTYPE(env, launch_prior, env, d_x, d_u, n, eps, d_f, d_A, d_B, d_xnext, (hipStream_t)stream);
 }
 
 extern "C" int scg_gae(int dtype, void* d_rew, const void* d_v, const void* d_mask, const void* d_terminal_v,

@@ -115,7 +115,7 @@ struct HotRand {
     X(n_box_rows) X(n_box_state_rows) X(integrator) X(init_compact) X(param_compact)
 #define SCG_CFG_INT_ARRAYS(X) X(n_dist, 3)
 #define SCG_CFG_T_FIELDS(X)                                                                            \
-    X(box_round) X(box_inv_round) X(pyb_dt) X(goal_tolerance) X(constraint_penalty) X(x_threshold)     \
+    X(box_round) X(box_inv_round) X(pyb_dt) X(ctrl_dt) X(goal_tolerance) X(constraint_penalty) X(x_threshold)     \
     X(theta_threshold) X(act_scale) X(hover_thrust) X(kf) X(km) X(pwm2rpm_scale) X(pwm2rpm_const)      \
     X(pwm_min) X(pwm_max) X(gravity) X(arm) X(vmax) X(pole_box_width)
 #define SCG_CFG_T_ARRAYS(X)                                                                            \

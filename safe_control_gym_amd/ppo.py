@@ -419,23 +419,18 @@ class PPO:
         critic = critic or self.agent.ac.critic
         rew_buf = self.rew if rew_buf is None else rew_buf
         v_buf = self.v if v_buf is None else v_buf
-
-        class _AC:           # (keeps the body below identical for both callers)
-            pass
-        ac = _AC()
-        ac.critic = critic
-        last_val = ac.critic(self.obs[self.T]).squeeze(-1)
+        last_val = critic(self.obs[self.T]).squeeze(-1)
         mask = 1.0 - self.done.to(torch.float32)
         # time truncation is not termination: bootstrap with the critic's value of the terminal observation
         trunc = (self.flags & 1).bool() & self.done.bool()
         if dense:
-            tv = ac.critic(self.term_obs.reshape(self.T * self.N, self.obs_dim)).reshape(self.T, self.N)
+            tv = critic(self.term_obs.reshape(self.T * self.N, self.obs_dim)).reshape(self.T, self.N)
             terminal_v = torch.where(trunc, tv, torch.zeros_like(tv))
         else:
             terminal_v = torch.zeros_like(rew_buf)
             idx = trunc.nonzero(as_tuple=False)
             if idx.numel():
-                terminal_v[idx[:, 0], idx[:, 1]] = ac.critic(self.term_obs[idx[:, 0], idx[:, 1]]).squeeze(-1)
+                terminal_v[idx[:, 0], idx[:, 1]] = critic(self.term_obs[idx[:, 0], idx[:, 1]]).squeeze(-1)
         rew = rew_buf.clone()
         ret, adv = self._gae(rew, v_buf, mask, terminal_v, last_val, cfg.gamma, cfg.gae_lambda, cfg.use_gae)
         moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])

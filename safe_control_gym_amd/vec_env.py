@@ -397,6 +397,24 @@ class HipVecEnv(VecEnv):
                 self._h, sp.ctypes.data_as(C.POINTER(C.c_int32)) if sp is not None else None,
                 ep.ctypes.data_as(C.POINTER(C.c_uint32)) if ep is not None else None, 0, self.num_envs, self._stream()))
 
+    def prior_model(self, x, u, want=('f', 'A', 'B', 'xnext'), eps=None):
+        """Batched prior-model services (scg_prior_model): x [n, state_dim], u [n, action_dim] device tensors (physical
+        units) -> dict with the requested entries: 'f' [n, nx] continuous-time dynamics, 'A' [n, nx, nx] and 'B' [n, nx, nu]
+        Jacobians, 'xnext' [n, nx] one RK4 step of the control period.  n is independent of num_envs."""
+        x = torch.as_tensor(x, device=self.device).to(self.dtype).contiguous()
+        u = torch.as_tensor(u, device=self.device).to(self.dtype).contiguous()
+        n, nx, nu = x.shape[0], self.spec.nx, self.spec.nu
+        assert x.shape == (n, nx) and u.shape == (n, nu)
+        if eps is None:
+            eps = 1e-6 if self.dtype == torch.float64 else 1e-3
+        shapes = {'f': (n, nx), 'A': (n, nx, nx), 'B': (n, nx, nu), 'xnext': (n, nx)}
+        out = {k: torch.empty(shapes[k], dtype=self.dtype, device=self.device) for k in want}
+        p = lambda k: C.c_void_p(out[k].data_ptr()) if k in out else None      # noqa: E731
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.scg_prior_model(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(u.data_ptr()), n, float(eps),
+                                                p('f'), p('A'), p('B'), p('xnext'), self._stream()))
+        return out
+
     def seed(self, seed):
         """New Philox key for every env of the batch (BenchmarkEnv.seed, benchmark_env.py:193-214)."""
         self.seed_value = int(seed)

@@ -57,3 +57,32 @@ def test_registry_and_quadrotor_facade():
     assert 0.0 < rew <= 1.0 and env.state.shape == (12,)
     np.testing.assert_allclose(env.denormalize_action(env.normalize_action(np.full(4, 0.07))), 0.07)
     env.close()
+
+
+@pytest.mark.parametrize('task', ['cartpole_stab', 'quadrotor_2D_track', 'quadrotor_3D_track'])
+def test_batched_prior_model_services_match_the_analytic_model(task):
+    """scg_prior_model: f, df/dx, df/du and one RK4 step for many (x, u) at once == the product's NumPy AnalyticModel
+    (which equals the oracle's symbolic restatement, tests/test_capi_cpu.py) evaluated point by point."""
+    import numpy as np
+    from safe_control_gym_amd.env_config import EnvSpec
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.symbolic import AnalyticModel
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task(task)
+    cfg = dict(cfg, engine_arm='symbolic')
+    env = HipVecEnv(env_id, 4, seed=0, dtype=torch.float64, return_numpy=False, **cfg)
+    am = AnalyticModel(env_id, EnvSpec(env_id, cfg))
+    rng = np.random.default_rng(3)
+    n = 300
+    x = rng.normal(0, 0.3, (n, env.spec.nx))
+    u = np.abs(rng.normal(0.08, 0.02, (n, env.spec.nu))) if env_id == 'quadrotor' else rng.normal(0, 3.0, (n, 1))
+    out = env.prior_model(x, u)
+    for i in range(0, n, 37):
+        np.testing.assert_allclose(out['f'][i].cpu().numpy(), am.f(x[i], u[i]), rtol=1e-11, atol=1e-12)
+        A, B = am.df_func(x[i], u[i])
+        np.testing.assert_allclose(out['A'][i].cpu().numpy(), A.toarray(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(out['B'][i].cpu().numpy(), B.toarray(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out['xnext'][i].cpu().numpy(), am.fd_func(x[i], u[i], substeps=1)['xf'].reshape(-1), rtol=1e-11, atol=1e-12)
+    only = env.prior_model(x[:5], u[:5], want=('A',))
+    assert set(only) == {'A'} and only['A'].shape == (5, env.spec.nx, env.spec.nx)
+    env.close()
