@@ -62,13 +62,14 @@ def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
     port = CPort(small, seed=42)
     port.reset()
     rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, size=(4, n_envs, small.action_dim))
-    port.step(acts[0])                                                              # warm-up (page faults, threads)
-    steps = 0
+    acts = rng.uniform(-1, 1, size=(8, n_envs, small.action_dim))
+    port.run(acts, 2)                                                               # warm-up (threads, caches)
+    # K control steps per call: every thread advances its own envs through all K steps (no barrier per step)
+    K, steps = 50, 0
     t0 = time.perf_counter()
     while True:
-        port.step(acts[steps % 4])
-        steps += 1
+        port.run(acts, K)
+        steps += K
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
@@ -83,7 +84,8 @@ def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
         k += 1
     np_rate = n_np * k / (time.perf_counter() - t1)
     return {'value': c_rate, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/scg_oracle.c (float64 C restatement of the control step, gcc -O3 -fopenmp, {cores} threads), '
+            'sample': f'oracle/scg_oracle.c (float64 C restatement of the control step, gcc -O3 -fopenmp, {cores} threads, '
+                      f'each thread runs its envs {K} steps per parallel region), '
                       f'{n_envs} envs x {steps} control steps of {task} with random actions in {el:.1f} s; '
                       f'NumPy oracle on 1 core: {np_rate:.3g} env-steps/s; reference README (1 PyBullet env, '
                       f'i7-1068NG7): 381-464 env-steps/s'}

@@ -109,16 +109,19 @@ class CPort:
             c.row_var[q], c.row_idx[q], c.row_sign[q], c.row_b[q] = v, ix, sg, b
         self.cfg = c
         n = c.n
-        self.state = np.zeros((n, c.ns))
+        self.state = np.empty((n, c.ns))
         self.step_ctr = np.zeros(n, dtype=np.int32)
         self.episode = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
-        self.obs = np.zeros((n, c.nobs))
+        self.obs = np.empty((n, c.nobs))
         self.rew = np.zeros(n)
         self.done = np.zeros(n, dtype=np.uint8)
         self.flags = np.zeros(n, dtype=np.uint8)
-        self.cvals = np.zeros((n, max(c.n_rows, 1)))
+        self.cvals = np.empty((n, max(c.n_rows, 1)))
         self.mse = np.zeros(n)
-        self.term_obs = np.zeros((n, c.nobs))
+        self.term_obs = np.empty((n, c.nobs))
+        # first touch by the OpenMP threads that will own the rows (NUMA placement on multi-socket hosts)
+        self.lib.oc_touch(C.byref(self.cfg), self._p(self.state, f64), self._p(self.obs, f64), self._p(self.cvals, f64),
+                          self._p(self.term_obs, f64))
 
     @staticmethod
     def _p(a, t):
@@ -135,4 +138,14 @@ class CPort:
                          self._p(self.episode, C.c_uint32), self._p(a, f64), self._p(self.obs, f64), self._p(self.rew, f64),
                          self._p(self.done, C.c_uint8), self._p(self.flags, C.c_uint8), self._p(self.cvals, f64),
                          self._p(self.mse, f64), self._p(self.term_obs, f64))
+        return self.obs, self.rew, self.done.astype(bool)
+
+    def run(self, actions, k_steps):
+        """k_steps control steps with the action ring `actions` [ring, n, nu]; no barrier between steps (envs are
+        independent), outputs hold the last step.  This is the loop bench.py times as the CPU baseline."""
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        self.lib.oc_run(C.byref(self.cfg), self._p(self.state, f64), self._p(self.step_ctr, i32),
+                        self._p(self.episode, C.c_uint32), self._p(a, f64), int(a.shape[0]), int(k_steps), self._p(self.obs, f64),
+                        self._p(self.rew, f64), self._p(self.done, C.c_uint8), self._p(self.flags, C.c_uint8),
+                        self._p(self.cvals, f64), self._p(self.mse, f64), self._p(self.term_obs, f64))
         return self.obs, self.rew, self.done.astype(bool)

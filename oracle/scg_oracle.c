@@ -158,10 +158,10 @@ void oc_reset(const oc_cfg* c, double* state, int32_t* step, uint32_t* episode, 
 }
 
 /* One vectorised control step with auto-reset.  flags: bit0 truncated, bit1 violation, bit2 out_of_bounds. */
-void oc_step(const oc_cfg* c, double* state, int32_t* step, uint32_t* episode, const double* action, double* obs,
-             double* rew, unsigned char* done, unsigned char* flags, double* cvals, double* mse_out, double* term_obs) {
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < c->n; ++i) {
+static inline void step_env(const oc_cfg* c, int i, double* state, int32_t* step, uint32_t* episode, const double* action,
+                            double* obs, double* rew, unsigned char* done, unsigned char* flags, double* cvals,
+                            double* mse_out, double* term_obs) {
+    {
         double* s = state + (size_t)i * c->ns;
         const int c0 = step[i];
         double noisy[OC_MAX_ACTION], clipped[OC_MAX_ACTION];
@@ -300,6 +300,35 @@ void oc_step(const oc_cfg* c, double* state, int32_t* step, uint32_t* episode, c
         } else {
             write_obs(c, st, c0 + 2, obs + (size_t)i * c->nobs);
         }
+    }
+}
+
+void oc_step(const oc_cfg* c, double* state, int32_t* step, uint32_t* episode, const double* action, double* obs,
+             double* rew, unsigned char* done, unsigned char* flags, double* cvals, double* mse_out, double* term_obs) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < c->n; ++i)
+        step_env(c, i, state, step, episode, action, obs, rew, done, flags, cvals, mse_out, term_obs);
+}
+
+/* k_steps control steps of every env with the actions of a ring of `ring` pre-generated batches ([ring][n][nu]); the envs are
+ * independent, so each thread advances its own envs through all the steps without a barrier per step (the output arrays
+ * hold the last step's values, like the GPU benchmark that reuses its output buffers).  This is the CPU baseline loop. */
+void oc_run(const oc_cfg* c, double* state, int32_t* step, uint32_t* episode, const double* actions, int ring, int k_steps,
+            double* obs, double* rew, unsigned char* done, unsigned char* flags, double* cvals, double* mse_out, double* term_obs) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < c->n; ++i)
+        for (int t = 0; t < k_steps; ++t)
+            step_env(c, i, state, step, episode, actions + (size_t)(t % ring) * c->n * c->nu, obs, rew, done, flags, cvals,
+                     mse_out, term_obs);
+}
+
+/* first-touch initialisation of the per-env arrays by the threads that will own them (NUMA placement) */
+void oc_touch(const oc_cfg* c, double* state, double* obs, double* cvals, double* term_obs) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < c->n; ++i) {
+        for (int k = 0; k < c->ns; ++k) state[(size_t)i * c->ns + k] = 0.0;
+        for (int k = 0; k < c->nobs; ++k) { obs[(size_t)i * c->nobs + k] = 0.0; term_obs[(size_t)i * c->nobs + k] = 0.0; }
+        for (int k = 0; k < c->n_rows; ++k) cvals[(size_t)i * c->n_rows + k] = 0.0;
     }
 }
 

@@ -33,3 +33,26 @@ def test_c_port_matches_numpy_oracle(task):
         np.testing.assert_array_equal((port.flags & 1) != 0, info['truncated'])
         n_done += int(done_o.sum())
     assert n_done > 0
+
+
+def test_multi_step_run_equals_repeated_steps():
+    """oc_run (no barrier between steps: what bench.py times) == k calls of oc_step with the ring's actions."""
+    import numpy as np
+    from oracle.c_port import CPort
+    from oracle.envs import make_oracle_env, make_rng
+    from safe_control_gym_amd.registration import load_task
+    env_id, cfg = load_task('quadrotor_2D_track')
+    acts = np.random.default_rng(4).uniform(-1, 1, (3, 40, 2))
+    outs = []
+    for mode in ('run', 'step'):
+        env = make_oracle_env(env_id, 40, make_rng('philox', 40, 6), **cfg)
+        port = CPort(env, seed=6)
+        port.reset()
+        if mode == 'run':
+            port.run(acts, 70)
+        else:
+            for t in range(70):
+                port.step(acts[t % 3])
+        outs.append((port.state.copy(), port.obs.copy(), port.step_ctr.copy(), port.episode.copy(), port.rew.copy()))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
