@@ -47,6 +47,30 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may really use: os.cpu_count() capped by the affinity mask and the cgroup CPU quota
+    (the GPU box reports 256 logical CPUs but runs the container with a 16-CPU quota: 256 OpenMP threads on it are slower
+    than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
     """CPU path timed on this box's host cores, same workload (task config, env count, random actions):
     oracle/scg_oracle.c — the double-precision C restatement of the control step (validated against the NumPy oracle,
@@ -55,8 +79,9 @@ def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
     from oracle.c_port import CPort
     from oracle.envs import make_oracle_env, make_rng
     from oracle.vec import OracleVecEnv
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))
+    cores = int(os.environ['OMP_NUM_THREADS'])
     small = make_oracle_env(env_id, 8, make_rng('philox', 8, 42), **cfg)            # constants / tables only
     small.num_envs = n_envs
     port = CPort(small, seed=42)
