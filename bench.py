@@ -85,6 +85,8 @@ def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
     small = make_oracle_env(env_id, 8, make_rng('philox', 8, 42), **cfg)            # constants / tables only
     small.num_envs = n_envs
     port = CPort(small, seed=42)
+    port.lib.oc_set_threads(cores)          # (torch initialised the OpenMP runtime before OMP_NUM_THREADS was set here)
+    cores = int(port.lib.oc_get_threads())
     port.reset()
     rng = np.random.default_rng(0)
     acts = rng.uniform(-1, 1, size=(8, n_envs, small.action_dim))

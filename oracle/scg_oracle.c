@@ -17,6 +17,7 @@
  * Random draws: Philox4x32-10 with the addressing of oracle/rng.py.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -333,3 +334,7 @@ void oc_touch(const oc_cfg* c, double* state, double* obs, double* cvals, double
 }
 
 int oc_sizeof_cfg(void) { return (int)sizeof(oc_cfg); }
+
+/* OMP_NUM_THREADS is read once per process (the host program may have initialised the OpenMP runtime long before) */
+void oc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int oc_get_threads(void) { return omp_get_max_threads(); }
