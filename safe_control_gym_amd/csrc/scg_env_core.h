@@ -16,15 +16,17 @@
 // not translated: state is SoA in HBM, everything between load and store lives in registers.
 //
 // Performance notes (gfx950).  At the headline size (65 536 envs = 1024 waves on 1024 SIMDs) every SIMD
-// holds ONE wave, so a launch lasts as long as one wave's dependent instruction chain: the code below is
-// written to keep that chain short —
+// holds ONE wave, so a launch lasts as long as one wave's instruction stream — one instruction of any kind
+// (SALU included) per 4-clock issue slot, taken branches ~25 clocks, nothing to overlap the memory phases
+// with (profiles/r01_latency_budget.md): the code below is written for a short instruction stream —
 //   * the engine substeps never call sin/cos: rpm are constant within a control step, so the attitude
 //     advances by small angles d = h*w (|d| <= h*100 by Bullet's velocity clamp) and (sin,cos) / the
 //     quaternion are rotated with short Taylor polynomials (error < 1 ulp, guarded by `small_angle`);
 //   * reciprocals of mass / inertia are hoisted out of the substep loop, clamps are v_med3;
 //   * disturbance code (Philox + Box-Muller per channel) is compiled out of the DIST=false kernels,
 //     which every shipped RL config uses; box constraints are evaluated per variable with static
-//     register indices; Philox draws at reset serve two variables per call.
+//     register indices; Philox draws at reset serve two (or, without normal draws, four) variables per block;
+//   * every per-env array is addressed through a buffer resource (Slot<T>): no VALU address arithmetic.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -11,10 +11,10 @@
 //   generic  (libscg_hip.so): CfgParams<T> lives in device memory; every workgroup stages it and the
 //            X_GOAL table into LDS (one 16-byte load per thread for the parameters, up to three for the
 //            table, all in flight together with the per-env state loads, ONE wait), then reads from LDS.
-//   SCG_SPEC (libscg_spec_<hash>.so, generated per task config by scg_spec.h): CfgParams<T> is a
-//            `static constexpr` object — parameters are immediates, config branches are resolved at
-//            compile time, the substep loop has a constant trip count; X_GOAL rows are read straight from
-//            global memory (L2-resident) and there is no LDS, no barrier.
+//   SCG_SPEC (libscg_spec_<hash>.so, generated per task config by scg_spec.h): CfgParams<T> is a constexpr
+//            object — parameters are immediates, config branches are resolved at compile time, the substep
+//            loop is straight-line code; X_GOAL rows are read straight from global memory (L2-resident); LDS
+//            is used only for the wave-private transpose of the observation rows (no workgroup barrier).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,7 +24,7 @@ namespace scg {
 
 // Workgroup size.  Specialised build: one wave per workgroup — nothing is shared between waves (the observation
 // transpose is wave-private), and single-wave workgroups dispatch and balance better: 5.73 -> 5.62 us per launch at
-// 65 536 envs, 49.1 -> 44.4 us at 1 048 576 (tools/exp_variants.sh).  Generic build: 256 threads stage the parameter
+// 65 536 envs (tools/exp_variants.sh).  Generic build: 256 threads stage the parameter
 // block and the X_GOAL table into LDS cooperatively.
 #ifndef SCG_BLOCK
 #ifdef SCG_SPEC
