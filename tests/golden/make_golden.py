@@ -282,6 +282,28 @@ def main():
     rollout_case('quadrotor_2D_adversary', 'quadrotor',
                  load_task_config('quadrotor', f'{rl}/quadrotor_2D/quadrotor_2D_track.yaml', adv),
                  n_envs=2, n_steps=220, seed=2, act_scale=0.5, adversary=True)
+    # --- goal horizon > 1, adversary on the ACTION channel, linear (non-exponential) reward with penalty ---
+    hz = {'obs_goal_horizon': 3, 'rew_exponential': False, 'adversary_disturbance': 'action',
+          'adversary_disturbance_scale': 0.02, 'use_constraint_penalty': True, 'constraint_penalty': 0.1, 'episode_len_sec': 3,
+          'task_info': {'trajectory_type': 'circle', 'num_cycles': 2, 'trajectory_plane': 'xz',
+                        'trajectory_position_offset': [0, 1.2], 'trajectory_scale': 0.6}}
+    rollout_case('quadrotor_2D_horizon', 'quadrotor',
+                 load_task_config('quadrotor', f'{rl}/quadrotor_2D/quadrotor_2D_track.yaml', hz),
+                 n_envs=3, n_steps=260, seed=5, act_scale=0.3, adversary=True)
+    # --- 3-D stabilisation (goal_reached / stale out_of_bounds paths in 3-D) ---
+    rollout_case('quadrotor_3D_stab', 'quadrotor',
+                 load_task_config('quadrotor', f'{rl}/quadrotor_3D/quadrotor_3D_track.yaml',
+                                  {'task': 'stabilization', 'episode_len_sec': 3,
+                                   'task_info': {'stabilization_goal': [0.3, 0.4, 1.3], 'stabilization_goal_tolerance': 0.35}}),
+                 n_envs=3, n_steps=240, seed=6, act_scale=0.3)
+    # --- cartpole: adversary on the dynamics channel, trajectory tracking with a 2-row goal horizon ---
+    rollout_case('cartpole_adversary', 'cartpole',
+                 load_task_config('cartpole', f'{rl}/cartpole/cartpole_stab.yaml',
+                                  {'task': 'traj_tracking', 'obs_goal_horizon': 2, 'adversary_disturbance': 'dynamics',
+                                   'adversary_disturbance_scale': 0.5, 'episode_len_sec': 4,
+                                   'task_info': {'trajectory_type': 'circle', 'num_cycles': 1, 'trajectory_plane': 'zx',
+                                                 'trajectory_position_offset': [0, 0], 'trajectory_scale': 0.3}}),
+                 n_envs=3, n_steps=200, seed=8, act_scale=0.5, adversary=True)
     gae_cases()
     shipped_models()
     # --- closed loop with the shipped policies: full-length episodes, time-limit truncation ---
