@@ -466,6 +466,31 @@ class EnvSpec:
             raise ValueError(f'more than {L.MAX_CON_ROWS} scalar constraint rows')
         self.num_constraints = len(self.con_rows)
 
+    def state_constraint_values(self, state):
+        """Values of the state-constraint rows for a batch of env.state vectors (torch tensor [n, nx], any device): what
+        `info['constraint_values']` holds after a reset (benchmark_env.py:356-357, constraints.py:97-109).  The step kernel
+        returns the pre-reset values of a finished episode; collectors that feed the constraint values of the NEW episode
+        to a policy (Safe-Explorer) evaluate them here from the returned state."""
+        import torch
+        x = state.to(torch.float64)
+        cols = []
+        for r in self.con_rows:
+            if r['var'] != 0:
+                continue
+            if r['kind'] == L.ROW_SPARSE:
+                c = r['sign'] * x[:, r['index']] - r['b']
+            elif r['kind'] == L.ROW_ABS:
+                c = x[:, r['index']].abs() - r['b']
+            elif r['kind'] == L.ROW_DENSE:
+                c = x @ torch.as_tensor(r['coef'][:x.shape[1]], dtype=torch.float64, device=x.device) - r['b']
+            else:
+                P = torch.as_tensor(self.quad_P[r['index']], dtype=torch.float64, device=x.device)
+                c = ((x @ P) * x).sum(-1) - r['b']
+            if r['round_scale'] > 0:
+                c = torch.round(c * r['round_scale']) / r['round_scale']
+            cols.append(c)
+        return torch.stack(cols, dim=1) if cols else x.new_zeros((x.shape[0], 0))
+
     @property
     def n_state_con_rows(self):
         return sum(1 for r in self.con_rows if r['var'] == 0)

@@ -50,8 +50,15 @@ class MLPActor(nn.Module):
         self.pi_net = MLP(obs_dim, act_dim, hidden_dims, activation)
         self.logstd = nn.Parameter(-0.5 * torch.ones(act_dim))       # ppo_utils.py:166
 
-    def forward(self, obs):
-        return self.pi_net(obs), self.logstd
+    def forward(self, obs, c=None):
+        """(mean, logstd).  `action_modifier(obs, mean, c)`, when set, filters the mean (Safe-Explorer's safety layer,
+        safe_explorer/safe_ppo_utils.py:88-110); it is not a sub-module, so its parameters are not the actor's."""
+        mean = self.pi_net(obs)
+        if self.action_modifier is not None:
+            mean = self.action_modifier(obs, mean, c)
+        return mean, self.logstd
+
+    action_modifier = None
 
 
 class MLPCritic(nn.Module):
@@ -87,16 +94,16 @@ class MLPActorCritic(nn.Module):
         self.critic = MLPCritic(obs_dim, list(hidden_dims), activation)
 
     @torch.no_grad()
-    def step(self, obs):
+    def step(self, obs, c=None):
         """Sampled action, value, log-prob (ppo_utils.py:224-231), all on device."""
-        mean, logstd = self.actor(obs)
+        mean, logstd = self.actor(obs, c)
         act = mean + torch.exp(logstd) * torch.randn_like(mean)
         return act, self.critic(obs).squeeze(-1), normal_log_prob(mean, logstd, act)
 
     @torch.no_grad()
-    def act(self, obs):
+    def act(self, obs, c=None):
         """Deterministic action = distribution mode (ppo_utils.py:233-238)."""
-        return self.actor(obs)[0]
+        return self.actor(obs, c)[0]
 
 
 # ------------------------------------------------------------------ hyper-parameters
@@ -136,7 +143,7 @@ class PPOConfig:
 # ------------------------------------------------------------------ losses / update
 def policy_loss_terms(ac, batch, clip_param):
     """ppo_utils.py:82-96."""
-    mean, logstd = ac.actor(batch['obs'])
+    mean, logstd = ac.actor(batch['obs'], batch.get('c'))
     logp = normal_log_prob(mean, logstd, batch['act'])
     ratio = torch.exp(logp - batch['logp'])
     adv = batch['adv']

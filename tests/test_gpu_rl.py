@@ -222,3 +222,28 @@ def test_rarl_alternates_protagonist_and_adversary_on_the_adversary_channel():
         e.close()
     with pytest.raises(ValueError):
         RARL(_env('quadrotor_2D_track', 64), cfg)
+
+
+def test_safe_explorer_ppo_pretrain_and_step():
+    """safe_ppo.py: constraint-model pre-training on random transitions (c_next = the step's pre-reset constraint values),
+    then a PPO iteration whose policy mean is filtered by the safety layer with the current constraint values as input."""
+    from safe_control_gym_amd.ppo import PPOConfig
+    from safe_control_gym_amd.safe_explorer import SafeExplorerPPO
+    env = _env('quadrotor_2D_track', 256)
+    cfg = PPOConfig(hidden_dim=16, use_gae=True, opt_epochs=1, mini_batch_size=1024, rollout_steps=8, actor_lr=1e-3, critic_lr=1e-3)
+    se = SafeExplorerPPO(env, cfg, seed=2, constraint_hidden_dim=16, constraint_batch_size=512)
+    assert se.C == 12 and se.c.shape == (256, 12)
+    # constraint values of the reset state == what the reset kernel reported
+    torch.testing.assert_close(se.c, env.out.c_values[:12].t().to(torch.float32), rtol=0, atol=1e-6)
+    hist = se.pretrain(256 * 40, epochs=4)
+    assert se.constraint_buffer.size == 256 * 40 and np.mean(hist[-1]) < np.mean(hist[0])
+    res = se.train_step()
+    assert res['step'] == 8 * 256 and np.isfinite(res['policy_loss']) and se.c_buf.shape == (8, 256, 12)
+    # where an episode ended the next policy input holds the NEW episode's constraint values, not the terminal ones
+    d = se.done[-1].bool()
+    if d.any():
+        fresh = env.spec.state_constraint_values(env.out.state.t()).to(torch.float32)
+        torch.testing.assert_close(se.c[d], fresh[d], rtol=0, atol=1e-6)
+    env.close()
+    with pytest.raises(ValueError):
+        SafeExplorerPPO(_env('quadrotor_2D_track', 64, constraints=None), cfg)
