@@ -225,3 +225,33 @@ def test_state_constraint_values_match_the_oracle_constraints():
         ref = env.constraints.get_values(env.state, None, only_state=True)
         got = EnvSpec(meta['task'], cfg).state_constraint_values(torch.as_tensor(env.state)).numpy()
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-8)
+
+
+def _norm_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from safe_control_gym_amd.normalization import MeanStdNormalizer
+    g = torch.Generator().manual_seed(7)
+    full = [torch.randn(64, 3, generator=g, dtype=torch.float64) * 2 + 1 for _ in range(5)]
+    nz = MeanStdNormalizer((3,), clip=100.0)
+    for x in full:
+        nz(x[rank * 32:(rank + 1) * 32])            # each rank sees its shard; statistics are reduced over ranks
+    if rank == 0:
+        torch.save({'mean': nz.rms.mean, 'var': nz.rms.var, 'count': nz.rms.count}, out_path)
+    dist.destroy_process_group()
+
+
+def test_normaliser_statistics_are_global_across_ranks(tmp_path):
+    """Two gloo ranks with half the batch each end up with the statistics of one process that saw the whole batch."""
+    import torch.multiprocessing as mp
+    from safe_control_gym_amd.normalization import MeanStdNormalizer
+    out = str(tmp_path / 'norm.pt')
+    mp.spawn(_norm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    g = torch.Generator().manual_seed(7)
+    nz = MeanStdNormalizer((3,), clip=100.0)
+    for _ in range(5):
+        nz(torch.randn(64, 3, generator=g, dtype=torch.float64) * 2 + 1)
+    torch.testing.assert_close(got['mean'], nz.rms.mean, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(got['var'], nz.rms.var, rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(got['count'], nz.rms.count, rtol=0, atol=0)
