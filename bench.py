@@ -236,7 +236,8 @@ def main():
                                    f'{"HIP graph of %d steps" % G if graph is not None else "per-step Python launches"}',
                        'envs_per_gpu': N, 'task_yaml': f'safe_control_gym_amd/configs/{args.task}.yaml',
                        'parallelism': f'env-shard x{world}', 'finite_outputs': ok,
-                       'kernel_build': 'config-specialised' if env.specialized else 'generic'},
+                       'kernel_build': 'config-specialised' if env.specialized else 'generic',
+                       'ppo_wall_clock_to_reward': 'measured separately: examples/train_ppo.py, profiles/r01_ppo_wallclock_q2track.md'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc, bytes per launch)' if traffic else None,
