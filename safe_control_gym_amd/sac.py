@@ -169,6 +169,25 @@ class SACAgent:
     def alpha(self):
         return self.log_alpha.exp()
 
+    # same keys as the reference's SACAgent (sac_utils.py:85-108), so its checkpoints load directly; the action bounds are
+    # buffers here (not in upstream's state dict), hence strict=False
+    def state_dict(self):
+        return {'ac': self.ac.state_dict(), 'log_alpha': self.log_alpha.detach().clone(), 'ac_targ': self.ac_targ.state_dict(),
+                'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict(),
+                'alpha_opt': self.alpha_opt.state_dict()}
+
+    def load_state_dict(self, sd, with_optimizers=True):
+        self.ac.load_state_dict(sd['ac'], strict=False)
+        if 'ac_targ' in sd:
+            self.ac_targ.load_state_dict(sd['ac_targ'], strict=False)
+        if 'log_alpha' in sd:
+            with torch.no_grad():
+                self.log_alpha.copy_(torch.as_tensor(sd['log_alpha'], dtype=self.log_alpha.dtype).reshape(()))
+        if with_optimizers and 'actor_opt' in sd and not self.use_graphs:
+            self.actor_opt.load_state_dict(sd['actor_opt'])
+            self.critic_opt.load_state_dict(sd['critic_opt'])
+            self.alpha_opt.load_state_dict(sd['alpha_opt'])
+
     def policy_loss(self, batch):
         obs = batch['obs']
         act, logp = self.ac.actor(obs)

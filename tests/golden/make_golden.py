@@ -197,6 +197,12 @@ def shipped_models():
             pol[f'{tag}/{k}'] = v.numpy()
         kat[f'{tag}/obs'] = np.asarray(d['obs'], dtype=float)
         kat[f'{tag}/total_steps'] = np.array(d['total_steps'])
+    # one shipped SAC actor (layout / squashing check of sac.MLPActorCritic; critics omitted to keep the fixture small)
+    d = torch.load(os.path.join(REF, 'examples/rl/models/sac/sac_model_cartpole_stab.pt'), weights_only=False, map_location='cpu')
+    sac = {k: v.numpy() for k, v in d['agent']['ac'].items() if k.startswith('actor.')}
+    sac['log_alpha'] = np.asarray(d['agent']['log_alpha'].detach().numpy() if hasattr(d['agent']['log_alpha'], 'detach') else d['agent']['log_alpha'])
+    sac['obs'] = np.asarray(d['obs'], dtype=float)
+    np.savez_compressed(os.path.join(HERE, 'sac_actor_cartpole_stab.npz'), **sac)
     np.savez_compressed(os.path.join(HERE, 'policies.npz'), **pol)
     np.savez_compressed(os.path.join(HERE, 'xgoal_kat.npz'), **kat)
     print('policies.npz, xgoal_kat.npz written')

@@ -67,3 +67,29 @@ def test_device_replay_ring_semantics():
     assert set(buf.rew[:, 0].tolist()) <= {1.0, 2.0, 3.0}
     s = buf.sample(256)
     assert s['obs'].shape == (256, 3) and s['mask'].shape == (256, 1)
+
+
+def test_shipped_reference_sac_actor_loads_and_acts():
+    """The reference's SAC checkpoint layout (actor.net.fcs.*, mu_layer, log_std_layer) loads into sac.MLPActorCritic;
+    the deterministic action equals a NumPy forward pass with tanh squashing onto the action bounds."""
+    import os
+    import numpy as np
+    import torch
+    from safe_control_gym_amd.sac import MLPActorCritic
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sac_actor_cartpole_stab.npz'))
+    sd = {k: torch.as_tensor(f[k]) for k in f.files if k.startswith('actor.')}
+    low, high = torch.tensor([-1.0]), torch.tensor([1.0])            # normalised RL action space of cartpole_stab
+    ac = MLPActorCritic(4, 1, low, high, [256, 256], 'relu')
+    missing, unexpected = ac.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith(('q1.', 'q2.', 'actor.low', 'actor.high')) for m in missing)
+    obs = np.asarray(f['obs'], dtype=np.float32)
+    h = obs
+    for i in (0, 1):
+        h = h @ f[f'actor.net.fcs.{i}.weight'].T + f[f'actor.net.fcs.{i}.bias']
+        if i == 0:
+            h = np.maximum(h, 0.0)               # upstream MLP: activation between layers, none after the last
+    mu = h @ f['actor.mu_layer.weight'].T + f['actor.mu_layer.bias']
+    ref = -1.0 + 0.5 * (np.tanh(mu) + 1.0) * 2.0
+    got = ac.act(torch.as_tensor(obs), deterministic=True).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert np.all(np.abs(got) <= 1.0)
