@@ -241,6 +241,14 @@ int scg_reset(scg_env* env, const uint8_t* d_mask, const scg_step_out* out, void
 int scg_step(scg_env* env, const void* d_action, const void* d_adv_action, const scg_step_out* out,
              void* stream);
 
+/* The same control step for the env range [first_env, first_env + n_envs) only (first_env a multiple of 64).  All
+ * array arguments are the FULL [N]-sized arrays; only the rows of that range are read and written.  Envs are
+ * independent (dummy_vec_env.py:29-41 is a serial loop over them), so a caller may advance disjoint ranges of one
+ * handle from different streams concurrently: at 65 536 envs a launch is a latency chain (dispatch, loads, one wave's
+ * instruction stream, store drain) and sub-shard launches on 2-4 streams overlap one range's chain with another's. */
+int scg_step_range(scg_env* env, int first_env, int n_envs, const void* d_action, const void* d_adv_action,
+                   const scg_step_out* out, void* stream);
+
 /* K control steps per launch with in-kernel actions ~ U(-1, 1) (Philox channel 4); same per-step
  * semantics as scg_step, state kept in registers between steps. */
 int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_out* out, void* stream);
@@ -294,6 +302,8 @@ size_t scg_sizeof_step_out(void);
  * the hash; dtype is. */
 int scg_spec_source(const scg_config* cfg, char* buf, size_t capacity, size_t* length, uint64_t* hash);
 uint64_t scg_spec_hash(void);    /* 0 = generic library, else the hash this library was specialised for */
+uint64_t scg_source_hash(void);  /* digest of the kernel sources the library was compiled from (build systems compare it
+                                    with the tree so that a stale library is rebuilt instead of loaded) */
 
 #ifdef __cplusplus
 }

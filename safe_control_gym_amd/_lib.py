@@ -93,25 +93,51 @@ class RolloutOut(C.Structure):
     _fields_ = [(n, c_vp) for n in ('d_reward_sum', 'd_done_count', 'd_violation_count', 'd_last_obs')]
 
 
-EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step',
+EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step', 'scg_step_range',
            'scg_rollout_random', 'scg_set_state', 'scg_get_state', 'scg_set_params', 'scg_get_params',
            'scg_set_counters', 'scg_get_counters', 'scg_set_seed', 'scg_gae', 'scg_prior_model', 'scg_last_error', 'scg_abi_version',
-           'scg_sizeof_config', 'scg_sizeof_step_out', 'scg_spec_source', 'scg_spec_hash']
+           'scg_sizeof_config', 'scg_sizeof_step_out', 'scg_spec_source', 'scg_spec_hash', 'scg_source_hash']
 
 
 class ScgError(RuntimeError):
     pass
 
 
+def source_hash():
+    """64-bit digest of the kernel sources; compiled into every library (-DSCG_SRC_HASH) and compared at load time, so a
+    library built from older sources is never used silently (file times do not survive a copy of the tree)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.normpath(os.path.join(CSRC_DIR, name)), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return int.from_bytes(h.digest()[:8], 'little')
+
+
+def _hipcc():
+    return os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+def _lib_source_hash(path):
+    """SCG_SRC_HASH baked into a built library, read from the file's bytes (never dlopen here: a library loaded once
+    stays mapped under its path, a rebuilt file would not be seen).  0 if absent."""
+    import re
+    try:
+        with open(path, 'rb') as f:
+            m = re.search(rb'SCG_SRC_HASH:0x([0-9a-f]{16})ULL', f.read())
+    except OSError:
+        return 0
+    return int(m.group(1), 16) if m else 0
+
+
 def build(force=False, verbose=False):
     """Compile libscg_hip.so for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
-    deps = srcs + [os.path.normpath(os.path.join(CSRC_DIR, h)) for h in HEADERS]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    if not force and os.path.exists(LIB_PATH) and _lib_source_hash(LIB_PATH) == source_hash():
+        return LIB_PATH
+    hipcc = _hipcc()
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL',
+           '-o', LIB_PATH] + srcs
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -149,6 +175,7 @@ def _bind(path):
     L.scg_destroy.argtypes = [c_vp]
     L.scg_reset.argtypes = [c_vp, c_vp, C.POINTER(StepOut), c_vp]
     L.scg_step.argtypes = [c_vp, c_vp, c_vp, C.POINTER(StepOut), c_vp]
+    L.scg_step_range.argtypes = [c_vp, C.c_int, C.c_int, c_vp, c_vp, C.POINTER(StepOut), c_vp]
     L.scg_rollout_random.argtypes = [c_vp, C.c_int, C.POINTER(RolloutOut), c_vp]
     for fn in (L.scg_set_state, L.scg_get_state, L.scg_set_params, L.scg_get_params):
         fn.argtypes = [c_vp, C.POINTER(c_f64), C.c_int, C.c_int, c_vp]
@@ -159,14 +186,22 @@ def _bind(path):
                           c_f64, c_f64, C.c_int, c_vp]
     L.scg_spec_source.argtypes = [C.POINTER(Config), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(c_u64)]
     L.scg_spec_hash.restype = c_u64
+    L.scg_source_hash.restype = c_u64
     L.scg_set_seed.argtypes = [c_vp, c_u64]
     return L
 
 
 def lib():
-    """The generic library (any config).  Raises ScgError (never falls back) if it is missing or inconsistent."""
+    """The generic library (any config).  Raises ScgError (never falls back) if it is missing or inconsistent.
+    A library compiled from other kernel sources than the ones in the tree is rebuilt when hipcc is present,
+    refused otherwise."""
     global _lib
     if _lib is None:
+        if os.path.exists(LIB_PATH) and _lib_source_hash(LIB_PATH) != source_hash():
+            if os.path.exists(_hipcc()):
+                build(force=True)
+            else:
+                raise ScgError(f'{LIB_PATH} was built from different kernel sources and hipcc is not available to rebuild it')
         _lib = _bind(LIB_PATH)
     return _lib
 
@@ -183,8 +218,12 @@ def spec_source(cfg):
 
 
 def spec_paths(hash_value):
+    """(header, library) of a specialisation.  Development variants: SCG_SPEC_TAG=<name> selects / builds
+    libscg_spec_<hash>_<name>.so (compiled with the extra flags in SCG_SPEC_FLAGS, e.g. -DSCG_Q3_UNROLL=20)."""
     tag = f'{hash_value:016x}'
-    return os.path.join(SPEC_DIR, f'scg_spec_{tag}.h'), os.path.join(SPEC_DIR, f'libscg_spec_{tag}.so')
+    var = os.environ.get('SCG_SPEC_TAG', '')
+    return (os.path.join(SPEC_DIR, f'scg_spec_{tag}.h'),
+            os.path.join(SPEC_DIR, f'libscg_spec_{tag}{"_" + var if var else ""}.so'))
 
 
 def build_spec(cfg, force=False, verbose=False):
@@ -193,14 +232,13 @@ def build_spec(cfg, force=False, verbose=False):
     hdr, so = spec_paths(h)
     os.makedirs(SPEC_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
-    deps = srcs + [os.path.normpath(os.path.join(CSRC_DIR, x)) for x in HEADERS]
-    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
+    if not force and os.path.exists(so) and _lib_source_hash(so) == source_hash():
         return so
     with open(hdr, 'w') as f:
         f.write(src)
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hipcc = _hipcc()
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSCG_SPEC', '-include', hdr,
-           '-o', so] + srcs
+           f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL', '-o', so] + os.environ.get('SCG_SPEC_FLAGS', '').split() + srcs
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -215,18 +253,20 @@ def lib_for(cfg, specialize='auto'):
     if specialize in (False, 'off', None):
         return lib(), False
     _, h = spec_source(cfg)
-    if h in _spec_libs:
-        return _spec_libs[h], True
+    key = (h, os.environ.get('SCG_SPEC_TAG', ''))
+    if key in _spec_libs:
+        return _spec_libs[key], True
     _, so = spec_paths(h)
-    if not os.path.exists(so):
-        if specialize is True or specialize == 'build':
-            build_spec(cfg)
+    stale = os.path.exists(so) and _lib_source_hash(so) != source_hash()
+    if not os.path.exists(so) or stale:
+        if specialize is True or specialize == 'build' or (stale and os.path.exists(_hipcc())):
+            build_spec(cfg, force=True)     # (stale: the kernel sources changed since this specialisation was compiled)
         else:
-            return lib(), False
+            return lib(), False             # never run kernels of older sources: the generic library was checked by lib()
     L = _bind(so)
     if int(L.scg_spec_hash()) != h:
         raise ScgError(f'{so} was built for another config')
-    _spec_libs[h] = L
+    _spec_libs[key] = L
     return L, True
 
 

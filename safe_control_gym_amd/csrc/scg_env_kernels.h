@@ -38,6 +38,7 @@ constexpr size_t LDS_GOAL_LIMIT = 64 * 1024;
 
 constexpr size_t lds16(size_t sz) { return (sz + 15) / 16 * 16; }
 static_assert(sizeof(CfgParams<double>) <= 3 * 256 * 16, "CfgParams must fit three 16-byte loads per thread");
+static_assert(offsetof(CfgParams<double>, dist) + sizeof(HotDist<double>) * 3 * SCG_MAX_DISTURB == sizeof(CfgParams<double>), "dist must be the last member of CfgParams");
 
 #ifdef SCG_SPEC
 #define SCG_DEV_GOAL_TABLE 0
@@ -52,11 +53,15 @@ struct StageRegs {
 };
 
 #ifndef SCG_SPEC
-template <typename T>
+// bytes of CfgParams a kernel stages into LDS: kernels without disturbances stop before the disturbance table
+template <typename T, bool DIST>
+constexpr size_t cfg_stage_bytes() { return lds16(DIST ? sizeof(CfgParams<T>) : offsetof(CfgParams<T>, dist)); }
+
+template <typename T, bool DIST>
 __device__ __forceinline__ StageRegs stage_issue(const CfgParams<T>* __restrict__ Cg, const InstParams<T>& I) {
     StageRegs R;
     R.c0 = R.c1 = R.c2 = R.g0 = R.g1 = R.g2 = make_uint4(0, 0, 0, 0);
-    R.n_cfg16 = (int)(lds16(sizeof(CfgParams<T>)) / 16);
+    R.n_cfg16 = (int)(cfg_stage_bytes<T, DIST>() / 16);
     const uint4* src = reinterpret_cast<const uint4*>(Cg);
     const int t = (int)threadIdx.x;
     if (t < R.n_cfg16) R.c0 = src[t];
@@ -136,9 +141,9 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
                                                       const uint8_t* __restrict__ mask, const OutTabPtr OT) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = I.env_first + blockIdx.x * blockDim.x + threadIdx.x;
     const int N = I.num_envs;
-    const bool live = i < N && (!mask || mask[i]);
+    const bool live = i < I.env_end && (!mask || mask[i]);
     typename Ops::E e;
 #ifdef SCG_SPEC
     constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();     // compile-time constants (see scg_spec.h)
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
     Ops::load_state(P, i, e);
 #else
     extern __shared__ __align__(16) unsigned char smem[];
-    const StageRegs SR = stage_issue(Cg, I);
+    const StageRegs SR = stage_issue<T, DIST>(Cg, I);
     {
         const PV<T> Pg{*Cg, I};
         if (live) Ops::load_state(Pg, i, e);
@@ -222,7 +227,8 @@ __device__ __forceinline__ void fence_out(const OutTabPtr& O) {
 template <typename T, typename TAB>
 __device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* action, const T* adv, const TAB& O) {
     sreg_fence(I.cold); sreg_fence(I.x_goal); sreg_fence(I.ws); sreg_fence(I.state_off); sreg_fence(I.param_off);
-    sreg_fence(I.step_off); sreg_fence(I.episode_off); sreg_fence(I.oob_off); sreg_fence(I.num_envs);
+    sreg_fence(I.step_off); sreg_fence(I.episode_off); sreg_fence(I.oob_off); sreg_fence(I.dist_off); sreg_fence(I.num_envs);
+    sreg_fence(I.env_first); sreg_fence(I.env_end);
     sreg_fence(I.env_id_offset); sreg_fence(I.key0); sreg_fence(I.key1);
     sreg_fence(action); sreg_fence(adv);
     fence_out<T>(O);
@@ -234,9 +240,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
                                                      const typename OutTabOf<ONE>::type O) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int i = I.env_first + blockIdx.x * BLOCK + threadIdx.x;
     const int N = I.num_envs;
-    const bool live = i < N;
+    const bool live = i < I.env_end;
     // ---- memory round 1: kernargs — every pointer is fetched in this block, one scalar-memory round
     SCG_TL(0);
     fence_kernargs<T>(I, action, adv, O);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     const int nobs_early = kcfg.nobs;
 #else
     extern __shared__ __align__(16) unsigned char smem[];
-    const StageRegs SR = stage_issue(Cg, I);
+    const StageRegs SR = stage_issue<T, DIST>(Cg, I);
     const PV<T> Pg{*Cg, I};
     const int nobs_early = D::NX * (1 + I.obs_ext_rows);
 #endif
@@ -403,8 +409,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
                                                                int32_t* __restrict__ violation_count, T* __restrict__ last_obs) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < I.num_envs;
+    const int i = I.env_first + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < I.env_end;
     typename Ops::E e;
 #ifdef SCG_SPEC
     constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();     // compile-time constants (see scg_spec.h)
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
     Ops::load_state(P, i, e);
 #else
     extern __shared__ __align__(16) unsigned char smem[];
-    const StageRegs SR = stage_issue(Cg, I);
+    const StageRegs SR = stage_issue<T, DIST>(Cg, I);
     {
         const PV<T> Pg{*Cg, I};
         if (live) Ops::load_state(Pg, i, e);

@@ -262,6 +262,18 @@ static void build_cfg(const scg_config& c, CfgParams<double>& h) {
     h.auto_reset = c.auto_reset; h.adversary_channel = c.adversary_channel;
     h.n_con_rows = c.n_con_rows; h.n_state_con_rows = c.n_state_con_rows;
     for (int k = 0; k < 3; ++k) h.n_dist[k] = c.n_dist[k];
+    // disturbance lists (hot copy; offset slots numbered in channel/list order like count_offset_slots)
+    int oslot = 0;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < c.n_dist[ch]; ++k) {
+            const scg_disturbance& sd = c.dist[ch][k];
+            HotDist<double>& d = h.dist[ch][k];
+            d.kind = sd.kind; d.step_offset = sd.step_offset; d.max_step = sd.max_step;
+            d.offset_slot = -1;
+            if ((sd.kind == SCG_DIST_IMPULSE || sd.kind == SCG_DIST_STEP) && sd.step_offset < 0) d.offset_slot = oslot++;
+            d.half_duration = sd.duration / 2.0; d.decay_rate = sd.decay_rate; d.two_pi_freq = 2.0 * M_PI * sd.frequency;
+            for (int j = 0; j < SCG_MAX_STATE; ++j) { d.a[j] = sd.a[j]; d.b[j] = sd.b[j]; d.mask[j] = sd.mask[j]; }
+        }
     h.pyb_dt = c.pyb_dt; h.ctrl_dt = c.ctrl_dt; h.goal_tolerance = c.goal_tolerance; h.constraint_penalty = c.constraint_penalty;
     h.x_threshold = c.x_threshold; h.theta_threshold = c.theta_threshold; h.act_scale = c.act_scale;
     h.hover_thrust = c.hover_thrust; h.kf = c.kf; h.km = c.km; h.pwm2rpm_scale = c.pwm2rpm_scale;
@@ -323,6 +335,14 @@ static void convert_cfg(const CfgParams<double>& d, CfgParams<T>& o) {
     for (int k = 0; k < SCG_MAX_PARAM; ++k) { o.param_rand[k].kind = d.param_rand[k].kind; o.param_rand[k].p0 = (T)d.param_rand[k].p0; o.param_rand[k].p1 = (T)d.param_rand[k].p1; }
     for (int k = 0; k < SCG_MAX_STATE; ++k) { o.init_rand[k].kind = d.init_rand[k].kind; o.init_rand[k].p0 = (T)d.init_rand[k].p0; o.init_rand[k].p1 = (T)d.init_rand[k].p1; }
     for (int k = 0; k < SCG_MAX_CON_ROWS; ++k) { o.box[k].packed = d.box[k].packed; o.box[k].b = (T)d.box[k].b; }
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < SCG_MAX_DISTURB; ++k) {
+            const HotDist<double>& a = d.dist[ch][k];
+            HotDist<T>& b = o.dist[ch][k];
+            b.kind = a.kind; b.step_offset = a.step_offset; b.max_step = a.max_step; b.offset_slot = a.offset_slot;
+            b.half_duration = (T)a.half_duration; b.decay_rate = (T)a.decay_rate; b.two_pi_freq = (T)a.two_pi_freq;
+            for (int j = 0; j < SCG_MAX_STATE; ++j) { b.a[j] = (T)a.a[j]; b.b[j] = (T)a.b[j]; b.mask[j] = (T)a.mask[j]; }
+        }
     // np.round(., decimals) is only meaningful in double precision
     if (sizeof(T) != 8) { o.box_round = (T)0; o.box_inv_round = (T)0; }
 }
@@ -364,6 +384,18 @@ static std::string spec_body(const scg_config& c) {
     for (int k = 0; k < h.n_box_rows; ++k) {
         std::snprintf(buf, sizeof buf, "    c.box[%d].packed = %d; c.box[%d].b = (T)%a;\n", k, h.box[k].packed, k, h.box[k].b); s += buf;
     }
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < h.n_dist[ch]; ++k) {
+            const HotDist<double>& d = h.dist[ch][k];
+            std::snprintf(buf, sizeof buf, "    c.dist[%d][%d].kind = %d; c.dist[%d][%d].step_offset = %d; c.dist[%d][%d].max_step = %d; c.dist[%d][%d].offset_slot = %d;\n",
+                          ch, k, d.kind, ch, k, d.step_offset, ch, k, d.max_step, ch, k, d.offset_slot); s += buf;
+            std::snprintf(buf, sizeof buf, "    c.dist[%d][%d].half_duration = (T)%a; c.dist[%d][%d].decay_rate = (T)%a; c.dist[%d][%d].two_pi_freq = (T)%a;\n",
+                          ch, k, d.half_duration, ch, k, d.decay_rate, ch, k, d.two_pi_freq); s += buf;
+            for (int j = 0; j < SCG_MAX_STATE; ++j) {
+                std::snprintf(buf, sizeof buf, "    c.dist[%d][%d].a[%d] = (T)%a; c.dist[%d][%d].b[%d] = (T)%a; c.dist[%d][%d].mask[%d] = (T)%a;\n",
+                              ch, k, j, d.a[j], ch, k, j, d.b[j], ch, k, j, d.mask[j]); s += buf;
+            }
+        }
     s += "    if (sizeof(T) != 8) { c.box_round = (T)0; c.box_inv_round = (T)0; }\n";
     std::snprintf(buf, sizeof buf, "// system %d dtype %d dist %d\n", c.system, c.dtype,
                   (int)(c.n_dist[0] > 0 || c.n_dist[1] > 0 || c.n_dist[2] > 0 || c.adversary_channel >= 0));
@@ -402,6 +434,16 @@ extern "C" int scg_spec_source(const scg_config* cfg, char* buf, size_t capacity
     }
     return SCG_OK;
 }
+
+// Digest of the kernel sources this library was compiled from (-DSCG_SRC_HASH, see _lib.py::source_hash); 0 = unknown.
+#ifndef SCG_SRC_HASH
+#define SCG_SRC_HASH 0ULL
+#endif
+extern "C" uint64_t scg_source_hash(void) { return SCG_SRC_HASH; }
+// the same digest as text inside the file, so that a build script can read it without loading the library
+#define SCG_STR2(x) #x
+#define SCG_STR(x) SCG_STR2(x)
+extern "C" const char* scg_source_hash_tag(void) { return "SCG_SRC_HASH:" SCG_STR(SCG_SRC_HASH); }
 
 // 0 for the generic library, the baked-in config hash for a specialised one.
 extern "C" uint64_t scg_spec_hash(void) {
@@ -460,8 +502,9 @@ static InstParams<T> inst_of(const scg_env* e) {
     I.ws = (char*)e->d_workspace;
     auto off = [&](const void* q) { return q ? (uint32_t)((const char*)q - (const char*)e->d_workspace) : SCG_NO_OFF; };
     I.state_off = off(e->d_state); I.param_off = off(e->d_param); I.step_off = off(e->d_step);
-    I.episode_off = off(e->d_episode); I.oob_off = off(e->d_oob);
+    I.episode_off = off(e->d_episode); I.oob_off = off(e->d_oob); I.dist_off = off(e->d_dist_offset);
     I.num_envs = e->cfg.num_envs; I.env_id_offset = e->cfg.env_id_offset;
+    I.env_first = 0; I.env_end = e->cfg.num_envs;
     I.key0 = (uint32_t)(e->cfg.seed & 0xffffffffu); I.key1 = (uint32_t)(e->cfg.seed >> 32);
     I.goal_lds16 = e->goal_lds16; I.obs_ext_rows = e->nobs / e->nx - 1;
     return I;
@@ -499,7 +542,7 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
 #ifdef SCG_SPEC
     e->lds_bytes = 0; e->goal_lds16 = 0;
 #else
-    e->lds_bytes = lds16(cfg_sz) + (size_t)e->goal_lds16 * 16;
+    e->lds_bytes = lds16(cfg_sz) + (size_t)e->goal_lds16 * 16;      // (kernels without disturbances stage less of it)
 #endif
     unsigned char* w = (unsigned char*)d_workspace;
     e->d_workspace = d_workspace;
@@ -597,14 +640,15 @@ static int launch_reset(scg_env* env, const uint8_t* mask, const scg_step_out* o
 }
 
 template <typename T>
-static int launch_step(scg_env* env, const void* action, const void* adv, const scg_step_out* out, hipStream_t st) {
-    const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
+static int launch_step(scg_env* env, int first, int count, const void* action, const void* adv, const scg_step_out* out, hipStream_t st) {
+    const int grid = (count + BLOCK - 1) / BLOCK;
     bool one_base;
     OutTabOne O1;
     OutTabPtr O;
     out_tabs<T>(env, out, &O1, &O, &one_base);
     const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
-    const InstParams<T> I = inst_of<T>(env);
+    InstParams<T> I = inst_of<T>(env);
+    I.env_first = first; I.env_end = first + count;
     if (one_base) {
         DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
     } else {
@@ -636,8 +680,12 @@ extern "C" int scg_reset(scg_env* env, const uint8_t* d_mask, const scg_step_out
     return rc;
 }
 
-extern "C" int scg_step(scg_env* env, const void* d_action, const void* d_adv_action, const scg_step_out* out, void* stream) {
+extern "C" int scg_step_range(scg_env* env, int first_env, int n_envs, const void* d_action, const void* d_adv_action,
+                              const scg_step_out* out, void* stream) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
+    if (first_env < 0 || n_envs <= 0 || (int64_t)first_env + n_envs > env->cfg.num_envs)
+        return fail(SCG_ERR_INVALID, "env range out of bounds");
+    if (first_env % 64 != 0) return fail(SCG_ERR_INVALID, "first_env must be a multiple of 64 (one wave = 64 envs)");
     if (!d_action) return fail(SCG_ERR_INVALID, "d_action is NULL");
     if (!out || !out->d_obs || !out->d_reward || !out->d_done || !out->d_flags)
         return fail(SCG_ERR_INVALID, "scg_step needs d_obs, d_reward, d_done and d_flags");
@@ -646,7 +694,12 @@ extern "C" int scg_step(scg_env* env, const void* d_action, const void* d_adv_ac
     // benchmark_env.py:230-235: "You must call env.reset() at least once before using env.step()."
     if (!env->has_reset) return fail(SCG_ERR_STATE, "scg_reset (all envs) must be called before scg_step");
     HIP_TRY(hipSetDevice(env->device));
-    return SCG_BY_DTYPE(env, launch_step, env, d_action, d_adv_action, out, (hipStream_t)stream);
+    return SCG_BY_DTYPE(env, launch_step, env, first_env, n_envs, d_action, d_adv_action, out, (hipStream_t)stream);
+}
+
+extern "C" int scg_step(scg_env* env, const void* d_action, const void* d_adv_action, const scg_step_out* out, void* stream) {
+    if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
+    return scg_step_range(env, 0, env->cfg.num_envs, d_action, d_adv_action, out, stream);
 }
 
 extern "C" int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_out* out, void* stream) {

@@ -93,6 +93,16 @@ struct HotRand {
     T p0, p1;
 };
 
+// One disturbance of a channel list, hot copy (DevDist without the fields only the host needs).  Lives at the END of
+// CfgParams: kernels without disturbances (DIST = false) never stage it into LDS, specialised builds read it as
+// compile-time constants (kind / mask / magnitude branches fold, loops over the list and the dimensions unroll).
+template <typename T>
+struct HotDist {
+    int32_t kind, step_offset, max_step, offset_slot;       // offset_slot: row of the per-env offset table, -1 = fixed offset
+    T half_duration, decay_rate, two_pi_freq;
+    T a[SCG_MAX_STATE], b[SCG_MAX_STATE], mask[SCG_MAX_STATE];
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Hot-path parameters.
 //
@@ -141,6 +151,7 @@ struct CfgParams {
     HotRand<T> param_rand[SCG_MAX_PARAM];
     HotRand<T> init_rand[SCG_MAX_STATE];
     BoxRow<T> box[SCG_MAX_CON_ROWS];     // sorted by variable slot, state rows first
+    HotDist<T> dist[3][SCG_MAX_DISTURB]; // must stay the last member (see HotDist)
 };
 
 constexpr uint32_t SCG_NO_OFF = 0xffffffffu;
@@ -152,8 +163,9 @@ struct InstParams {
     // Per-env simulator arrays all live in the caller's workspace: ONE buffer resource (`ws`) and a 32-bit byte
     // offset per array (SCG_NO_OFF = absent), see Slot in scg_env_core.h.
     char* ws;
-    uint32_t state_off, param_off, step_off, episode_off, oob_off;
+    uint32_t state_off, param_off, step_off, episode_off, oob_off, dist_off;
     int32_t num_envs, env_id_offset;
+    int32_t env_first, env_end; // env range [env_first, env_end) this launch advances (sub-shard launches; whole batch: 0, N)
     uint32_t key0, key1;
     int32_t goal_lds16;         // generic build: number of 16-byte chunks of x_goal staged into LDS (0 = read from global)
     int32_t obs_ext_rows;       // obs_dim / state_dim - 1 (needed before the parameter block is staged)

@@ -292,6 +292,22 @@ class HipVecEnv(VecEnv):
                                        C.byref(c_out if c_out is not None else self._c_out), self._stream()))
         return out if out is not None else self.out
 
+    def step_range_tensors(self, first, count, actions, adv_actions=None, out=None, c_out=None):
+        """The control step for envs [first, first + count) only (scg_step_range): `actions` (and every output) are the
+        full [N, ...] tensors, only that range's rows are read / written.  Disjoint ranges may be advanced from different
+        streams concurrently (sub-shard launches: one range's launch latency overlaps another's)."""
+        a = actions
+        if a.dtype != self.dtype or a.device != self.device or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=self.dtype).contiguous()
+        adv_ptr = None
+        if adv_actions is not None:
+            adv = adv_actions.to(device=self.device, dtype=self.dtype).contiguous()
+            adv_ptr = C.c_void_p(adv.data_ptr())
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.scg_step_range(self._h, int(first), int(count), C.c_void_p(a.data_ptr()), adv_ptr,
+                                               C.byref(c_out if c_out is not None else self._c_out), self._stream()))
+        return out if out is not None else self.out
+
     def bind_outputs(self, **tensors):
         """A (StepTensors, StepOut) pair whose listed fields point at caller-owned tensors (e.g. slices of a
         rollout buffer) and whose other fields alias this env's default output buffers."""

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Compile (here, on CPU — hipcc cross-compiles) the config-specialised libraries the GPU tests ask for, so that the
+GPU box finds them in the snapshot instead of spending GPU-minutes in hipcc: every golden rollout config in both dtypes,
+plus their `integrator: rk4` variants where the test uses them.  usage: prebuild_specs.py [jobs]"""
+import glob
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def configs():
+    import numpy as np
+    out = []
+    for p in sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', 'rollout_*.npz'))):
+        meta = json.loads(str(np.load(p)['meta_json']))
+        cfg = dict(meta['config'])
+        cfg.pop('seed', None)
+        out.append((meta['task'], cfg))
+    return out
+
+
+def main():
+    jobs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    from safe_control_gym_amd import _lib
+    from safe_control_gym_amd.env_config import EnvSpec
+    _lib.lib()
+    todo = {}
+    for task, cfg in configs():
+        variants = [cfg]
+        if not cfg.get('disturbances') and not cfg.get('adversary_disturbance'):
+            variants.append(dict(cfg, integrator='rk4'))
+        for c in variants:
+            for dt in (_lib.F32, _lib.F64):
+                try:
+                    cc, _ = EnvSpec(task, dict(c)).to_c_config(1, dt, 0)
+                except Exception:                               # noqa: BLE001  (a variant the config layer rejects)
+                    continue
+                _, h = _lib.spec_source(cc)
+                todo[h] = cc
+    with ThreadPoolExecutor(jobs) as ex:
+        for so in ex.map(_lib.build_spec, todo.values()):
+            print(os.path.basename(so), flush=True)
+    print(f'{len(todo)} specialisations present')
+
+
+if __name__ == '__main__':
+    main()
