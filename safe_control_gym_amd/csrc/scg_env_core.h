@@ -37,7 +37,7 @@
 
 // box-constraint loop: fully unrolled when the row table is a compile-time constant (specialised build)
 #ifndef SCG_Q3_UNROLL
-#define SCG_Q3_UNROLL 4     // substeps of the packed 3-D integrator per loop iteration (specialised build)
+#define SCG_Q3_UNROLL 5     // substeps of the packed 3-D integrator per loop iteration (specialised build)
 #endif
 #ifdef SCG_SPEC
 #define SCG_BOX_UNROLL _Pragma("unroll")
@@ -591,7 +591,8 @@ struct EnvOps {
 
     // Reset one env (Quadrotor.reset / CartPole.reset).  Increments the episode index, draws disturbance
     // offsets, inertial parameters and the initial state (each addressed by its own Philox counter).
-    __device__ static __forceinline__ void reset(const PV<T>& P, int i, E& e, RngKey key) {
+    // st_out (optional): env.state of the fresh episode (what state_vector(e, .) would return).
+    __device__ static __forceinline__ void reset(const PV<T>& P, int i, E& e, RngKey key, T* st_out = nullptr) {
         e.episode += 1u;
         e.step = 0;
         if constexpr (DIST) {
@@ -670,7 +671,23 @@ SCG_DIST_UNROLL
             euler_to_quat(iv[6], iv[7], iv[8], &e.s[3]);             // quat from (phi, theta, psi)
             e.s[7] = iv[1]; e.s[8] = iv[3]; e.s[9] = iv[5];         // vel
             e.s[10] = iv[9]; e.s[11] = iv[10]; e.s[12] = iv[11];    // p,q,r applied as WORLD rates (:379-384)
+            if constexpr (sizeof(T) == 4) {
+                // float: getEulerFromQuaternion(getQuaternionFromEuler(a)) == a to rounding while the angles are
+                // principal values away from the gimbal snap, so the Euler extraction (two atan2 + asin on the
+                // auto-reset path of every wave that holds a finished episode) is skipped; the double path keeps it.
+                if (st_out && m_abs(iv[6]) < (T)3.1 && m_abs(iv[7]) < (T)1.5 && m_abs(iv[8]) < (T)3.1) {
+                    T R[3][3];
+                    quat_to_mat(&e.s[3], R);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) st_out[k] = iv[k];
+                    st_out[9] = R[0][0] * iv[9] + R[1][0] * iv[10] + R[2][0] * iv[11];
+                    st_out[10] = R[0][1] * iv[9] + R[1][1] * iv[10] + R[2][1] * iv[11];
+                    st_out[11] = R[0][2] * iv[9] + R[1][2] * iv[10] + R[2][2] * iv[11];
+                    return;
+                }
+            }
         }
+        if (st_out) state_vector(e, st_out);
     }
 
     // Observation row: state (+ observation-channel noise) (+ angle wrap) (+ goal rows).

@@ -165,9 +165,8 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
 #endif
     Ops::load_params(P, i, e);
     const RngKey key{I.key0, I.key1};
-    Ops::reset(P, i, e, key);
     T st[D::NX];
-    Ops::state_vector(e, st);
+    Ops::reset(P, i, e, key, st);
     const OutPtrs<T> Q = out_ptrs<T>(OT, i, P.c.nobs);
     if (Q.obs) Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs);
     if (Q.c_values && P.c.n_state_con_rows > 0) Ops::constraints(P, st, st, Q.c_values, (size_t)N, true);
@@ -365,8 +364,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
         if (r.done && Q.terminal_obs) Ops::store_obs_row(P, row, nrow, Q.terminal_obs);   // (also the non-auto-reset case)
         SCG_TL(6);
         if (do_reset) {
-            Ops::reset(P, i, e, key);               // auto-reset (dummy_vec_env.py:33-38)
-            Ops::state_vector(e, st);
+            Ops::reset(P, i, e, key, st);           // auto-reset (dummy_vec_env.py:33-38)
             nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row);
         }
 #ifdef SCG_SPEC
@@ -389,8 +387,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
             Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, Q.terminal_obs, nullptr);
         SCG_TL(6);
         if (do_reset) {
-            Ops::reset(P, i, e, key);
-            Ops::state_vector(e, st);
+            Ops::reset(P, i, e, key, st);
             Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs, nullptr);
         }
     }
@@ -449,8 +446,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
             ++dones;
             if (P.c.auto_reset) {
                 dirty = true;
-                Ops::reset(P, i, e, key);
-                Ops::state_vector(e, st);
+                Ops::reset(P, i, e, key, st);
             }
         }
     }

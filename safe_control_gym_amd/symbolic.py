@@ -110,7 +110,12 @@ class AnalyticModel:
         return {'xf': x.reshape(-1, 1)}
 
     def loss(self, x, u, Xr, Ur, Q, R):
-        """0.5 (x-Xr)' Q (x-Xr) + 0.5 (u-Ur)' R (u-Ur) — quadrotor.py:578, cartpole.py:422."""
+        """The reference's `loss` Function (symbolic_systems.py:106-121) for its quadratic cost
+        l = 0.5 (x-Xr)' Q (x-Xr) + 0.5 (u-Ur)' R (u-Ur)  (quadrotor.py:578, cartpole.py:422): value, gradients and Hessians
+        with CasADi's shapes (l_x 1 x nx, l_xx nx x nx, l_u 1 x nu, l_uu nu x nu, l_xu nx x nu)."""
         ex = np.asarray(x, dtype=float).reshape(-1) - np.asarray(Xr, dtype=float).reshape(-1)
         eu = np.asarray(u, dtype=float).reshape(-1) - np.asarray(Ur, dtype=float).reshape(-1)
-        return {'l': 0.5 * ex @ np.asarray(Q) @ ex + 0.5 * eu @ np.asarray(R) @ eu}
+        Q, R = np.asarray(Q, dtype=float), np.asarray(R, dtype=float)
+        Qs, Rs = 0.5 * (Q + Q.T), 0.5 * (R + R.T)
+        return {'l': 0.5 * ex @ Q @ ex + 0.5 * eu @ R @ eu, 'l_x': (Qs @ ex).reshape(1, -1), 'l_xx': Qs,
+                'l_u': (Rs @ eu).reshape(1, -1), 'l_uu': Rs, 'l_xu': np.zeros((ex.size, eu.size))}

@@ -10,9 +10,9 @@ stand-ins:
 
 * ``gymnasium``: Env / Wrapper base classes, spaces.Box, utils.seeding.np_random
   (= Generator(PCG64(SeedSequence(seed))), as gymnasium implements it).
-* ``casadi``: a permissive symbolic mock (the CasADi prior model is built but never
-  evaluated on the rl_reward path); ``Function('loss', ...)`` evaluates the quadratic cost
-  expression the reference defines at quadrotor.py:578 / cartpole.py:422.
+* ``casadi``: tests/golden/casadi_numeric.py, a numeric implementation of the API slice the
+  reference uses (MX expression graph over NumPy, symbolic jacobian, Function, integrator):
+  the reference's OWN prior-model and cost expressions evaluate (fc / df / loss / rk_discrete).
 * ``pybullet`` / ``pybullet_data``: the ~25 API calls the two robots make, backed by the
   restated Bullet semantics in oracle/bullet.py (one body per client).  Geometry and
   inertial data are parsed from the URDF files the reference passes to loadURDF, so e.g.
@@ -30,6 +30,7 @@ import xml.etree.ElementTree as etxml
 import numpy as np
 
 REFERENCE_ROOT = '/root/reference'
+REAL_PYBULLET = False       # set by install(): fixtures come from a real pybullet wheel instead of oracle/bullet.py
 
 
 # --------------------------------------------------------------------------- #
@@ -112,48 +113,17 @@ def _make_gymnasium():
 
 
 # --------------------------------------------------------------------------- #
-# casadi
+# casadi: tests/golden/casadi_numeric.py — a NUMERIC stand-in (expression graph over NumPy with symbolic
+# differentiation), so the reference's own prior-model / cost expressions (quadrotor.py:468-604, cartpole.py:390-437,
+# symbolic_systems.py:68-121) evaluate instead of being absorbed.
 # --------------------------------------------------------------------------- #
-class _Sym:
-    """Absorbs any symbolic construction."""
-
-    def __init__(self, *a, **k):
-        pass
-
-    def _any(self, *a, **k):
-        return _Sym()
-
-    __call__ = __getattr__ = lambda self, *a, **k: _Sym()
-    for _op in ('add', 'radd', 'sub', 'rsub', 'mul', 'rmul', 'truediv', 'rtruediv', 'matmul', 'rmatmul',
-                'pow', 'rpow', 'neg', 'getitem'):
-        locals()[f'__{_op}__'] = _any
-    __array_ufunc__ = None
-
-
-def _quadratic_loss(x, Xr, u, Ur, Q, R):
-    # 0.5 (X-Xr)' Q (X-Xr) + 0.5 (U-Ur)' R (U-Ur)   (quadrotor.py:578, cartpole.py:422)
-    ex = np.asarray(x, dtype=float).reshape(-1) - np.asarray(Xr, dtype=float).reshape(-1)
-    eu = np.asarray(u, dtype=float).reshape(-1) - np.asarray(Ur, dtype=float).reshape(-1)
-    return {'l': 0.5 * ex @ np.asarray(Q, dtype=float) @ ex + 0.5 * eu @ np.asarray(R, dtype=float) @ eu}
-
-
 def _make_casadi():
-    cs = types.ModuleType('casadi')
-
-    class _MX(_Sym):
-        @staticmethod
-        def sym(*a, **k):
-            return _Sym()
-
-    def _function(name, *a, **k):
-        return _quadratic_loss if name == 'loss' else _Sym()
-
-    cs.MX = _MX
-    cs.Function = _function
-    for fn in ('vertcat', 'horzcat', 'blockcat', 'sin', 'cos', 'tan', 'sqrt', 'skew', 'integrator',
-               'jacobian', 'mtimes', 'diag', 'inv', 'DM'):
-        setattr(cs, fn, lambda *a, **k: _Sym())
-    return {'casadi': cs}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import casadi_numeric
+    mods = {}
+    casadi_numeric.install(mods)
+    return mods
 
 
 # --------------------------------------------------------------------------- #
@@ -415,7 +385,13 @@ def install():
     mods = {}
     mods.update(_make_gymnasium())
     mods.update(_make_casadi())
-    mods.update(_make_pybullet())
+    try:                                        # a machine that HAS the wheel generates the fixtures from real Bullet
+        import pybullet  # noqa: F401
+        import pybullet_data  # noqa: F401
+        global REAL_PYBULLET
+        REAL_PYBULLET = True
+    except ImportError:
+        mods.update(_make_pybullet())
     for name in ('munch', 'imageio', 'termcolor', 'dict_deep'):
         mods[name] = types.ModuleType(name)
     mods['munch'].munchify = lambda x: x
