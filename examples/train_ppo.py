@@ -42,6 +42,8 @@ def main():
                     help='honour init_state_randomization_info of the YAML (the reference class ignores it)')
     ap.add_argument('--quiet', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='eager PyTorch update / rollout instead of HIP-graph replay')
+    ap.add_argument('--no-fused-rollout', action='store_true', help='rollout / evaluation as HIP graphs of PyTorch policy + step kernel')
+    ap.add_argument('--no-fused', action='store_true', help='PyTorch (graphed) minibatch update instead of the fused MFMA kernels')
     args = ap.parse_args()
 
     import torch
@@ -56,15 +58,16 @@ def main():
     env_id, cfg = load_task(args.task)
     if args.respect_yaml_init:
         cfg['respect_randomization_info'] = True
-    env = HipVecEnv(env_id, args.envs, seed=args.seed, env_id_offset=rank * args.envs, return_numpy=False, **cfg)
+    pol = None if (args.no_fused or args.no_fused_rollout or args.no_graphs) else (args.hidden, args.activation)
+    env = HipVecEnv(env_id, args.envs, seed=args.seed, env_id_offset=rank * args.envs, return_numpy=False, policy=pol, **cfg)
     # evaluation: the config's init_state, no randomisation (how BASELINE.md's 236/250 reference reward is defined)
     eval_cfg = dict(cfg, randomized_init=False)
-    eval_env = HipVecEnv(env_id, args.eval_envs, seed=args.seed * 111, return_numpy=False, **eval_cfg)
+    eval_env = HipVecEnv(env_id, args.eval_envs, seed=args.seed * 111, return_numpy=False, policy=pol, **eval_cfg)
     pcfg = PPOConfig(hidden_dim=args.hidden, activation=args.activation, gamma=args.gamma, use_gae=True, gae_lambda=args.lam,
                      target_kl=args.target_kl, entropy_coef=args.entropy, opt_epochs=args.epochs,
                      mini_batch_size=args.minibatch, actor_lr=args.lr, critic_lr=args.critic_lr or args.lr,
                      rollout_batch_size=args.envs, rollout_steps=args.rollout_steps, max_env_steps=int(args.max_env_steps),
-                     extra={'cuda_graphs': not args.no_graphs})
+                     extra={'cuda_graphs': not args.no_graphs, 'fused_update': not args.no_fused})
     ppo = PPO(env, pcfg, seed=args.seed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -76,7 +79,7 @@ def main():
         it += 1
         res.update(ppo.episode_stats())
         if it % args.eval_every == 0:
-            ev = evaluate(ppo.agent.ac, eval_env)
+            ev = evaluate(ppo.agent.ac, eval_env, policy=ppo._policy_struct(True) if pol else None)
             res['eval_return'] = ev['ep_return']
             res['eval_length'] = ev['ep_length']
             best = max(best, ev['ep_return'])

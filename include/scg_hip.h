@@ -253,6 +253,33 @@ int scg_step_range(scg_env* env, int first_env, int n_envs, const void* d_action
  * semantics as scg_step, state kept in registers between steps. */
 int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_out* out, void* stream);
 
+/* K control steps per launch with the POLICY in the loop — the rollout collector of PPO.train_step
+ * (controllers/ppo/ppo.py:266-284) and the evaluation loop of PPO.run (:210-257) as ONE launch: per step the actor MLP
+ * obs -> H -> H -> act_dim (ppo_utils.py:149-199; exact float32 on the matrix cores), action = mean + exp(logstd) N(0,1)
+ * (Philox channel 5 of the env's stream) or the mean, log-probability, then the same control step as scg_step.
+ * Only libraries specialised for a task config AND a policy shape implement it (libscg_spec_<hash>_pol<H>_<act>.so, see
+ * safe_control_gym_amd/_lib.py); others return SCG_ERR_INVALID.  float32 envs, single-row observations. */
+typedef struct {
+    const float* d_params;          /* flat float32 parameter vector */
+    int32_t W1, b1, W2, b2, W3, b3; /* offsets (floats) of the actor's pi_net.fcs.{0,1,2}.{weight,bias} (nn.Linear layout) */
+    int32_t logstd_off;             /* offset of actor.logstd [act_dim] */
+    int32_t hidden, activation;     /* must equal the library's compiled policy shape (0 tanh | 1 relu | 2 leaky_relu) */
+    int32_t deterministic;          /* 1: action = mean (evaluation) */
+} scg_policy;
+typedef struct {
+    void* d_obs;                    /* [k + 1][N][obs_dim]: row 0 = observation of the current state, row t + 1 = after step t */
+    void* d_act;                    /* [k][N][act_dim] */
+    void* d_logp;                   /* [k][N] */
+    void* d_reward;                 /* [k][N] */
+    uint8_t* d_done;                /* [k][N] */
+    uint8_t* d_flags;               /* [k][N] bits as in scg_step_out */
+    void* d_terminal_obs;           /* [k][N][obs_dim], written where done (nullable) */
+    void* d_ep_stats;               /* [N][4] running episode totals, shared with scg_step's accumulator (nullable) */
+    void* d_episode_acc;            /* [N][8] += per finished episode: count, return, length, violation steps, mse sum, 0, 0, 0 (nullable) */
+    int32_t max_episodes;           /* > 0: an env stops adding to d_episode_acc after that many episodes (evaluation) */
+} scg_policy_rollout;
+int scg_rollout_policy(scg_env* env, const scg_policy* policy, int k_steps, const scg_policy_rollout* out, void* stream);
+
 /* Parity-test / checkpoint accessors (host side, synchronise `stream`).
  * Raw simulator state, n_state_arrays doubles per env:
  *   cartpole  x, x_dot, theta, theta_dot

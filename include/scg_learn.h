@@ -1,0 +1,84 @@
+/* scg_learn.h — C ABI of libscg_learn_<obs>_<hidden>_<act_dim>_<activation>.so: the PPO learner's hot kernels on MI355X
+ * (gfx950 matrix cores, exact float32) for ONE actor / critic shape, obs -> H -> H -> {act_dim, 1}
+ * (the reference's MLPActor / MLPCritic, /root/reference/safe_control_gym/controllers/ppo/ppo_utils.py:149-199 over
+ * math_and_models/neural_networks.py:18-54).  The library is compiled per shape from safe_control_gym_amd/csrc/scg_learn.hip
+ * with -DSCG_L_NIN= -DSCG_L_H= -DSCG_L_NU= -DSCG_L_ACT= (see safe_control_gym_amd/_learn.py), like the config-specialised
+ * simulator libraries.
+ *
+ * Conventions as in scg_hip.h: plain C types, every d_* pointer is a caller-owned DEVICE pointer (torch tensors), kernels
+ * are enqueued on the caller's hipStream_t and never synchronise, 0 = ok / negative = error + scg_learn_last_error().
+ * Parameters and gradients are FLAT float32 vectors in the caller's order; scg_mlp_layout gives the offset (in floats) of
+ * each tensor of one network inside them, tensors in torch.nn.Linear layout (weight [out][in] row-major).
+ */
+#ifndef SCG_LEARN_H
+#define SCG_LEARN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t W1, b1;     /* fcs.0.weight [H][obs_dim], fcs.0.bias [H] */
+    int32_t W2, b2;     /* fcs.1.weight [H][H],       fcs.1.bias [H] */
+    int32_t W3, b3;     /* fcs.2.weight [out][H],     fcs.2.bias [out] */
+} scg_mlp_layout;
+
+/* The shape this library was compiled for (obs_dim, hidden, act_dim, activation 0 tanh | 1 relu | 2 leaky_relu). */
+void scg_learn_shape(int32_t* obs_dim, int32_t* hidden, int32_t* act_dim, int32_t* activation);
+
+/* MLP.forward on a batch (neural_networks.py:45-54): d_x [m][obs_dim] -> d_out [m][nout], nout = act_dim or 1. */
+int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m, float* d_out,
+                    void* stream);
+
+/* One minibatch of PPOAgent.update up to (and including) the gradients — replaces compute_policy_loss,
+ * compute_value_loss, both backward passes and the approx-KL of ppo_utils.py:82-131:
+ *   policy_loss = -mean(min(ratio adv, clip(ratio, 1 -+ clip_param) adv)),  ratio = exp(logp - logp_old),
+ *                 logp = Normal(actor(obs), exp(logstd)).log_prob(act).sum(-1)
+ *   entropy_loss = -sum_a (0.5 + 0.5 log 2 pi + logstd_a)         (state-independent std: ppo_utils.py:166)
+ *   value_loss  = 0.5 mean((critic(obs) - ret)^2)                  (or the clipped form with use_clipped_value)
+ * d_grad [n_params + 1] receives d(policy_loss + entropy_coef entropy_loss)/d(actor params), d(value_loss)/d(critic
+ * params) at the parameters' own offsets and approx_kl = mean(logp_old - logp) in the last slot (so that ONE data-parallel
+ * all-reduce carries gradients and the gate value); d_stats [4] = policy_loss, value_loss, entropy_loss, approx_kl.
+ * The minibatch is the rows d_idx[0..batch) of the flat rollout arrays (batch a multiple of 32).
+ * d_workspace: scg_ppo_grad_workspace_bytes(n_workgroups) bytes of scratch (per-workgroup partial gradients; the result
+ * is a deterministic sum, no global atomics).  n_workgroups: launch width per network, e.g. the CU count / 2. */
+typedef struct {
+    const float* d_params;
+    scg_mlp_layout actor, critic;
+    int32_t logstd_off;             /* offset of actor.logstd [act_dim] */
+    int32_t n_params;               /* length of the flat parameter vector */
+    const float* d_obs;             /* [M][obs_dim] */
+    const float* d_act;             /* [M][act_dim] */
+    const float* d_logp_old;        /* [M] */
+    const float* d_adv;             /* [M] (already normalised, ppo.py:300) */
+    const float* d_ret;             /* [M] */
+    const float* d_v_old;           /* [M] (clipped value loss only) */
+    const int32_t* d_idx;           /* [batch] row indices of this minibatch */
+    int32_t batch;
+    float clip_param, entropy_coef;
+    int32_t use_clipped_value;
+    int32_t n_workgroups;
+    void* d_workspace;
+    float* d_grad;                  /* [n_params + 1] */
+    float* d_stats;                 /* [4] */
+} scg_ppo_grad_args;
+size_t scg_ppo_grad_workspace_bytes(int n_workgroups);
+int scg_ppo_grad(const scg_ppo_grad_args* args, void* stream);
+
+/* The two torch.optim.Adam steps of ppo_utils.py:126-138 on flat buffers (defaults: betas 0.9 / 0.999, eps 1e-8): elements
+ * [0, n_actor) belong to the actor and step only when d_g[n] (approx_kl, possibly all-reduced) <= 1.5 target_kl (or
+ * target_kl <= 0); the critic's always step.  d_steps [2]: step counts (float).  d_stats_acc [5] (nullable): running sums of
+ * d_stats [4] and of the actor steps taken. */
+int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor, float lr_critic,
+                   float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, void* stream);
+
+const char* scg_learn_last_error(void);
+const char* scg_learn_source_hash_tag(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCG_LEARN_H */

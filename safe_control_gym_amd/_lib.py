@@ -89,11 +89,21 @@ class StepOut(C.Structure):
         'd_noisy_action', 'd_ep_stats', 'd_fin_stats')]
 
 
+class Policy(C.Structure):
+    _fields_ = [('d_params', c_vp)] + [(n, c_i32) for n in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3', 'logstd_off', 'hidden',
+                                                            'activation', 'deterministic')]
+
+
+class PolicyRollout(C.Structure):
+    _fields_ = [(n, c_vp) for n in ('d_obs', 'd_act', 'd_logp', 'd_reward', 'd_done', 'd_flags', 'd_terminal_obs',
+                                    'd_ep_stats', 'd_episode_acc')] + [('max_episodes', c_i32)]
+
+
 class RolloutOut(C.Structure):
     _fields_ = [(n, c_vp) for n in ('d_reward_sum', 'd_done_count', 'd_violation_count', 'd_last_obs')]
 
 
-EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step', 'scg_step_range',
+EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step', 'scg_step_range', 'scg_rollout_policy',
            'scg_rollout_random', 'scg_set_state', 'scg_get_state', 'scg_set_params', 'scg_get_params',
            'scg_set_counters', 'scg_get_counters', 'scg_set_seed', 'scg_gae', 'scg_prior_model', 'scg_last_error', 'scg_abi_version',
            'scg_sizeof_config', 'scg_sizeof_step_out', 'scg_spec_source', 'scg_spec_hash', 'scg_source_hash']
@@ -177,6 +187,7 @@ def _bind(path):
     L.scg_step.argtypes = [c_vp, c_vp, c_vp, C.POINTER(StepOut), c_vp]
     L.scg_step_range.argtypes = [c_vp, C.c_int, C.c_int, c_vp, c_vp, C.POINTER(StepOut), c_vp]
     L.scg_rollout_random.argtypes = [c_vp, C.c_int, C.POINTER(RolloutOut), c_vp]
+    L.scg_rollout_policy.argtypes = [c_vp, C.POINTER(Policy), C.c_int, C.POINTER(PolicyRollout), c_vp]
     for fn in (L.scg_set_state, L.scg_get_state, L.scg_set_params, L.scg_get_params):
         fn.argtypes = [c_vp, C.POINTER(c_f64), C.c_int, C.c_int, c_vp]
     L.scg_set_counters.argtypes = [c_vp, C.POINTER(c_i32), C.POINTER(C.c_uint32), C.c_int, C.c_int, c_vp]
@@ -217,19 +228,29 @@ def spec_source(cfg):
     return buf.value.decode(), int(h.value)
 
 
-def spec_paths(hash_value):
-    """(header, library) of a specialisation.  Development variants: SCG_SPEC_TAG=<name> selects / builds
-    libscg_spec_<hash>_<name>.so (compiled with the extra flags in SCG_SPEC_FLAGS, e.g. -DSCG_Q3_UNROLL=20)."""
+POLICY_ACTS = {'tanh': 0, 'relu': 1, 'leaky_relu': 2}
+
+
+def spec_paths(hash_value, policy=None):
+    """(header, library) of a specialisation.  policy=(hidden, activation): the variant that also carries the fused
+    policy-in-the-loop rollout kernel (scg_rollout_policy) for that actor shape.  Development variants: SCG_SPEC_TAG=<name>
+    selects / builds libscg_spec_<hash>_<name>.so (compiled with the extra flags in SCG_SPEC_FLAGS)."""
     tag = f'{hash_value:016x}'
     var = os.environ.get('SCG_SPEC_TAG', '')
+    pol = f'_pol{policy[0]}_{policy[1]}' if policy else ''
     return (os.path.join(SPEC_DIR, f'scg_spec_{tag}.h'),
-            os.path.join(SPEC_DIR, f'libscg_spec_{tag}{"_" + var if var else ""}.so'))
+            os.path.join(SPEC_DIR, f'libscg_spec_{tag}{pol}{"_" + var if var else ""}.so'))
 
 
-def build_spec(cfg, force=False, verbose=False):
-    """Compile libscg_spec_<hash>.so: the same sources with this task config as compile-time constants."""
+def policy_supported(obs_dim, hidden, act_dim, activation):
+    return 1 <= obs_dim <= 32 and hidden in (32, 64, 96, 128) and 1 <= act_dim <= 4 and activation in POLICY_ACTS
+
+
+def build_spec(cfg, force=False, verbose=False, policy=None):
+    """Compile libscg_spec_<hash>.so: the same sources with this task config as compile-time constants
+    (policy=(hidden, activation): + the fused policy rollout kernel for that actor shape)."""
     src, h = spec_source(cfg)
-    hdr, so = spec_paths(h)
+    hdr, so = spec_paths(h, policy)
     os.makedirs(SPEC_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
     if not force and os.path.exists(so) and _lib_source_hash(so) == source_hash():
@@ -238,7 +259,10 @@ def build_spec(cfg, force=False, verbose=False):
         f.write(src)
     hipcc = _hipcc()
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSCG_SPEC', '-include', hdr,
-           f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL', '-o', so] + os.environ.get('SCG_SPEC_FLAGS', '').split() + srcs
+           f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL', '-o', so] + os.environ.get('SCG_SPEC_FLAGS', '').split()
+    if policy:
+        cmd += [f'-DSCG_POLICY_H={int(policy[0])}', f'-DSCG_POLICY_ACT={POLICY_ACTS[policy[1]]}']
+    cmd += srcs
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -247,20 +271,21 @@ def build_spec(cfg, force=False, verbose=False):
     return so
 
 
-def lib_for(cfg, specialize='auto'):
+def lib_for(cfg, specialize='auto', policy=None):
     """Library to drive an env with this config: the matching specialised build when it exists in-tree
-    (or, with specialize=True, after compiling it now), else the generic library."""
-    if specialize in (False, 'off', None):
+    (or, with specialize=True, after compiling it now), else the generic library.  policy=(hidden, activation) asks for
+    the variant with the fused policy rollout; it is compiled on demand (it cannot come from the generic library)."""
+    if specialize in (False, 'off', None) and not policy:
         return lib(), False
     _, h = spec_source(cfg)
-    key = (h, os.environ.get('SCG_SPEC_TAG', ''))
+    key = (h, os.environ.get('SCG_SPEC_TAG', ''), tuple(policy) if policy else None)
     if key in _spec_libs:
         return _spec_libs[key], True
-    _, so = spec_paths(h)
+    _, so = spec_paths(h, policy)
     stale = os.path.exists(so) and _lib_source_hash(so) != source_hash()
     if not os.path.exists(so) or stale:
-        if specialize is True or specialize == 'build' or (stale and os.path.exists(_hipcc())):
-            build_spec(cfg, force=True)     # (stale: the kernel sources changed since this specialisation was compiled)
+        if policy or specialize is True or specialize == 'build' or (stale and os.path.exists(_hipcc())):
+            build_spec(cfg, force=True, policy=policy)     # (stale: the kernel sources changed since it was compiled)
         else:
             return lib(), False             # never run kernels of older sources: the generic library was checked by lib()
     L = _bind(so)

@@ -19,6 +19,9 @@
 #include <hip/hip_runtime.h>
 
 #include "scg_env_core.h"
+#if defined(SCG_SPEC) && defined(SCG_POLICY_H)
+#include "scg_mlp.h"
+#endif
 
 namespace scg {
 
@@ -461,6 +464,168 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
     }
     Ops::store(P, i, e, dirty);
 }
+
+#if defined(SCG_SPEC) && defined(SCG_POLICY_H)
+// ---------------------------------------------------------------------------------------------------------------
+// K control steps per launch WITH THE POLICY IN THE LOOP (PPO.train_step's collector, controllers/ppo/ppo.py:266-284, and
+// PPO.run's evaluation loop, :210-257): per step, for the 64 envs of a wave, the actor MLP obs -> H -> H -> act_dim
+// (ppo_utils.py:149-199) runs on the matrix cores in exact float32 (scg_mlp.h), the action is sampled
+// (mean + exp(logstd) N(0,1), Philox channel 5) or taken as the mean, the env steps (same EnvOps::step as scg_step, state
+// in registers), and the rollout-buffer rows of step t are written: obs[t], act[t], logp[t], rew[t], done[t], flags[t],
+// terminal_obs[t] where done.  The critic is NOT evaluated here: values of all (t, env) rows are one batched
+// scg_mlp_forward over the finished obs buffer (full-chip MFMA instead of one wave per SIMD).
+// Built only into libscg_spec_<hash>_pol<H>_<act>.so (-DSCG_POLICY_H= -DSCG_POLICY_ACT=): obs_dim and act_dim are the
+// specialised config's, the hidden width and activation the policy's.
+// One launch replaces K x (policy forward, sampling, log-prob, scg_step, episode statistics) launches; with 65 536 envs the
+// per-step cost is the actor's ~290 MFMA issues per 32 envs (15 us) + the 2.5 us of in-register simulation.
+struct PolicyArgs {
+    const float* params; int32_t W1, b1, W2, b2, W3, b3, logstd_off; int32_t deterministic;
+    int32_t k_steps;
+    float* obs; float* act; float* logp; float* reward; uint8_t* done; uint8_t* flags; float* terminal_obs;
+    float* ep_stats; float* episode_acc; int32_t max_episodes;
+};
+constexpr uint32_t RNG_CH_POLICY = 5;
+
+template <int SYS, bool DIST>
+__global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<float> I, const PolicyArgs A) {
+    using T = float;
+    using Ops = EnvOps<SYS, T, DIST>;
+    using D = Dims<SYS>;
+    constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();
+    constexpr int NIN = kcfg.nobs, NU = D::NU, HID = SCG_POLICY_H, ACT = SCG_POLICY_ACT;
+    static_assert(NIN == D::NX || NIN == 2 * D::NX, "the fused rollout serves single-row observations (goal horizon <= 1)");
+    using L = MlpLds<NIN, HID, NU, 16>;
+    constexpr int L1Q = L::L1Q;
+    extern __shared__ __align__(16) float lds[];
+    unsigned char* const s_obs = reinterpret_cast<unsigned char*>(lds + L::END);       // [4 waves][64 rows][NIN] transpose scratch
+    const PV<T> P{kcfg, I};
+    const GoalTab<T> goal{nullptr, I.x_goal, false};
+    {
+        const MlpWeights w{A.params + A.W1, A.params + A.b1, A.params + A.W2, A.params + A.b2, A.params + A.W3, A.params + A.b3};
+        mlp_fill_lds<NIN, HID, NU, 16>(lds, w, threadIdx.x, blockDim.x);
+    }
+    __syncthreads();
+    const int N = I.num_envs;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i0 < N;
+    const int i = live ? i0 : N - 1;                  // surplus lanes shadow the last env (they take part in the MFMAs, never store)
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const bool full_wave = (blockIdx.x * 256 + (threadIdx.x & ~63) + 64) <= N;
+    unsigned char* const s_wave = s_obs + (threadIdx.x >> 6) * (64 * NIN * (int)sizeof(T));
+    typename Ops::E e;
+    Ops::load_state(P, i, e);
+    Ops::load_params(P, i, e);
+    const RngKey key{I.key0, I.key1};
+    float ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (A.ep_stats) slot(A.ep_stats, i, 4).template load_row<4>(ep);
+    if (A.episode_acc) slot(A.episode_acc, i, 8).template load_row<8>(acc);
+    float logstd[NU], sigma[NU], logp_const = 0.0f;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+        logstd[a] = A.params[A.logstd_off + a];
+        sigma[a] = __expf(logstd[a]);
+        logp_const -= logstd[a] + 0.91893853320467274f;
+    }
+    // observation of the current state (what the previous step / reset returned)
+    T st[D::NX], row[2 * D::NX];
+    Ops::state_vector(e, st);
+    {
+        const bool fresh = e.step == 0;
+        const int32_t c0 = e.step - 1;
+        Ops::obs_row(P, goal, st, e, key, fresh ? 1 : c0 + 2, fresh ? 0u : (uint32_t)(c0 + 1), fresh ? 0 : c0, i, nullptr, row);
+    }
+    bool dirty = false;
+    for (int t = 0; t <= A.k_steps; ++t) {
+        // ---- rollout row obs[t]
+        {
+            const Slot<T> dst = slot(A.obs + (size_t)t * N * NIN, i, NIN);
+            if (full_wave) store_rows_coalesced<T, NIN>(dst, row, s_wave, lane);
+            else if (live) dst.template store_row<NIN>(row);
+        }
+        if (t == A.k_steps) break;
+        // ---- actor forward for the wave's two 32-env column tiles (lane (c, h) owns env 32 h + c of the wave)
+        float xo[L1Q], xr[L1Q];
+#pragma unroll
+        for (int q = 0; q < L1Q; ++q) {
+            const float a0 = d_row(q, 0) < NIN ? row[d_row(q, 0) < NIN ? d_row(q, 0) : 0] : 0.0f;
+            const float a1 = d_row(q, 1) < NIN ? row[d_row(q, 1) < NIN ? d_row(q, 1) : 0] : 0.0f;
+            xo[q] = h ? a1 : a0;                                        // my own env's rows row(q, h)
+            xr[q] = __shfl_xor(h ? a0 : a1, 32, 64);                    // the partner env's rows row(q, h)
+        }
+        float mean[NU];
+        {
+            float x[L1Q], out[NU];
+            f32x16 h1[L::NT], h2[L::NT];
+#pragma unroll
+            for (int q = 0; q < L1Q; ++q) x[q] = h == 0 ? xo[q] : xr[q];                // column tile 0: envs 0..31 of the wave
+            mlp_forward_tile<NIN, HID, NU, ACT, 16>(lds, x, h1, h2, out, lane);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) mean[a] = out[a];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < L1Q; ++q) x[q] = h == 1 ? xo[q] : xr[q];                // column tile 1: envs 32..63
+            mlp_forward_tile<NIN, HID, NU, ACT, 16>(lds, x, h1, h2, out, lane);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) mean[a] = h ? out[a] : mean[a];
+        }
+        // ---- action and its log-probability (ppo_utils.py:224-231; distributions.py:12-22)
+        T act[NU];
+        float logp = logp_const;
+        if (A.deterministic) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) act[a] = mean[a];
+        } else {
+            const U4 w = rng_words(key, e.gid, e.episode, (uint32_t)e.step, rng_tag(RNG_CH_POLICY, 0, 0));
+            float eps[4];
+            {
+                const float r0 = m_sqrt(-2.0f * m_log(u01<float>(w.x))), u0 = u01<float>(w.y);
+                eps[0] = r0 * cos_2pi(u0);
+                eps[1] = r0 * cos_2pi(u0 < 0.25f ? u0 + 0.75f : u0 - 0.25f);        // sin(2 pi u) = cos(2 pi (u - 1/4))
+                const float r1 = m_sqrt(-2.0f * m_log(u01<float>(w.z))), u1 = u01<float>(w.w);
+                eps[2] = r1 * cos_2pi(u1);
+                eps[3] = r1 * cos_2pi(u1 < 0.25f ? u1 + 0.75f : u1 - 0.25f);
+            }
+#pragma unroll
+            for (int a = 0; a < NU; ++a) {
+                act[a] = __builtin_fmaf(sigma[a], eps[a], mean[a]);
+                logp -= 0.5f * eps[a] * eps[a];
+            }
+        }
+        // ---- the control step (identical code to scg_step's kernel)
+        const int32_t c0 = e.step;
+        T noisy[NU];
+        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, slot((T*)nullptr, 0), 0);
+        const size_t tn = (size_t)t * N + i;
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) A.act[tn * NU + a] = act[a];
+            A.logp[tn] = logp;
+            A.reward[tn] = r.reward;
+            A.done[tn] = r.done ? 1 : 0;
+            A.flags[tn] = r.flags;
+        }
+        ep[0] += r.reward; ep[1] += 1.0f; ep[2] += (r.flags & FLAG_VIOLATION) ? 1.0f : 0.0f; ep[3] += r.mse;
+        Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, nullptr, row);
+        if (r.done) {
+            if (A.terminal_obs && live) slot(A.terminal_obs + (size_t)t * N * NIN, i, NIN).template store_row<NIN>(row);
+            if (A.max_episodes <= 0 || acc[0] < (float)A.max_episodes) {
+                acc[0] += 1.0f; acc[1] += ep[0]; acc[2] += ep[1]; acc[3] += ep[2]; acc[4] += ep[3];
+            }
+            ep[0] = ep[1] = ep[2] = ep[3] = 0.0f;
+            if (P.c.auto_reset) {
+                dirty = true;
+                Ops::reset(P, i, e, key, st);
+                Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, nullptr, row);
+            }
+        }
+    }
+    if (live) {
+        if (A.ep_stats) slot(A.ep_stats, i, 4).template store_row<4>(ep);
+        if (A.episode_acc) slot(A.episode_acc, i, 8).template store_row<8>(acc);
+        Ops::store(P, i, e, dirty);
+    }
+}
+#endif  // SCG_SPEC && SCG_POLICY_H
 
 // Batched prior-model services (symbolic_systems.py:68-121: fc_func, df_func, fd_func) for model-based controllers that
 // linearise / roll out the prior at many points (LQR/iLQR gains along a trajectory, GP-MPC data collection): one thread

@@ -710,6 +710,41 @@ extern "C" int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_o
     return SCG_BY_DTYPE(env, launch_rollout, env, k_steps, out, (hipStream_t)stream);
 }
 
+extern "C" int scg_rollout_policy(scg_env* env, const scg_policy* pol, int k_steps, const scg_policy_rollout* out, void* stream) {
+    if (!env || !pol || !out) return fail(SCG_ERR_INVALID, "NULL argument to scg_rollout_policy");
+#if defined(SCG_SPEC) && defined(SCG_POLICY_H) && SCG_SPEC_DTYPE == 0
+    if (k_steps <= 0) return fail(SCG_ERR_INVALID, "k_steps must be positive");
+    if (!env->has_reset) return fail(SCG_ERR_STATE, "scg_reset (all envs) must be called before scg_rollout_policy");
+    if (pol->hidden != SCG_POLICY_H || pol->activation != SCG_POLICY_ACT)
+        return fail(SCG_ERR_INVALID, "this library was compiled for another policy shape (hidden / activation)");
+    if (!pol->d_params || !out->d_obs || !out->d_act || !out->d_logp || !out->d_reward || !out->d_done || !out->d_flags)
+        return fail(SCG_ERR_INVALID, "scg_rollout_policy needs d_params, d_obs, d_act, d_logp, d_reward, d_done and d_flags");
+    if (((uintptr_t)out->d_obs | (uintptr_t)out->d_terminal_obs | (uintptr_t)out->d_ep_stats | (uintptr_t)out->d_episode_acc) & 15)
+        return fail(SCG_ERR_INVALID, "row outputs must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(env->device));
+    constexpr int S = SCG_SPEC_SYS;
+    constexpr bool DD = SCG_SPEC_DIST != 0;
+    PolicyArgs A;
+    A.params = pol->d_params; A.W1 = pol->W1; A.b1 = pol->b1; A.W2 = pol->W2; A.b2 = pol->b2; A.W3 = pol->W3; A.b3 = pol->b3;
+    A.logstd_off = pol->logstd_off; A.deterministic = pol->deterministic; A.k_steps = k_steps;
+    A.obs = (float*)out->d_obs; A.act = (float*)out->d_act; A.logp = (float*)out->d_logp; A.reward = (float*)out->d_reward;
+    A.done = out->d_done; A.flags = out->d_flags; A.terminal_obs = (float*)out->d_terminal_obs;
+    A.ep_stats = (float*)out->d_ep_stats; A.episode_acc = (float*)out->d_episode_acc; A.max_episodes = out->max_episodes;
+    const InstParams<float> I = inst_of<float>(env);
+    constexpr int nobs = scg_make_spec_cfg<float>().nobs;
+    const size_t bytes = MlpLds<nobs, SCG_POLICY_H, Dims<S>::NU, 16>::END * sizeof(float) + 4 * 64 * nobs * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const int grid = (env->cfg.num_envs + 255) / 256;
+    rollout_policy_kernel<S, DD><<<dim3(grid), dim3(256), bytes, (hipStream_t)stream>>>(I, A);
+    HIP_TRY(hipGetLastError());
+    return SCG_OK;
+#else
+    (void)k_steps; (void)stream;
+    return fail(SCG_ERR_INVALID, "scg_rollout_policy needs a library specialised for the task config and the policy shape "
+                                 "(float32): build it with _lib.build_spec(cfg, policy=(hidden, activation))");
+#endif
+}
+
 // ---- host accessors ---------------------------------------------------------------------------
 template <typename T>
 static int copy_soa(scg_env* env, void* d_base, int n_arrays, double* h_out, const double* h_in, int first, int n, hipStream_t st) {

@@ -1,0 +1,535 @@
+// scg_learn.hip — the PPO learner's hot kernels for ONE network shape, compiled per shape like the config-specialised
+// simulator builds:   hipcc -DSCG_L_NIN=<obs_dim> -DSCG_L_H=<hidden> -DSCG_L_NU=<act_dim> -DSCG_L_ACT=<0 tanh|1 relu|2 leaky>
+//                     -> libscg_learn_<nin>_<h>_<nu>_<act>.so   (C ABI: include/scg_learn.h)
+//
+// Replaces, for the actor / critic pair of controllers/ppo/ppo_utils.py (MLPActor / MLPCritic: obs -> H -> H -> out):
+//   scg_mlp_forward      MLP.forward on a batch                          (neural_networks.py:45-54)
+//   scg_ppo_grad         one minibatch of PPOAgent.update up to the gradients: compute_policy_loss + compute_value_loss
+//                        (ppo_utils.py:82-111) forward, backward through both networks, approx-KL — ONE launch
+//   scg_adam_gated       the two Adam steps with the approx-KL gate on the actor (ppo_utils.py:126-138)
+// All arithmetic is float32; the matrix products run on v_mfma_f32_32x32x2_f32 (exact f32, scg_mlp.h).
+//
+// scg_ppo_grad, per workgroup (4 waves, one per SIMD; blockIdx.y selects actor / critic):
+//   * the network's parameters are packed into LDS once (scg_mlp.h layouts);
+//   * each wave walks over 32-sample column tiles of the minibatch: forward (activations stay in registers), loss
+//     derivatives, backward data gradients through the same LDS image, weight gradients:
+//       - dW2 (H x H, the bulk): MFMA over sample pairs, accumulated over ALL the wave's tiles in 16 H^2 / 1024
+//         accumulator registers (256 for H = 128: the AGPR half of the unified file at one wave per SIMD);
+//       - dW1, dW3, biases, log-std: small — vector unit on transposed tiles, accumulated in LDS with ds_add_f32;
+//   * at the end the four waves' dW2 accumulators are summed through LDS and the workgroup writes ONE partial gradient
+//     vector; ppo_reduce_kernel sums the partials of all workgroups into the flat gradient buffer (+ the approx-KL slot
+//     that the data-parallel all-reduce carries), deterministic: no global atomics anywhere.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/scg_learn.h"
+#include "scg_mlp.h"
+
+#ifndef SCG_L_NIN
+#error "compile with -DSCG_L_NIN= -DSCG_L_H= -DSCG_L_NU= -DSCG_L_ACT="
+#endif
+
+using namespace scg;
+
+constexpr int NIN = SCG_L_NIN, HID = SCG_L_H, NU = SCG_L_NU, ACT = SCG_L_ACT;
+constexpr int NT = HID / 32;
+constexpr int NINP = (NIN + 3) / 4 * 4;                 // padded input row in the LDS sample cache
+constexpr int WAVES = 4;                                // waves per workgroup of the gradient kernel
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+extern "C" const char* scg_learn_last_error(void) { return g_err.c_str(); }
+extern "C" void scg_learn_shape(int32_t* nin, int32_t* hidden, int32_t* nu, int32_t* act) {
+    *nin = NIN; *hidden = HID; *nu = NU; *act = ACT;
+}
+#ifndef SCG_SRC_HASH
+#define SCG_SRC_HASH 0ULL
+#endif
+#define SCG_STR2(x) #x
+#define SCG_STR(x) SCG_STR2(x)
+extern "C" const char* scg_learn_source_hash_tag(void) { return "SCG_SRC_HASH:" SCG_STR(SCG_SRC_HASH); }
+
+#define HIP_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) return fail(-2, std::string(#e) + ": " + hipGetErrorString(_e)); } while (0)
+
+__host__ __device__ static inline MlpWeights weights_of(const float* p, const scg_mlp_layout& L) {
+    return MlpWeights{p + L.W1, p + L.b1, p + L.W2, p + L.b2, p + L.W3, p + L.b3};
+}
+
+// ------------------------------------------------------------------ input operands of a column tile
+// x[q] = obs[sample][row(q, h)] for q < L1Q (rows >= NIN are zero).
+template <int L1Q>
+__device__ __forceinline__ void load_x(const float* __restrict__ obs, int sample, int h, float* x) {
+#pragma unroll
+    for (int g = 0; g < L1Q / 4; ++g) {
+        const int r0 = 8 * g + 4 * h;
+        if constexpr (NIN % 4 == 0) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (r0 < NIN) v = *reinterpret_cast<const f32x4*>(obs + (size_t)sample * NIN + r0);
+            x[4 * g + 0] = v.x; x[4 * g + 1] = v.y; x[4 * g + 2] = v.z; x[4 * g + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[4 * g + r] = (r0 + r < NIN) ? obs[(size_t)sample * NIN + r0 + r] : 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ batched forward (inference / tests)
+template <int NOUT>
+__global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
+                                                          const float* __restrict__ xin, int M, float* __restrict__ out) {
+    using L = MlpLds<NIN, HID, NOUT>;
+    extern __shared__ __align__(16) float lds[];
+    const MlpWeights w = weights_of(params, lay);
+    mlp_fill_lds<NIN, HID, NOUT>(lds, w, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int n_tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * (blockDim.x >> 6) + wave; tile < n_tiles; tile += gridDim.x * (blockDim.x >> 6)) {
+        int s = tile * 32 + c;
+        const bool live = s < M;
+        s = live ? s : M - 1;
+        float x[L::L1Q];
+        load_x<L::L1Q>(xin, s, h, x);
+        f32x16 h1[NT], h2[NT];
+        float o[NOUT];
+        mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, o, lane);
+        if (live && h == 0) {
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) out[(size_t)s * NOUT + k] = o[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ PPO minibatch gradients
+// Small-gradient block in LDS (float words) for a network with NOUT outputs.
+template <int NOUT>
+struct GradLds {
+    static constexpr int DW1 = 0;                       // [NIN][H]
+    static constexpr int DB1 = DW1 + NIN * HID;
+    static constexpr int DB2 = DB1 + HID;
+    static constexpr int DW3 = DB2 + HID;               // [NOUT][H]
+    static constexpr int DB3 = DW3 + NOUT * HID;
+    static constexpr int DLS = DB3 + 4;                 // d log-std (actor)
+    static constexpr int STAT = DLS + 4;                // loss sum, approx-KL sum (x 1 / B)
+    static constexpr int END = STAT + 4;
+};
+// Per-workgroup partial vector, identical order for both networks (NOUT <= 4 padded to its own NOUT):
+//   [dW1 NIN*H ([in][out])] [db1 H] [db2 H] [dW3 NOUT*H] [db3 4] [dlogstd 4] [stats 4] [dW2 staging H*H]
+template <int NOUT> constexpr int partial_small() { return GradLds<NOUT>::END; }
+template <int NOUT> constexpr int partial_words() { return GradLds<NOUT>::END + HID * HID; }
+constexpr int PARTIAL_STRIDE = partial_words<(NU > 1 ? NU : 1)>();      // actor's is the longer one
+
+struct GradArgs {
+    const float* params; scg_mlp_layout actor, critic; int logstd_off;
+    const float* obs; const float* act; const float* logp_old; const float* adv; const float* ret; const float* v_old;
+    const int32_t* idx; int batch;
+    float clip_param; int use_clipped_value;
+    float* partials;                                    // [gridDim.x][2][PARTIAL_STRIDE]
+};
+
+template <int NOUT, bool ACTOR>
+__device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
+    using L = MlpLds<NIN, HID, NOUT>;
+    using G = GradLds<NOUT>;
+    constexpr int L1Q = L::L1Q;
+    float* const gl = lds + L::END;                                     // small gradients
+    float* const xs_all = gl + G::END;                                  // [WAVES][32][NINP]
+    float* const dout_all = xs_all + WAVES * 32 * NINP;                 // [WAVES][NOUT][32]
+    float* const scr_all = dout_all + WAVES * 4 * 32;                   // [WAVES][32 * 33]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const MlpWeights w = weights_of(A.params, ACTOR ? A.actor : A.critic);
+    mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid, blockDim.x);
+    for (int k = tid; k < G::END; k += blockDim.x) gl[k] = 0.0f;
+    __syncthreads();
+    float* const xs = xs_all + wave * 32 * NINP;
+    float* const dout_l = dout_all + wave * 4 * 32;
+    float* const scr = scr_all + wave * 32 * 33;
+    float logstd[NOUT], inv_std[NOUT];
+    if constexpr (ACTOR) {
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) { logstd[a] = A.params[A.logstd_off + a]; inv_std[a] = __expf(-logstd[a]); }
+    }
+    const float inv_b = 1.0f / (float)A.batch;
+    float st_loss = 0.0f, st_kl = 0.0f, dls[NOUT];
+#pragma unroll
+    for (int a = 0; a < NOUT; ++a) dls[a] = 0.0f;
+    f32x16 dW2[NT][NT];                                                 // [tau (in tile)][rho (out tile)]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dW2[t][r][q] = 0.0f;
+
+    const int n_tiles = A.batch / 32;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        const int s = A.idx[tile * 32 + c];
+        float x[L1Q];
+        load_x<L1Q>(A.obs, s, h, x);
+        // sample cache for dW1: xs[c][feature]
+#pragma unroll
+        for (int g = 0; g < L1Q / 4; ++g) {
+            const int r0 = 8 * g + 4 * h;
+            if (r0 < NINP) *reinterpret_cast<f32x4*>(xs + c * NINP + r0) = (f32x4){x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+        }
+        f32x16 h1[NT], h2[NT];
+        float out[NOUT], dout[NOUT];
+        mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, out, lane);
+        // ---- loss derivatives w.r.t. the network outputs (both lane halves compute the same numbers)
+        if constexpr (ACTOR) {
+            // compute_policy_loss (ppo_utils.py:82-96): Normal(mean, exp(logstd)).log_prob(act).sum(-1), clipped surrogate
+            float logp = 0.0f, z[NOUT];
+#pragma unroll
+            for (int a = 0; a < NOUT; ++a) {
+                z[a] = (A.act[(size_t)s * NOUT + a] - out[a]) * inv_std[a];
+                logp += -0.5f * z[a] * z[a] - logstd[a] - 0.91893853320467274f;
+            }
+            const float lp_old = A.logp_old[s], adv = A.adv[s];
+            const float ratio = __expf(logp - lp_old);
+            const float lo = 1.0f - A.clip_param, hi = 1.0f + A.clip_param;
+            const float rc = fminf(fmaxf(ratio, lo), hi);
+            const float s1 = ratio * adv, s2 = rc * adv;
+            // d min(s1, s2) / d ratio: inside the clip range both terms move (torch splits the tie, the sum is adv);
+            // outside it only the unclipped term has a gradient, and only if it is the smaller one
+            const bool inside = ratio >= lo && ratio <= hi;
+            const float dsur = (inside || s1 < s2) ? adv : 0.0f;
+            const float wl = -dsur * ratio * inv_b;                     // d policy_loss / d logp
+#pragma unroll
+            for (int a = 0; a < NOUT; ++a) {
+                dout[a] = wl * z[a] * inv_std[a];                       // d logp / d mean = z / sigma
+                if (h == 0) dls[a] += wl * (z[a] * z[a] - 1.0f);        // d logp / d logstd
+            }
+            if (h == 0) { st_loss += -fminf(s1, s2) * inv_b; st_kl += (lp_old - logp) * inv_b; }
+        } else {
+            // compute_value_loss (ppo_utils.py:98-111)
+            const float v = out[0], ret = A.ret[s];
+            float dv = v - ret, l = dv * dv;
+            if (A.use_clipped_value) {
+                const float vo = A.v_old[s];
+                const float d = v - vo;
+                const float vc = vo + fminf(fmaxf(d, -A.clip_param), A.clip_param);
+                const float e2 = vc - ret, l2 = e2 * e2;
+                const float pass = (d >= -A.clip_param && d <= A.clip_param) ? 1.0f : 0.0f;
+                if (l2 > l) { dv = e2 * pass; l = l2; }
+                else if (l2 == l) dv = 0.5f * (dv + e2 * pass);
+            }
+            dout[0] = dv * inv_b;
+            if (h == 0) st_loss += 0.5f * l * inv_b;
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) { dout_l[o * 32 + c] = dout[o]; atomicAdd(gl + G::DB3 + o, dout[o]); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef DBG_NO_DW3
+        // ---- output layer backward: dW3 from the transposed h2 tiles, then dz2 = (W3^T dout) * act'(h2) in place
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            float t[16];
+            tile_transpose(scr, h2[tau], t, lane);                      // t[s'] = h2[feature 32 tau + c][sample 2 s' + h]
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + 2 * sp + h], acc);
+                acc += __shfl_xor(acc, 32, 64);
+                if (h == 0) atomicAdd(gl + G::DW3 + o * HID + 32 * tau + c, acc);
+            }
+        }
+#endif
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + L::W3 + o * HID + 32 * tau + 8 * g + 4 * h);
+                    dh[0] = __builtin_fmaf(wv.x, dout[o], dh[0]); dh[1] = __builtin_fmaf(wv.y, dout[o], dh[1]);
+                    dh[2] = __builtin_fmaf(wv.z, dout[o], dh[2]); dh[3] = __builtin_fmaf(wv.w, dout[o], dh[3]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h2[tau][4 * g + r] = dh[r] * mlp_dact<ACT>(h2[tau][4 * g + r]);
+            }
+        }
+        // (h2 now holds dz2)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- data gradient through layer 2, one input tile at a time:
+        //      dh1[tau'] = sum over (rho', q') of W2[32 rho' + row(q', h)][32 tau' + i'] dz2[rho'][q'],  dz1 = dh1 * act'(h1);
+        //      each dz1 tile is consumed at once (transposed: dW1 and db1 with the cached inputs) and never stored
+        {
+            const int ip = lane & 31;
+            const int qi = 4 * (ip >> 3) + (ip & 3), hi2 = (ip >> 2) & 1;
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+                for (int rp = 0; rp < NT; ++rp) {
+                    const float* base = lds + L::W2F + (rp * NT + tp) * L::TILE2 + 32 * hi2 * L::S + qi;
+                    float a[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a[q] = base[d_row(q, h) * L::S];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = mfma32(a[q], h2[rp][q], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[tp][q]);
+#ifndef DBG_NO_DW1
+                // transposed through the scratch: element [out 32 tp + c][sample 2 s' + h] is read back inside a ROLLED
+                // loop over the sample pairs (an unrolled one lets the compiler pull all 48 cached-input loads up front)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) scr[d_row(q, h) * 33 + c] = acc[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float sb = 0.0f, aw[NINP];
+#pragma unroll
+                for (int k = 0; k < NINP; ++k) aw[k] = 0.0f;
+#pragma unroll 1
+                for (int sp = 0; sp < 16; ++sp) {
+                    const float ts = scr[c * 33 + 2 * sp + h];
+                    sb += ts;
+#pragma unroll
+                    for (int kk = 0; kk < NINP / 4; ++kk) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (2 * sp + h) * NINP + 4 * kk);
+                        aw[4 * kk + 0] = __builtin_fmaf(ts, xv.x, aw[4 * kk + 0]); aw[4 * kk + 1] = __builtin_fmaf(ts, xv.y, aw[4 * kk + 1]);
+                        aw[4 * kk + 2] = __builtin_fmaf(ts, xv.z, aw[4 * kk + 2]); aw[4 * kk + 3] = __builtin_fmaf(ts, xv.w, aw[4 * kk + 3]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                sb += __shfl_xor(sb, 32, 64);
+                if (h == 0) atomicAdd(gl + G::DB1 + 32 * tp + c, sb);
+#pragma unroll
+                for (int k = 0; k < NINP; ++k) {
+                    const float v = aw[k] + __shfl_xor(aw[k], 32, 64);
+                    if (h == 0 && k < NIN) atomicAdd(gl + G::DW1 + k * HID + 32 * tp + c, v);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifndef DBG_NO_DW2
+        // ---- dW2 += h1 dz2^T over this tile's 32 samples (MFMA over sample pairs), db2
+#pragma unroll
+        for (int rho = 0; rho < NT; ++rho) {
+            float b[16];
+            tile_transpose(scr, h2[rho], b, lane);                      // dz2[out 32 rho + c][sample 2 s' + h]
+            float sb = 0.0f;
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp) sb += b[sp];
+            sb += __shfl_xor(sb, 32, 64);
+            if (h == 0) atomicAdd(gl + G::DB2 + 32 * rho + c, sb);
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) {
+                float a[16];
+                tile_transpose(scr, h1[tau], a, lane);                  // h1[in 32 tau + c][sample 2 s' + h]
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp) dW2[tau][rho] = mfma32(a[sp], b[sp], dW2[tau][rho]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+    }
+    // ---- workgroup reduction and the partial vector
+    if constexpr (ACTOR) {
+#pragma unroll
+        for (int a = 0; a < NOUT; ++a) {
+            float v = dls[a];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) atomicAdd(gl + G::DLS + a, v);
+        }
+    }
+    {
+        float v0 = st_loss, v1 = st_kl;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { v0 += __shfl_xor(v0, m, 64); v1 += __shfl_xor(v1, m, 64); }
+        if (lane == 0) { atomicAdd(gl + G::STAT + 0, v0); atomicAdd(gl + G::STAT + 1, v1); }
+    }
+    __syncthreads();                                                    // every wave is done with the weight image
+    float* const stg = lds + L::W2F;                                    // reuse it as the dW2 staging area (H * H words)
+    for (int k = tid; k < HID * HID; k += blockDim.x) stg[k] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+        for (int rho = 0; rho < NT; ++rho)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) atomicAdd(stg + ((tau * NT + rho) * 16 + q) * 64 + lane, dW2[tau][rho][q]);
+    __syncthreads();
+    float* const P = A.partials + ((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE;
+    for (int k = tid; k < G::END; k += blockDim.x) P[k] = gl[k];
+    for (int k = tid; k < HID * HID; k += blockDim.x) P[G::END + k] = stg[k];
+}
+
+constexpr size_t grad_lds_words() {
+    constexpr int NOUT_A = NU;
+    size_t a = MlpLds<NIN, HID, NOUT_A>::END + GradLds<NOUT_A>::END;
+    size_t c = MlpLds<NIN, HID, 1>::END + GradLds<1>::END;
+    return (a > c ? a : c) + WAVES * 32 * NINP + WAVES * 4 * 32 + WAVES * 32 * 33;
+}
+
+__global__ __launch_bounds__(64 * WAVES, 1) void ppo_grad_kernel(const GradArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    if (blockIdx.y == 0) grad_net<NU, true>(A, lds);
+    else grad_net<1, false>(A, lds);
+}
+
+// Sum of the workgroup partials -> flat gradient vector (torch parameter order) + approx-KL slot + loss statistics.
+struct ReduceArgs {
+    const float* partials; int n_wg;
+    scg_mlp_layout actor, critic; int logstd_off; int n_params;
+    float entropy_coef;
+    const float* params;
+    float* grad;            // [n_params + 1]: gradients, then approx_kl
+    float* stats;           // [4]: policy_loss, value_loss, entropy_loss, approx_kl of this minibatch
+};
+
+template <int NOUT>
+__device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay, int logstd_off, bool actor) {
+    using G = GradLds<NOUT>;
+    if (k < G::DB1) { const int in = k / HID, o = k % HID; return lay.W1 + o * NIN + in; }
+    if (k < G::DB2) return lay.b1 + (k - G::DB1);
+    if (k < G::DW3) return lay.b2 + (k - G::DB2);
+    if (k < G::DB3) return lay.W3 + (k - G::DW3);
+    if (k < G::DLS) return (k - G::DB3) < NOUT ? lay.b3 + (k - G::DB3) : -1;
+    if (k < G::STAT) return (actor && (k - G::DLS) < NOUT) ? logstd_off + (k - G::DLS) : -1;
+    if (k < G::END) return -2 - (k - G::STAT);                          // statistics slots
+    const int p = k - G::END;                                           // dW2 staging order -> W2[out][in]
+    const int lane = p & 63, q = (p >> 6) & 15, tr = p >> 10;
+    const int tau = tr / NT, rho = tr % NT;
+    return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
+}
+
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
+    const int net = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
+    if (k >= words) return;
+    float s = 0.0f;
+    for (int g = 0; g < R.n_wg; ++g) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
+    const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
+    if (d >= 0) {
+        if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
+        R.grad[d] = s;
+    } else if (d == -2) {                                   // loss sum
+        R.stats[net == 0 ? 0 : 1] = s;
+    } else if (d == -3 && net == 0) {                       // approx-KL: rides in the gradient buffer's last slot
+        R.grad[R.n_params] = s;
+        R.stats[3] = s;
+        float ent = 0.0f;                                   // entropy_loss = -sum_a (0.5 + 0.5 log(2 pi) + logstd_a)
+        for (int a = 0; a < NU; ++a) ent -= 1.4189385332046727f + R.params[R.logstd_off + a];
+        R.stats[2] = ent;
+    }
+}
+
+// Two Adam optimisers on the flat buffers (torch.optim.Adam defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay),
+// the actor's step gated by approx_kl <= 1.5 target_kl (ppo_utils.py:126-131); step counters are read here and advanced
+// by adam_count_kernel afterwards.
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; int n; int n_actor; float lr_actor, lr_critic;
+    float* steps;           // [2] actor, critic step counts (float, as the graphed torch version kept them)
+    float target_kl;
+    float* stats_acc; const float* stats;       // running sums over the update: 3 losses, kl, actor steps taken
+};
+
+__global__ __launch_bounds__(256) void adam_gated_kernel(const AdamArgs A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n) return;
+    const float kl = A.g[A.n];
+    const bool gate = A.target_kl <= 0.0f || kl <= 1.5f * A.target_kl;
+    const bool critic = e >= A.n_actor;
+    if (!critic && !gate) return;
+    const float t = (critic ? A.steps[1] : A.steps[0]) + 1.0f;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float g = A.g[e];
+    const float m = b1 * A.m[e] + (1.0f - b1) * g;
+    const float v = b2 * A.v[e] + (1.0f - b2) * g * g;
+    A.m[e] = m; A.v[e] = v;
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    const float lr = critic ? A.lr_critic : A.lr_actor;
+    A.p[e] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
+}
+
+__global__ void adam_count_kernel(const AdamArgs A) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float kl = A.g[A.n];
+    const bool gate = A.target_kl <= 0.0f || kl <= 1.5f * A.target_kl;
+    A.steps[0] += gate ? 1.0f : 0.0f;
+    A.steps[1] += 1.0f;
+    if (A.stats_acc) {
+        A.stats_acc[0] += A.stats[0]; A.stats_acc[1] += A.stats[1]; A.stats_acc[2] += A.stats[2]; A.stats_acc[3] += A.stats[3];
+        A.stats_acc[4] += gate ? 1.0f : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m,
+                               float* d_out, void* stream) {
+    if (!d_params || !layout || !d_x || !d_out || m <= 0) return fail(-1, "scg_mlp_forward: bad argument");
+    const int grid = std::min(256, (m + 127) / 128);
+    hipStream_t st = (hipStream_t)stream;
+    if (nout == NU) {
+        const size_t bytes = MlpLds<NIN, HID, NU>::END * sizeof(float);
+        HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        mlp_forward_kernel<NU><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out);
+    } else if (nout == 1) {
+        const size_t bytes = MlpLds<NIN, HID, 1>::END * sizeof(float);
+        HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        mlp_forward_kernel<1><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out);
+    } else {
+        return fail(-1, "scg_mlp_forward: this library serves nout = act_dim or 1");
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t scg_ppo_grad_workspace_bytes(int n_workgroups) { return (size_t)n_workgroups * 2 * PARTIAL_STRIDE * sizeof(float); }
+
+extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
+    if (!a || !a->d_params || !a->d_obs || !a->d_act || !a->d_logp_old || !a->d_adv || !a->d_ret || !a->d_v_old || !a->d_idx ||
+        !a->d_workspace || !a->d_grad || !a->d_stats)
+        return fail(-1, "scg_ppo_grad: NULL argument");
+    if (a->batch <= 0 || a->batch % 32 != 0) return fail(-1, "scg_ppo_grad: the minibatch size must be a positive multiple of 32");
+    if (a->n_workgroups <= 0) return fail(-1, "scg_ppo_grad: n_workgroups must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    GradArgs G;
+    G.params = a->d_params; G.actor = a->actor; G.critic = a->critic; G.logstd_off = a->logstd_off;
+    G.obs = a->d_obs; G.act = a->d_act; G.logp_old = a->d_logp_old; G.adv = a->d_adv; G.ret = a->d_ret; G.v_old = a->d_v_old;
+    G.idx = a->d_idx; G.batch = a->batch; G.clip_param = a->clip_param; G.use_clipped_value = a->use_clipped_value;
+    G.partials = (float*)a->d_workspace;
+    const size_t bytes = grad_lds_words() * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ppo_grad_kernel<<<dim3(a->n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
+    HIP_TRY(hipGetLastError());
+    ReduceArgs R;
+    R.partials = G.partials; R.n_wg = a->n_workgroups; R.actor = a->actor; R.critic = a->critic; R.logstd_off = a->logstd_off;
+    R.n_params = a->n_params; R.entropy_coef = a->entropy_coef; R.params = a->d_params; R.grad = a->d_grad; R.stats = a->d_stats;
+    ppo_reduce_kernel<<<dim3((PARTIAL_STRIDE + 255) / 256, 2), dim3(256), 0, st>>>(R);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor,
+                              float lr_critic, float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats,
+                              void* stream) {
+    if (!d_p || !d_g || !d_m || !d_v || !d_steps || n <= 0) return fail(-1, "scg_adam_gated: bad argument");
+    AdamArgs A{d_p, d_g, d_m, d_v, n, n_actor, lr_actor, lr_critic, d_steps, target_kl, d_stats_acc, d_stats};
+    hipStream_t st = (hipStream_t)stream;
+    adam_gated_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(A);
+    adam_count_kernel<<<dim3(1), dim3(64), 0, st>>>(A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -180,6 +180,15 @@ class PPOAgent:
         self._g = None
         # flatten NOW: every graph captured later (rollout and update) must see the final parameter storage
         self._flat = self._flatten() if self.use_graphs else None
+        # fused MFMA learner (csrc/scg_learn.hip): forward + backward of both networks + approx-KL in ONE launch per
+        # minibatch, a deterministic reduction and a gated Adam kernel, in place of ~100 PyTorch kernels; exact float32.
+        # Shapes it does not serve (hidden not a multiple of 32 / > 128, 3 or > 4 actions, a safety-layer action
+        # modifier) keep the PyTorch update below — chosen here, visibly, not silently at run time.
+        from safe_control_gym_amd import _learn
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
+                          and _learn.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
+        self._fused = None
 
     # ---- graphed update -------------------------------------------------------------------------------------
     def _flatten(self):
@@ -202,6 +211,92 @@ class PPOAgent:
         return {'p': flat_p, 'g': flat_g, 'm': torch.zeros(n, device=self.device), 'v': torch.zeros(n, device=self.device),
                 'lr': lr, 'is_critic': is_critic, 'n_a': n_a, 'n': n,
                 'steps': torch.zeros(2, device=self.device)}          # Adam step counts: actor, critic
+
+    # ---- fused update (scg_ppo_grad / scg_adam_gated) -------------------------------------------------------
+    def _layouts(self):
+        """Offsets of every tensor inside the flat parameter vector built by _flatten (actor parameters, then critic's)."""
+        from safe_control_gym_amd._learn import MlpLayout
+        off, table = 0, {}
+        for prefix, mod in (('actor', self.ac.actor), ('critic', self.ac.critic)):
+            for name, prm in mod.named_parameters():
+                table[f'{prefix}.{name}'] = off
+                off += prm.numel()
+        def lay(prefix, net):
+            return MlpLayout(*[table[f'{prefix}.{net}.fcs.{i}.{k}'] for i in range(3) for k in ('weight', 'bias')])
+        return lay('actor', 'pi_net'), lay('critic', 'v_net'), table['actor.logstd'], off
+
+    def _build_fused(self, data, mb):
+        import ctypes as C
+        from safe_control_gym_amd import _learn
+        cfg, dev = self.cfg, self.device
+        D = _learn.lib(self.obs_dim, cfg.hidden_dim, self.act_dim, cfg.activation)
+        F = {'lib': D, 'data': data}
+        a_lay, c_lay, ls_off, n = self._layouts()
+        assert n == self._flat['n']
+        n_wg = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 2)
+        n_wg = min(n_wg, max(1, mb // 128))                     # every wave of every workgroup gets at least one tile
+        F['ws'] = torch.empty(D.scg_ppo_grad_workspace_bytes(n_wg), dtype=torch.uint8, device=dev)
+        F['stats'] = torch.zeros(4, device=dev)
+        F['stats_acc'] = torch.zeros(5, device=dev)
+        F['idx'] = torch.zeros(mb, dtype=torch.int32, device=dev)
+        p = lambda t: t.data_ptr()                              # noqa: E731
+        F['args'] = _learn.PpoGradArgs(
+            d_params=p(self._flat['p']), actor=a_lay, critic=c_lay, logstd_off=ls_off, n_params=n,
+            d_obs=p(data['obs']), d_act=p(data['act']), d_logp_old=p(data['logp']), d_adv=p(data['adv']), d_ret=p(data['ret']),
+            d_v_old=p(data['v']), d_idx=p(F['idx']), batch=mb, clip_param=float(cfg.clip_param),
+            entropy_coef=float(cfg.entropy_coef), use_clipped_value=int(bool(cfg.use_clipped_value)), n_workgroups=n_wg,
+            d_workspace=p(F['ws']), d_grad=p(self._flat['g']), d_stats=p(F['stats']))
+        F['C'] = C
+        return F
+
+    def _fused_grad(self, F):
+        """Gradients of the minibatch F['idx'] into the flat gradient buffer (+ approx_kl in its last slot)."""
+        from safe_control_gym_amd import _learn
+        st = F['C'].c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _learn.check(F['lib'], F['lib'].scg_ppo_grad(F['C'].byref(F['args']), st))
+
+    def _fused_adam(self, F):
+        from safe_control_gym_amd import _learn
+        fl, cfg, C = self._flat, self.cfg, F['C']
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _learn.check(F['lib'], F['lib'].scg_adam_gated(
+            fl['p'].data_ptr(), fl['g'].data_ptr(), fl['m'].data_ptr(), fl['v'].data_ptr(), fl['n'], fl['n_a'],
+            float(cfg.actor_lr), float(cfg.critic_lr), fl['steps'].data_ptr(), float(cfg.target_kl),
+            F['stats_acc'].data_ptr(), F['stats'].data_ptr(), st))
+
+    def _update_fused(self, data, generator=None):
+        cfg = self.cfg
+        M = data['obs'].shape[0]
+        mb = min(cfg.mini_batch_size, M)
+        mb -= mb % 32                                           # the kernel works on 32-sample tiles (drop-last, like upstream's)
+        n_mb = M // mb
+        assert n_mb != 0, 'num_mini_batch is 0'
+        for k, v in data.items():
+            assert v.dtype == torch.float32 and v.is_contiguous(), k
+        if self._fused is None or self._fused['key'] != (M, mb):
+            static = {k: (v if k in ('obs', 'act', 'logp', 'v') else torch.empty_like(v)) for k, v in data.items()}
+            self._fused = self._build_fused(static, mb)
+            self._fused['key'] = (M, mb)
+        F = self._fused
+        for k, v in data.items():
+            if F['data'][k].data_ptr() != v.data_ptr():
+                F['data'][k].copy_(v)
+        F['stats_acc'].zero_()
+        world = parallel.world_size()
+        with torch.cuda.device(self.device):
+            for _ in range(cfg.opt_epochs):
+                perm = torch.randperm(M, device=self.device, generator=generator)[:n_mb * mb].to(torch.int32).view(n_mb, mb)
+                for j in range(n_mb):
+                    F['args'].d_idx = perm[j].data_ptr()
+                    self._fused_grad(F)
+                    if world > 1:                                   # gradients of both networks + approx_kl, one collective
+                        parallel.all_reduce_sum_(self._flat['g'])
+                        self._flat['g'].div_(world)
+                    self._fused_adam(F)
+                F['keep'] = perm                                    # (the index rows must outlive the queued launches)
+        st = (F['stats_acc'] / (cfg.opt_epochs * n_mb)).tolist()
+        return {'policy_loss': st[0], 'value_loss': st[1], 'entropy_loss': st[2], 'approx_kl': st[3],
+                'actor_steps': int(round(st[4] * cfg.opt_epochs * n_mb)), 'minibatches': cfg.opt_epochs * n_mb}
 
     def _build_graphs(self, data, mb):
         cfg = self.cfg
@@ -291,8 +386,8 @@ class PPOAgent:
 
     def state_dict(self):
         sd = {'ac': self.ac.state_dict(), 'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict()}
-        if self._g is not None:
-            sd['flat_adam'] = {k: self._g[k].clone() for k in ('m', 'v', 'steps')}
+        if self._flat is not None:      # graph / fused modes: the Adam moments live in the flat buffers (torch optimisers never step)
+            sd['flat_adam'] = {k: self._flat[k].clone() for k in ('m', 'v', 'steps')}
         return sd
 
     def load_state_dict(self, sd):
@@ -300,13 +395,18 @@ class PPOAgent:
         if 'actor_opt' in sd:
             self.actor_opt.load_state_dict(sd['actor_opt'])
             self.critic_opt.load_state_dict(sd['critic_opt'])
-        if 'flat_adam' in sd and self._g is not None:
+        if 'flat_adam' in sd and self._flat is not None:
             for k, t in sd['flat_adam'].items():
-                self._g[k].copy_(t)
+                self._flat[k].copy_(t.to(self.device))      # in place: captured graphs alias these buffers
+        elif self._flat is not None and 'actor_opt' in sd and sd['actor_opt'].get('state'):
+            raise ValueError('checkpoint carries torch.optim state only (saved with cuda_graphs off); load it with '
+                             "extra={'cuda_graphs': False} or re-save — the flat Adam moments would silently restart from zero")
 
     def update(self, data, generator=None):
         """`data`: dict of flat [M, .] tensors (obs, act, logp, adv, ret, v).  Epochs x shuffled minibatches, drop last
         (ppo_utils.py:113-146, :358-371).  Returns the reference's averaged loss statistics."""
+        if self.use_fused and self.ac.actor.action_modifier is None:
+            return self._update_fused(data, generator)
         if self.use_graphs:
             return self._update_graphed(data, generator)
         cfg = self.cfg
@@ -386,8 +486,19 @@ class PPO:
         self.obs_normalizer = MeanStdNormalizer((self.obs_dim,), self.device, clip=cfg.clip_obs) if cfg.norm_obs else BaseNormalizer()
         self.reward_normalizer = (RewardStdNormalizer(cfg.gamma, self.device, clip=cfg.clip_reward) if cfg.norm_reward
                                   else BaseNormalizer())
+        if cfg.norm_reward:         # eager: graphs captured later (and checkpoint loads, in place) share this storage
+            self.reward_normalizer.ret = torch.zeros(self.N, dtype=torch.float64, device=self.device)
         self._normalise = cfg.norm_obs or cfg.norm_reward
         self._graph_rollout = self.agent.use_graphs and not (self._normalise and parallel.world_size() > 1)
+        # fused rollout (scg_rollout_policy): the whole T-step collection is ONE launch with the actor on the matrix cores
+        # inside the env kernel; values come from one batched critic pass afterwards.  Needs an env built with this
+        # policy shape (HipVecEnv(..., policy=(hidden, activation))), the flat parameter vector, no normalisers.
+        self._fused_rollout = (self.agent.use_fused and bool(cfg.extra.get('fused_rollout', True)) and not self._normalise
+                               and getattr(env, 'policy_shape', None) == (cfg.hidden_dim, cfg.activation))
+        if self._fused_rollout:
+            self._episode_acc = torch.zeros(N, 8, **f)
+            self._v_all = torch.zeros(T + 1, N, **f)
+            self._tv = torch.zeros(T, N, **f)
         self.obs[0].copy_(self.obs_normalizer(env.reset_tensors()))
         # finished-episode statistics (VecRecordEpisodeStatistics), accumulated on device
         self.ep_count = torch.zeros((), device=self.device)
@@ -443,6 +554,46 @@ class PPO:
         moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])
         return ret, adv, moments
 
+    # ---- fused rollout front end -----------------------------------------------------------------------------
+    def _policy_struct(self, deterministic=False):
+        from safe_control_gym_amd import _lib as L
+        a_lay, _, ls_off, _ = self.agent._layouts()
+        return L.Policy(d_params=self.agent._flat['p'].data_ptr(), W1=a_lay.W1, b1=a_lay.b1, W2=a_lay.W2, b2=a_lay.b2,
+                        W3=a_lay.W3, b3=a_lay.b3, logstd_off=ls_off, hidden=self.cfg.hidden_dim,
+                        activation=L.POLICY_ACTS[self.cfg.activation], deterministic=int(deterministic))
+
+    def _critic_batch(self, x, out):
+        """out[m] = critic(x[m]) through the MFMA forward kernel (scg_mlp_forward)."""
+        import ctypes as C
+        from safe_control_gym_amd import _learn
+        D = _learn.lib(self.obs_dim, self.cfg.hidden_dim, self.act_dim, self.cfg.activation)
+        _, c_lay, _, _ = self.agent._layouts()
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _learn.check(D, D.scg_mlp_forward(self.agent._flat['p'].data_ptr(), C.byref(c_lay), 1, x.data_ptr(), int(x.shape[0]),
+                                              out.data_ptr(), st))
+
+    @torch.no_grad()
+    def _collect_fused(self):
+        """One launch for the T control steps (policy inside), two batched critic passes, scg_gae."""
+        cfg, T, N = self.cfg, self.T, self.N
+        self.env.rollout_policy(self._policy_struct(), T, self.obs, self.act, self.logp, self.rew, self.done, self.flags,
+                                terminal_obs=self.term_obs, episode_acc=self._episode_acc)
+        self._critic_batch(self.obs.view((T + 1) * N, self.obs_dim), self._v_all.view(-1))
+        self._critic_batch(self.term_obs.view(T * N, self.obs_dim), self._tv.view(-1))
+        self.v.copy_(self._v_all[:T])
+        mask = 1.0 - self.done.to(torch.float32)
+        trunc = (self.flags & 1).bool() & self.done.bool()
+        terminal_v = torch.where(trunc, self._tv, torch.zeros_like(self._tv))
+        rew = self.rew.clone()
+        ret, adv = self._gae(rew, self.v, mask, terminal_v, self._v_all[T], cfg.gamma, cfg.gae_lambda, cfg.use_gae)
+        moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])
+        tot = self._episode_acc.sum(0)
+        self.ep_count += tot[0]; self.ep_return_sum += tot[1]; self.ep_length_sum += tot[2]; self.ep_violation_sum += tot[3]
+        self._episode_acc.zero_()
+        self.total_steps += T * N * parallel.world_size()
+        return ret, adv, moments
+
     def _build_rollout_graph(self):
         """One HIP graph for the whole iteration front end: T x (policy forward, sampling, value, log-prob, env step
         kernel, episode statistics), then bootstrap values, scg_gae and the advantage moments."""
@@ -463,9 +614,13 @@ class PPO:
     # ---- returns / advantages / update (ppo.py:286-303)
     def train_step(self):
         t0 = time.perf_counter()
-        if self._graph_rollout:
-            if self._rollout_graph is None:       # capture records the launches without running them
+        if self._fused_rollout:
+            ret, adv, moments = self._collect_fused()
+        elif self._graph_rollout:
+            if self._rollout_graph is None or self._rollout_epoch != getattr(self.env, 'seed_epoch', 0):
+                # capture records the launches without running them (re-captured after env.seed(): the key is a kernel argument)
                 self._rollout_graph, self._rollout_out = self._build_rollout_graph()
+                self._rollout_epoch = getattr(self.env, 'seed_epoch', 0)
             self._rollout_graph.replay()
             self.total_steps += self.T * self.N * parallel.world_size()
             ret, adv, moments = self._rollout_out
@@ -486,7 +641,8 @@ class PPO:
             torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
         res = self.agent.update(data)
-        self.obs[0].copy_(self.obs[self.T])
+        if not self._fused_rollout:             # (the fused collector re-derives obs[0] from the simulator state)
+            self.obs[0].copy_(self.obs[self.T])
         res.update({'step': self.total_steps, 'collect_time': t1 - t0, 'elapsed_time': time.perf_counter() - t0})
         return res
 
@@ -514,10 +670,15 @@ class PPO:
         for name, nz in (('obs', self.obs_normalizer), ('reward', self.reward_normalizer)):
             if state.get(f'{name}_normalizer'):
                 nz.load_state_dict(state[f'{name}_normalizer'])
-                if f'{name}_normalizer_count' in state:
+                if f'{name}_normalizer_count' in state and hasattr(nz, 'rms'):
                     nz.rms.count.fill_(state[f'{name}_normalizer_count'])
         if 'reward_normalizer_ret' in state and hasattr(self.reward_normalizer, 'rms'):
-            self.reward_normalizer.ret = state['reward_normalizer_ret'].to(self.device)
+            ret = state['reward_normalizer_ret'].to(self.device)
+            if self.reward_normalizer.ret is not None and self.reward_normalizer.ret.shape == ret.shape:
+                self.reward_normalizer.ret.copy_(ret)       # in place: a captured rollout graph aliases this tensor
+            else:
+                self.reward_normalizer.ret = ret
+                self._rollout_graph = None                  # (re-capture with the new storage)
         if training and 'total_steps' in state:
             self.total_steps = state['total_steps']
             self.obs[0].copy_(state['obs'].to(self.device))
@@ -559,14 +720,38 @@ class PPO:
 
 
 @torch.no_grad()
-def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None):
+def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None, policy=None):
     """Deterministic policy (action = mean, ppo_utils.py:233-238) on every env of `env` until each finished
     `episodes_per_env` episodes; returns mean episode return / length / violations / mse (batched counterpart of
     PPO.run, ppo.py:210-257).  An episode lasts at most CTRL_STEPS control steps, so the loop has a fixed length and no
-    host synchronisation; on a GPU it is captured once per (policy, env) pair and replayed as one HIP graph."""
+    host synchronisation; on a GPU it is captured once per (policy, env) pair and replayed as one HIP graph.
+    policy: an _lib.Policy with deterministic = 1 (PPO._policy_struct(True)) for an env built with that policy shape —
+    the whole evaluation is then ONE launch of the fused rollout kernel."""
     N = env.num_envs
     steps = int(env.spec.CTRL_STEPS) * episodes_per_env
     dev = env.device
+    if policy is not None and obs_normalizer is None and getattr(env, 'policy_shape', None) is not None:
+        # ONE launch: deterministic actor inside the env kernel, per-env episode totals accumulated in the kernel
+        buf = getattr(env, '_eval_fused', None)
+        if buf is None:
+            f = dict(device=dev, dtype=torch.float32)
+            nobs, nu = env.spec.obs_dim, env.spec.nu
+            buf = {'obs': torch.zeros(steps + 1, N, nobs, **f), 'act': torch.zeros(steps, N, nu, **f),
+                   'logp': torch.zeros(steps, N, **f), 'rew': torch.zeros(steps, N, **f),
+                   'done': torch.zeros(steps, N, dtype=torch.uint8, device=dev), 'flags': torch.zeros(steps, N, dtype=torch.uint8, device=dev),
+                   'acc': torch.zeros(N, 8, **f)}
+            env._eval_fused = buf
+        env.reset_tensors()
+        buf['acc'].zero_()
+        env.rollout_policy(policy, steps, buf['obs'], buf['act'], buf['logp'], buf['rew'], buf['done'], buf['flags'],
+                           episode_acc=buf['acc'], max_episodes=episodes_per_env)
+        a = buf['acc']
+        n = a[:, 0].sum().clamp(min=1.0)
+        res = torch.stack([a[:, 0].sum(), a[:, 1].sum() / n, a[:, 2].sum() / n, a[:, 3].sum() / n, a[:, 4].sum() / n]).tolist()
+        out = {'episodes': res[0], 'ep_return': res[1], 'ep_length': res[2], 'ep_constraint_violation': res[3], 'ep_mse': res[4]}
+        if episodes_per_env == 1:
+            out['metrics'] = episode_metrics(a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 0] > 0)
+        return out
     use_graph = (dev.type == 'cuda') if use_graph is None else use_graph
     cache = getattr(env, '_eval_cache', None)
     key = (id(ac), episodes_per_env, bool(use_graph), id(obs_normalizer))

@@ -170,7 +170,7 @@ class HipVecEnv(VecEnv):
     """N independent copies of one environment stepped by libscg_hip.so on one GPU."""
 
     def __init__(self, env_id, num_envs, seed=0, device=None, dtype=torch.float32, env_id_offset=0,
-                 return_numpy=True, auto_reset=True, specialize='auto', **task_config):
+                 return_numpy=True, auto_reset=True, specialize='auto', policy=None, **task_config):
         L.lib()                                        # fail loudly, before touching torch.cuda
         if not torch.cuda.is_available():
             raise L.ScgError('HipVecEnv needs a HIP device (torch.cuda.is_available() is False); '
@@ -195,12 +195,19 @@ class HipVecEnv(VecEnv):
         cfg, x_goal = spec.to_c_config(self.num_envs, self._cdtype, self.seed_value, self.env_id_offset, auto_reset)
         self.auto_reset = bool(auto_reset)
         # config-specialised library when one was built for this config (specialize=True compiles it now)
-        self._lib, self.specialized = L.lib_for(cfg, specialize)
+        # policy=(hidden, activation): use the variant of the specialised library that also carries the fused
+        # policy-in-the-loop rollout kernel for that actor shape (rollout_policy below); float32 only
+        self.policy_shape = None
+        if policy is not None and dtype == torch.float32 and L.policy_supported(self.spec.obs_dim, int(policy[0]), self.spec.nu, policy[1]) \
+                and self.spec.obs_dim in (self.spec.nx, 2 * self.spec.nx):
+            self.policy_shape = (int(policy[0]), policy[1])
+        self._lib, self.specialized = L.lib_for(cfg, specialize, self.policy_shape)
         self._cfg = cfg
         nbytes = C.c_size_t(0)
         self._chk(self._lib.scg_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = int(nbytes.value)
             base = self.workspace.data_ptr()
             self._ws_ptr = (base + 255) // 256 * 256
             handle = C.c_void_p()
@@ -236,6 +243,7 @@ class HipVecEnv(VecEnv):
         self._c_out = self._make_c_out(o)
         self._actions = None
         self._adv = None
+        self.seed_epoch = 0
         self.closed = False
 
     def _chk(self, rc):
@@ -331,6 +339,20 @@ class HipVecEnv(VecEnv):
         with torch.cuda.device(self.device):
             self._chk(self._lib.scg_rollout_random(self._h, int(k_steps), C.byref(self._ro_c), self._stream()))
         return self._ro
+
+    def rollout_policy(self, policy, k_steps, obs, act, logp, reward, done, flags, terminal_obs=None, episode_acc=None,
+                       max_episodes=0):
+        """K control steps in ONE launch with the actor in the loop (scg_rollout_policy): `policy` is an _lib.Policy
+        (flat parameter pointer + offsets), the other arguments are the [K(+1), N, .] float32 rollout tensors it fills."""
+        if self.policy_shape is None:
+            raise L.ScgError('this env was not built with a policy shape (HipVecEnv(..., policy=(hidden, activation)))')
+        o = L.PolicyRollout()
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        o.d_obs, o.d_act, o.d_logp, o.d_reward, o.d_done, o.d_flags = p(obs), p(act), p(logp), p(reward), p(done), p(flags)
+        o.d_terminal_obs, o.d_ep_stats, o.d_episode_acc = p(terminal_obs), p(self.ep_stats), p(episode_acc)
+        o.max_episodes = int(max_episodes)
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.scg_rollout_policy(self._h, C.byref(policy), int(k_steps), C.byref(o), self._stream()))
 
     # ------------------------------------------------------------------ reference VecEnv API
     def reset(self):
@@ -435,6 +457,10 @@ class HipVecEnv(VecEnv):
         """New Philox key for every env of the batch (BenchmarkEnv.seed, benchmark_env.py:193-214)."""
         self.seed_value = int(seed)
         self._chk(self._lib.scg_set_seed(self._h, C.c_uint64(self.seed_value & 0xFFFFFFFFFFFFFFFF)))
+        # the key is a kernel argument: HIP graphs captured before this call replay the OLD key — owners of such graphs
+        # (ppo.evaluate's cache here, PPO's rollout graph via seed_epoch) re-capture
+        self._eval_cache = None
+        self.seed_epoch += 1
         return [seed]
 
     def _n_state_arrays(self):
@@ -445,13 +471,27 @@ class HipVecEnv(VecEnv):
     def get_env_random_state(self):
         step, ep = self.get_counters()
         return [{'seed': self.seed_value, 'env_id_offset': self.env_id_offset, 'step': step, 'episode': ep,
-                 'workspace': self.workspace.cpu(), 'ep_stats': self.ep_stats.cpu()}]
+                 'workspace': self._ws_view().cpu(), 'ep_stats': self.ep_stats.cpu()}]
+
+    def _ws_view(self):
+        """The bytes the kernels really use: [_ws_ptr, _ws_ptr + scg_workspace_bytes) — NOT the padded allocation, whose
+        alignment slack may differ between the saving and the loading process."""
+        off = self._ws_ptr - self.workspace.data_ptr()
+        return self.workspace[off: off + self._ws_bytes]
 
     def set_env_random_state(self, worker_random_states):
         st = worker_random_states[0]
         if st['seed'] != self.seed_value or st['env_id_offset'] != self.env_id_offset:
             raise ValueError('random state belongs to a different seed / env shard')
-        self.workspace.copy_(st['workspace'].to(self.device))
+        ws = st['workspace'].to(self.device)
+        if ws.numel() != self._ws_bytes:
+            if ws.numel() == self.workspace.numel():            # checkpoint of an older build: whole padded allocation
+                self.workspace.copy_(ws)
+                ws = None
+            else:
+                raise ValueError('random state belongs to a different env batch (workspace size)')
+        if ws is not None:
+            self._ws_view().copy_(ws)
         if 'ep_stats' in st:
             self.ep_stats.copy_(st['ep_stats'].to(self.device))
 

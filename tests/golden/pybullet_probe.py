@@ -184,6 +184,8 @@ def probe_end_to_end(ref, write_trace):
         report(f'7 {name}: 300 control steps, real Bullet vs oracle (north_star bar 1e-4 relative per state dim)', bool(np.all(rel < 1e-4)),
                f'max relative deviation per dim {np.array2string(rel, precision=2)}')
         out[name + '/states'], out[name + '/actions'], out[name + '/x0'] = states, np.array(acts), states[0]
+        import yaml
+        out[name + '/config_yaml'] = yaml.safe_dump(ocfg)
         env.close()
     if write_trace:
         np.savez_compressed(os.path.join(HERE, 'pybullet_trace.npz'), **out)

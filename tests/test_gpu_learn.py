@@ -1,0 +1,148 @@
+"""The fused MFMA learner kernels (csrc/scg_learn.hip, include/scg_learn.h) against plain PyTorch float32 autograd of the
+reference's loss definitions (controllers/ppo/ppo_utils.py:82-146 as restated in safe_control_gym_amd/ppo.py, which the CPU
+tests pin to fixtures produced by the reference's own PPOAgent)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(12, 128, 2, 'tanh'), (4, 64, 1, 'leaky_relu'), (24, 128, 4, 'relu'), (12, 32, 2, 'tanh')]
+
+
+def _agent(obs_dim, hidden, act_dim, act, **extra):
+    from safe_control_gym_amd.ppo import PPOAgent, PPOConfig
+    torch.manual_seed(3)
+    cfg = PPOConfig(hidden_dim=hidden, activation=act, mini_batch_size=2048, opt_epochs=2, target_kl=0.02,
+                    actor_lr=1e-3, critic_lr=2e-3, entropy_coef=0.01, extra=extra)
+    ag = PPOAgent(obs_dim, act_dim, cfg, 'cuda:0')
+    with torch.no_grad():
+        ag.ac.actor.logstd.copy_(torch.linspace(-0.7, -0.3, act_dim))
+    return ag
+
+
+def _data(obs_dim, act_dim, M, ag, seed=0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    obs = torch.randn(M, obs_dim, device='cuda', generator=g) * 1.5
+    with torch.no_grad():
+        mean, logstd = ag.ac.actor(obs)
+        act = mean + torch.exp(logstd) * torch.randn(M, act_dim, device='cuda', generator=g)
+        from safe_control_gym_amd.ppo import normal_log_prob
+        logp = normal_log_prob(mean, logstd, act) + 0.15 * torch.randn(M, device='cuda', generator=g)     # off-policy on purpose
+        v = ag.ac.critic(obs).squeeze(-1)
+    adv = torch.randn(M, device='cuda', generator=g)
+    ret = v + torch.randn(M, device='cuda', generator=g)
+    v_old = v + 0.3 * torch.randn(M, device='cuda', generator=g)
+    return {'obs': obs, 'act': act, 'logp': logp, 'adv': adv, 'ret': ret, 'v': v_old}
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_mfma_forward_equals_torch(shape):
+    from safe_control_gym_amd import _learn
+    obs_dim, hidden, act_dim, act = shape
+    ag = _agent(obs_dim, hidden, act_dim, act)
+    D = _learn.lib(obs_dim, hidden, act_dim, act)
+    a_lay, c_lay, _, n = ag._layouts()
+    M = 1000                                    # not a multiple of 32: tail tile
+    x = torch.randn(M, obs_dim, device='cuda') * 2
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for lay, nout, net in ((a_lay, act_dim, ag.ac.actor.pi_net), (c_lay, 1, ag.ac.critic.v_net)):
+        out = torch.full((M, nout), float('nan'), device='cuda')
+        _learn.check(D, D.scg_mlp_forward(ag._flat['p'].data_ptr(), C.byref(lay), nout, x.data_ptr(), M, out.data_ptr(), st))
+        ref = net(x)
+        torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('clipped_value', [False, True])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_fused_minibatch_gradients_equal_autograd(shape, clipped_value):
+    from safe_control_gym_amd.ppo import policy_loss_terms, value_loss_term
+    obs_dim, hidden, act_dim, act = shape
+    ag = _agent(obs_dim, hidden, act_dim, act)
+    ag.cfg.use_clipped_value = clipped_value
+    M, mb = 8192, 4096
+    data = _data(obs_dim, act_dim, M, ag)
+    F = ag._build_fused(data, mb)
+    idx = torch.randperm(M, device='cuda')[:mb]
+    F['idx'].copy_(idx.to(torch.int32))
+    ag._flat['g'].zero_()
+    ag._fused_grad(F)
+    torch.cuda.synchronize()
+    got = ag._flat['g'].clone()
+    stats = F['stats'].tolist()
+    # reference: autograd on the same minibatch
+    batch = {k: v[idx] for k, v in data.items()}
+    ag._flat['g'].zero_()
+    pl, el, kl = policy_loss_terms(ag.ac, batch, ag.cfg.clip_param)
+    vl = value_loss_term(ag.ac, batch, ag.cfg.clip_param, clipped_value)
+    (pl + ag.cfg.entropy_coef * el).backward()
+    vl.backward()
+    ref = ag._flat['g'].clone()
+    n, n_a = ag._flat['n'], ag._flat['n_a']
+    for name, lo, hi in (('actor', 0, n_a), ('critic', n_a, n)):
+        scale = ref[lo:hi].abs().max().item()
+        err = (got[lo:hi] - ref[lo:hi]).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-8, (name, err, scale)
+    assert abs(got[n].item() - kl.item()) < 1e-5 + 1e-4 * abs(kl.item())
+    np.testing.assert_allclose(stats, [pl.item(), vl.item(), el.item(), kl.item()], rtol=2e-4, atol=1e-6)
+    # the clip really bites on this data (both branches of the surrogate are exercised)
+    with torch.no_grad():
+        from safe_control_gym_amd.ppo import normal_log_prob
+        mean, logstd = ag.ac.actor(batch['obs'])
+        ratio = torch.exp(normal_log_prob(mean, logstd, batch['act']) - batch['logp'])
+        frac = ((ratio < 0.8) | (ratio > 1.2)).float().mean().item()
+    assert 0.05 < frac < 0.95
+
+
+def test_gated_adam_kernel_equals_the_graphed_torch_adam():
+    """scg_adam_gated == PPOAgent's torch formulation of the two Adam steps with the approx-KL gate (itself pinned to the
+    eager torch.optim path by tests/test_gpu_rl.py), over several steps with the gate open and closed."""
+    ag = _agent(12, 128, 2, 'tanh')
+    fl = ag._flat
+    n, n_a = fl['n'], fl['n_a']
+    F = ag._build_fused(_data(12, 2, 256, ag), 256)
+    p0 = fl['p'].clone()
+    ref = {'p': p0.clone(), 'm': torch.zeros(n, device='cuda'), 'v': torch.zeros(n, device='cuda'), 'steps': [0.0, 0.0]}
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for it, kl in enumerate([0.001, 0.5, 0.02, 0.029, 0.031]):
+        grad = torch.randn(n + 1, device='cuda', generator=g) * 0.1
+        grad[n] = kl
+        fl['g'].copy_(grad)
+        ag._fused_adam(F)
+        gate = kl <= 1.5 * ag.cfg.target_kl
+        for lo, hi, lr, k, take in ((0, n_a, ag.cfg.actor_lr, 0, gate), (n_a, n, ag.cfg.critic_lr, 1, True)):
+            if not take:
+                continue
+            ref['steps'][k] += 1
+            t = ref['steps'][k]
+            gg = grad[lo:hi]
+            ref['m'][lo:hi] = 0.9 * ref['m'][lo:hi] + 0.1 * gg
+            ref['v'][lo:hi] = 0.999 * ref['v'][lo:hi] + 0.001 * gg * gg
+            ref['p'][lo:hi] -= lr / (1 - 0.9 ** t) * ref['m'][lo:hi] / (ref['v'][lo:hi].sqrt() / (1 - 0.999 ** t) ** 0.5 + 1e-8)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(fl['p'], ref['p'], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(fl["m"], ref["m"], rtol=1e-4, atol=1e-8)
+    assert fl['steps'].tolist() == ref['steps']
+    assert F['stats_acc'][4].item() == ref['steps'][0]
+
+
+def test_fused_update_matches_the_torch_update_statistically():
+    """A whole PPOAgent.update through the fused kernels vs the graphed PyTorch path from identical parameters, data and
+    minibatch permutations: same number of gated actor steps, parameters equal to float32 accumulation-order noise."""
+    data = None
+    res, params = {}, {}
+    for mode, extra in (('fused', {}), ('torch', {'fused_update': False})):
+        ag = _agent(12, 128, 2, 'tanh', **extra)
+        assert ag.use_fused == (mode == 'fused')
+        if data is None:
+            data = _data(12, 2, 16384, ag)
+        gen = torch.Generator(device='cuda').manual_seed(11)
+        res[mode] = ag.update({k: v.clone() for k, v in data.items()}, generator=gen)
+        torch.cuda.synchronize()
+        params[mode] = ag._flat['p'].clone()
+    assert res['fused']['actor_steps'] == res['torch']['actor_steps'] and res['fused']['minibatches'] == res['torch']['minibatches']
+    for k in ('policy_loss', 'value_loss', 'entropy_loss', 'approx_kl'):
+        assert abs(res['fused'][k] - res['torch'][k]) < 1e-4 + 1e-3 * abs(res['torch'][k]), (k, res)
+    torch.testing.assert_close(params['fused'], params['torch'], rtol=0, atol=2e-4)

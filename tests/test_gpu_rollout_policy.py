@@ -1,0 +1,97 @@
+"""scg_rollout_policy — K control steps per launch with the actor in the loop — against the step-by-step path
+(PyTorch actor + scg_step), and the PPO collector / evaluation built on it."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def _setup(task, n, hidden, act, seed=5):
+    from safe_control_gym_amd.ppo import PPO, PPOConfig
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task(task)
+    env = HipVecEnv(env_id, n, seed=seed, return_numpy=False, policy=(hidden, act), **cfg)
+    ref = HipVecEnv(env_id, n, seed=seed, return_numpy=False, **cfg)
+    assert env.policy_shape == (hidden, act)
+    pcfg = PPOConfig(hidden_dim=hidden, activation=act, use_gae=True, rollout_batch_size=n, rollout_steps=8, mini_batch_size=n * 8 // 2,
+                     opt_epochs=1)
+    torch.manual_seed(0)
+    ppo = PPO(env, pcfg, seed=0)
+    assert ppo._fused_rollout and ppo.agent.use_fused
+    return env, ref, ppo
+
+
+@pytest.mark.parametrize('task,hidden,act', [('quadrotor_2D_track', 128, 'tanh'), ('cartpole_stab', 64, 'leaky_relu'),
+                                             ('quadrotor_3D_track', 128, 'relu')])
+def test_fused_rollout_equals_step_by_step(task, hidden, act):
+    n, K = 320, 12                                 # 5 waves: a partial workgroup as well
+    env, ref, ppo = _setup(task, n, hidden, act)
+    nobs, nu = env.spec.obs_dim, env.spec.nu
+    f = dict(device=env.device, dtype=torch.float32)
+    obs, actb, logp, rew = torch.zeros(K + 1, n, nobs, **f), torch.zeros(K, n, nu, **f), torch.zeros(K, n, **f), torch.zeros(K, n, **f)
+    done, flags = torch.zeros(K, n, dtype=torch.uint8, device=env.device), torch.zeros(K, n, dtype=torch.uint8, device=env.device)
+    term, acc = torch.zeros(K, n, nobs, **f), torch.zeros(n, 8, **f)
+    # (a) deterministic policy: must reproduce actor-mean actions fed to scg_step one step at a time
+    env.reset_tensors(); o = ref.reset_tensors().clone()
+    env.rollout_policy(ppo._policy_struct(True), K, obs, actb, logp, rew, done, flags, terminal_obs=term, episode_acc=acc)
+    torch.cuda.synchronize()
+    ac = ppo.agent.ac
+    n_done = 0
+    for t in range(K):
+        torch.testing.assert_close(obs[t], o, rtol=2e-4, atol=2e-4)
+        with torch.no_grad():
+            a = ac.act(obs[t])                      # same inputs as the kernel saw (no drift between the two paths)
+        torch.testing.assert_close(actb[t], a, rtol=1e-4, atol=2e-5)
+        out = ref.step_tensors(actb[t])
+        torch.testing.assert_close(rew[t], out.reward, rtol=2e-4, atol=2e-5)
+        assert torch.equal(done[t], out.done) and torch.equal(flags[t], out.flags)
+        d = out.done.bool()
+        if d.any():
+            torch.testing.assert_close(term[t][d], out.terminal_obs[d], rtol=2e-4, atol=2e-4)
+        n_done += int(d.sum())
+        o = out.obs.clone()
+    torch.testing.assert_close(obs[K], o, rtol=2e-4, atol=2e-4)
+    assert int(acc[:, 0].sum()) == n_done
+    lp = -(ac.actor.logstd + 0.9189385332).sum().item()
+    assert torch.allclose(logp, torch.full_like(logp, lp), atol=1e-5)
+    # (b) stochastic: log-prob consistent with the sampled action, unit normal noise, reproducible
+    env.reset_tensors()
+    env.rollout_policy(ppo._policy_struct(False), K, obs, actb, logp, rew, done, flags, terminal_obs=term, episode_acc=acc)
+    from safe_control_gym_amd.ppo import normal_log_prob
+    with torch.no_grad():
+        mean, logstd = ac.actor(obs[:K].reshape(K * n, nobs))
+        ref_lp = normal_log_prob(mean, logstd, actb.reshape(K * n, nu)).reshape(K, n)
+        z = ((actb.reshape(K * n, nu) - mean) * torch.exp(-logstd))
+    torch.testing.assert_close(logp, ref_lp, rtol=1e-3, atol=2e-3)
+    assert abs(z.mean().item()) < 0.05 and abs(z.std().item() - 1.0) < 0.05
+    a1 = actb.clone()
+    env.seed(5); env.reset_tensors()                                 # same key, fresh episodes -> different draws (episode index)
+    env.rollout_policy(ppo._policy_struct(False), K, obs, actb, logp, rew, done, flags, terminal_obs=term, episode_acc=acc)
+    assert not torch.equal(a1, actb)
+    env.close(); ref.close()
+
+
+
+def test_ppo_iteration_and_evaluation_on_the_fused_rollout():
+    from safe_control_gym_amd.ppo import evaluate
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env, ref, ppo = _setup('quadrotor_2D_track', 1024, 128, 'tanh')
+    res = ppo.train_step()
+    assert np.isfinite([res['policy_loss'], res['value_loss'], res['approx_kl']]).all() and res['minibatches'] == 2
+    st = ppo.episode_stats()
+    assert st['episodes'] > 0 and 0 < st['ep_length'] <= 250
+    # evaluation: the fused one-launch path == the graphed PyTorch-policy path
+    env_id, cfg = load_task('quadrotor_2D_track')
+    ev_cfg = dict(cfg, randomized_init=False)
+    e1 = HipVecEnv(env_id, 128, seed=9, return_numpy=False, policy=(128, 'tanh'), **ev_cfg)
+    e2 = HipVecEnv(env_id, 128, seed=9, return_numpy=False, **ev_cfg)
+    a = evaluate(ppo.agent.ac, e1, policy=ppo._policy_struct(True))
+    b = evaluate(ppo.agent.ac, e2)
+    assert a['episodes'] == b['episodes'] == 128
+    for k in ('ep_return', 'ep_length', 'ep_constraint_violation', 'ep_mse'):
+        assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    for e in (env, ref, e1, e2):
+        e.close()
