@@ -1,14 +1,29 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/r01_*: run ON THE GPU BOX (gpurun -- 'tools/profile_round.sh'), writes gpurun_out/prof/.
+# rocprofv3 passes behind profiles/r02_*: run ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh'), writes gpurun_out/prof/.
 # Counter passes are separate from the kernel trace (and from each other: TCC slot limit), as MI355X_MICROARCH.md prescribes.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/prof; mkdir -p $OUT
-for N in 65536 1048576; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$N -o p -- \
-      python bench.py --envs $N --steps 2000 --warmup 200 --no-cpu-baseline > $OUT/kt_$N.log 2>&1 < /dev/null
+B="--no-cpu-baseline --no-secondary --ppo-seeds 0"
+for spec in quadrotor_2D_track:65536 quadrotor_2D_track:1048576 quadrotor_2D_track:4194304 cartpole_stab:65536 quadrotor_3D_track:65536 quadrotor_3D_track_disturbed:65536; do
+  T=${spec%%:*}; N=${spec##*:}
+  S=2000; [ $N -gt 1000000 ] && S=300
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_${T}_$N -o p -- \
+      python bench.py --task $T --envs $N --steps $S --warmup 200 $B > $OUT/kt_${T}_$N.log 2>&1 < /dev/null
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$N -o p -- \
-        python bench.py --envs $N --steps 200 --warmup 50 --no-cpu-baseline --no-graph > $OUT/pmc_${C}_$N.log 2>&1 < /dev/null
+    timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_${T}_$N -o p -- \
+        python bench.py --task $T --envs $N --steps 100 --warmup 30 --no-graph $B > $OUT/pmc_${C}_${T}_$N.log 2>&1 < /dev/null
   done
 done
-ls -R $OUT | head -40
+# what bounds the 4 M-env (HBM-streaming) regime: write-request mix / stalls, read mix + L2 hit rate, wave occupancy and stall split
+N=4194304; T=quadrotor_2D_track
+i=0
+for C in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WR_UNCACHED_32B_sum" \
+         "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" \
+         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INST_CYCLES_VMEM" \
+         "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/diag${i}_$N -o p -- \
+      python bench.py --task $T --envs $N --steps 60 --warmup 20 --no-graph $B > $OUT/diag${i}_$N.log 2>&1 < /dev/null
+done
+find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete; find $OUT -name '*.log' -size +200k -delete
+du -sh $OUT; ls $OUT | head -80
