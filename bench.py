@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — env-steps/s of the HIP simulator on BASELINE.json's headline config.
+"""bench.py — the whole BASELINE.json metric in one JSON line: env-steps/s of the HIP simulator on the headline config
++ PPO wall-clock-to-reward on it, with the per-kernel roofline and the CPU path timed beside it.
 
-Workload (config.workload): Quadrotor2D trajectory tracking (the env of BASELINE configs[2];
-examples/rl/config_overrides/quadrotor_2D/quadrotor_2D_track.yaml), 65 536 envs per GPU, float32.
-One "step" = one control step of every env = ONE launch of the fused step kernel (action
-pre-processing, 20 engine substeps, observation / reward / done / info / 16 constraint rows,
-episode statistics, auto-reset), driven by synthetic actions ~U(-1,1) already resident in HBM
-(the reference's own README benchmark is the same open-loop random-action loop on one env).
-The K timed launches are replayed from a HIP graph so the measurement is not Python-bound.
+Headline (the top-level fields): Quadrotor2D trajectory tracking (BASELINE configs[2]; examples/rl/config_overrides/
+quadrotor_2D/quadrotor_2D_track.yaml), 65 536 envs per GPU, float32.  One "step" = one control step of every env = ONE
+launch of the fused step kernel (action pre-processing, 20 engine substeps, observation / reward / done / info / 16
+constraint rows, episode statistics, auto-reset), synthetic actions ~U(-1,1) resident in HBM (the reference's own README
+benchmark is the same open-loop random-action loop on one env).  The K timed launches are one HIP graph; when K is small
+the K-step graph is replayed R times, each replay timed between barrier + synchronize, and the MEDIAN replay is reported
+(`config.timing`), so that K = 20 is not a single 0.1 ms sample.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank
-per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.  Env shards are independent
-(rank r owns global env ids [r*N, (r+1)*N)), there is no data-path collective: scaling = weak.
+Secondary objects (rank 0, N = 1): `f64` (the float64 kernels of the same workload), `secondary` (the other BASELINE
+configs' env kernels: cartpole_stab incl. the fused random-action rollout of config #2, quadrotor_3D_track[_disturbed]),
+`gae` (scg_gae timing + its own roofline), `fused_rollout` (K steps per launch with the PPO actor in the loop), `ppo`
+(budgeted wall-clock-to-reward runs), `cpu_baseline`.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU with
+torch.distributed.run.  Rank 0 prints ONE JSON line.  Env shards are independent (rank r owns global env ids
+[r*N, (r+1)*N)), there is no data-path collective: scaling = weak.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,7 +35,10 @@ if ROOT not in sys.path:
 # + counter 4 + c_values 64 + mse 4  => 187 B with the survey's accounting.
 ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'quadrotor_3D_track': 363,
                            'quadrotor_3D_track_disturbed': 379}
+KERNEL_NAME = {'quadrotor_2D_track': 'step_kernel<QUAD_2D,float>', 'cartpole_stab': 'step_kernel<CARTPOLE,float>',
+               'quadrotor_3D_track': 'step_kernel<QUAD_3D,float>', 'quadrotor_3D_track_disturbed': 'step_kernel<QUAD_3D,float,DIST>'}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+TRAFFIC_FILES = ('r02_hbm_traffic.json', 'r01_hbm_traffic.json')
 
 
 def parse():
@@ -41,9 +51,12 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='headline only (no f64 / other configs / gae / ppo legs)')
     ap.add_argument('--generic', action='store_true', help='use libscg_hip.so (any config, parameters via LDS) instead of the config-specialised build')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU oracle baseline')
     ap.add_argument('--graph-len', type=int, default=1000, help='steps captured per HIP graph')
+    ap.add_argument('--ppo-seeds', type=int, default=3, help='seeds of the PPO wall-clock-to-reward leg (0 = skip)')
+    ap.add_argument('--ppo-seconds', type=float, default=10.0, help='budget per seed')
     return ap.parse_args()
 
 
@@ -118,12 +131,220 @@ def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
                       f'i7-1068NG7): 381-464 env-steps/s'}
 
 
+def traffic_of(task, dtype, n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this very command (separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 x2 fetch correction — tools/profile_round.sh, tools/profile_post.py)."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                t = json.load(f).get(f'{task}/{dtype}/{n}', {}).get('traffic_bytes_per_launch')
+            if t:
+                return t, f'profiles/{name} (rocprofv3 --pmc, bytes per launch)'
+        except OSError:
+            pass
+    return None, None
+
+
+class StepBench:
+    """K control steps of one env batch as a HIP graph of step-kernel launches on ring-buffered synthetic actions."""
+
+    def __init__(self, torch, task, n, dtype, rank=0, generic=False, graph_len=1000, use_graph=True):
+        from safe_control_gym_amd.registration import load_task
+        from safe_control_gym_amd.vec_env import HipVecEnv
+        self.torch, self.task, self.n = torch, task, n
+        dev = torch.device('cuda', torch.cuda.current_device())
+        env_id, cfg = load_task(task)
+        if os.environ.get('SCG_BENCH_OVERRIDE'):      # dev only: ablations of the task config
+            cfg.update(json.loads(os.environ['SCG_BENCH_OVERRIDE']))
+        self.env_id, self.cfg = env_id, cfg
+        self.env = HipVecEnv(env_id, n, seed=1337, dtype=dtype, env_id_offset=rank * n, return_numpy=False,
+                             specialize=False if generic else 'auto', **cfg)
+        ring = 64
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        self.actions = torch.rand(ring, n, self.env.spec.nu, device=dev, dtype=dtype, generator=gen) * 2 - 1
+        self.ring = ring
+        self.env.reset_tensors()
+        # outputs a rollout collector consumes (obs, reward, done, flags, constraint values, mse, terminal obs, fused episode
+        # statistics); the optional debugging outputs (env.state copy, noisy action) are not bound
+        self.out, self.c_out = self.env.bind_outputs(state=None, noisy_action=None)
+        self.G = graph_len
+        self.graph = None
+        if use_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._run(8)
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._run(self.G)
+
+    def _run(self, k):
+        for t in range(k):
+            self.env.step_tensors(self.actions[t % self.ring], out=self.out, c_out=self.c_out)
+
+    def do(self, k):
+        if self.graph is None:
+            self._run(k)
+            return k
+        reps = (k + self.G - 1) // self.G
+        for _ in range(reps):
+            self.graph.replay()
+        return reps * self.G
+
+    def kernel_period_us(self, k):
+        """Average launch-to-launch period of the step kernel over >= k launches (HIP events on the launch stream)."""
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        done = self.do(k)
+        ev1.record()
+        torch.cuda.synchronize()
+        return 1e3 * ev0.elapsed_time(ev1) / done
+
+    def sane(self):
+        return bool(self.torch.isfinite(self.out.reward).all().item()) and int(self.out.fin_length.max().item()) > 0
+
+
+def roofline_of(task, dtype_name, n, period_us):
+    algo = ALGO_BYTES_PER_ENV_STEP.get(task) if dtype_name == 'f32' else None
+    achieved = (algo * n / (period_us * 1e-6)) / 1e9 if algo else None
+    traffic, src = traffic_of(task, dtype_name, n)
+    return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic, 'traffic_source': src,
+            'kernel': KERNEL_NAME.get(task, 'step_kernel'), 'avg_launch_us': period_us, 'algorithmic_bytes_per_env_step': algo}
+
+
+def secondary_env_kernels(torch, n):
+    """The env kernels of the other BASELINE configs (same 65 536 envs, f32): us per launch and roofline fraction."""
+    out = {}
+    for task in ('cartpole_stab', 'quadrotor_3D_track', 'quadrotor_3D_track_disturbed'):
+        try:
+            b = StepBench(torch, task, n, torch.float32, graph_len=500)
+            b.do(500)
+            us = b.kernel_period_us(3000)
+            r = roofline_of(task, 'f32', n, us)
+            e = {'avg_launch_us': us, 'env_steps_per_s': n / (us * 1e-6), 'frac': r['frac'], 'algorithmic_bytes_per_env_step': r['algorithmic_bytes_per_env_step'],
+                 'traffic': r['traffic'], 'kernel_build': 'config-specialised' if b.env.specialized else 'generic', 'finite_outputs': b.sane()}
+            if task == 'cartpole_stab':         # BASELINE config #2: in-kernel random actions, K steps per launch
+                K = 1000
+                b.env.rollout_random(K)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    b.env.rollout_random(K)
+                torch.cuda.synchronize()
+                e['rollout_random_env_steps_per_s'] = 3 * K * n / (time.perf_counter() - t0)
+            b.env.close()
+            out[task] = e
+        except Exception as exc:                                    # noqa: BLE001  (a secondary never sinks the headline)
+            out[task] = {'error': repr(exc)[:200]}
+    return out
+
+
+def gae_leg(torch):
+    """scg_gae (compute_returns_and_advantages): 16 B read + 8 B written per (t, env) + the in-place reward update 8 B."""
+    from safe_control_gym_amd.rollout import gae_returns
+    out = {}
+    for T, N in ((32, 65536), (1000, 4)):
+        rew, v = torch.rand(T, N, device='cuda'), torch.rand(T, N, device='cuda')
+        mask = (torch.rand(T, N, device='cuda') > 0.01).float()
+        tv, last = torch.rand(T, N, device='cuda'), torch.rand(N, device='cuda')
+        for _ in range(3):
+            gae_returns(rew, v, mask, tv, last)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        reps = 50
+        ev0.record()
+        for _ in range(reps):
+            gae_returns(rew, v, mask, tv, last)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * ev0.elapsed_time(ev1) / reps
+        byts = 32 * T * N + 4 * N
+        out[f'{T}x{N}'] = {'us_per_call': us, 'algorithmic_bytes': byts, 'achieved_GBs': byts / (us * 1e-6) / 1e9,
+                           'frac': byts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           'note': 'includes two torch.empty_like allocations per call' if T * N > 100000 else 'launch-bound (4 envs: wave segmented scan over time)'}
+    return out
+
+
+def fused_rollout_leg(torch, n, T=32):
+    """K control steps per launch with the PPO actor (12 -> 128 -> 128 -> 2, tanh, exact f32 MFMA) inside the env kernel."""
+    from safe_control_gym_amd.ppo import PPO, PPOConfig
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task('quadrotor_2D_track')
+    env = HipVecEnv(env_id, n, seed=7, return_numpy=False, policy=(128, 'tanh'), **cfg)
+    ppo = PPO(env, PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, rollout_batch_size=n, rollout_steps=T, mini_batch_size=65536), seed=7)
+    if not ppo._fused_rollout:
+        return {'error': 'fused rollout unavailable'}
+    for _ in range(2):
+        ppo._collect_fused()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        ppo._collect_fused()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    env.close()
+    return {'envs': n, 'rollout_steps': T, 'ms_per_rollout': 1e3 * el, 'env_steps_per_s': n * T / el,
+            'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments'}
+
+
+def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384):
+    """PPO wall-clock until the deterministic-policy evaluation return reaches the reference reward (236 / 250, BASELINE.md
+    §2): fused rollout, fused MFMA update, fused evaluation; the clock starts after construction and includes every
+    evaluation.  With several ranks: env shards + one flat gradient all-reduce per minibatch (RCCL)."""
+    from safe_control_gym_amd import parallel
+    from safe_control_gym_amd.ppo import PPO, PPOConfig, evaluate
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task('quadrotor_2D_track')
+    pol = (128, 'tanh')
+    times, its, best_all = [], [], []
+    for seed in range(1, seeds + 1):
+        env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
+        eval_env = HipVecEnv(env_id, 256, seed=seed * 111, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
+        pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=0.03,
+                         entropy_coef=0.01, opt_epochs=4, mini_batch_size=65536, actor_lr=2e-3, critic_lr=2e-3,
+                         rollout_batch_size=envs, rollout_steps=32)
+        ppo = PPO(env, pcfg, seed=seed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reached, best, it = None, -1e30, 0
+        max_it = int(budget_s / 0.02)                   # iteration cap (identical on every rank: no rank leaves a collective alone)
+        while it < max_it:
+            ppo.train_step()
+            it += 1
+            ev = evaluate(ppo.agent.ac, eval_env, policy=ppo._policy_struct(True))
+            best = max(best, ev['ep_return'])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            flag = torch.tensor([1.0 if ev['ep_return'] >= 236.0 else 0.0, 1.0 if el > budget_s else 0.0], device=env.device)
+            if world > 1:                               # rank 0 decides for everybody
+                dist.broadcast(flag, src=0)
+            if flag[0].item() > 0:
+                reached = el
+                break
+            if flag[1].item() > 0:
+                break
+        times.append(reached); its.append(it); best_all.append(best)
+        env.close(); eval_env.close()
+    ok = [t for t in times if t is not None]
+    return {'target_return': 236.0, 'envs_per_gpu': envs, 'rollout_steps': 32, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
+            'wall_clock_to_target_s': times, 'iterations': its, 'best_eval_return': best_all, 'reached': len(ok),
+            'median_s': statistics.median(ok) if ok else None, 'budget_s_per_seed': budget_s,
+            'hyper': 'MLP 12-128-128-{2,1} tanh, 4 epochs x 8 minibatches of 65 536, lr 2e-3, target_kl 0.03, GAE 0.95, gamma 0.99, ent 0.01',
+            'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA) + fused evaluation every iteration'}
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from safe_control_gym_amd.registration import load_task
-    from safe_control_gym_amd.vec_env import HipVecEnv
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -145,86 +366,37 @@ def main():
         print(f'[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
     dev = torch.device('cuda', torch.cuda.current_device())
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
-    env_id, cfg = load_task(args.task)
-    if os.environ.get('SCG_BENCH_OVERRIDE'):      # dev only: ablations of the task config
-        cfg.update(json.loads(os.environ['SCG_BENCH_OVERRIDE']))
     N = args.envs
-    env = HipVecEnv(env_id, N, seed=1337, dtype=dtype, env_id_offset=rank * N, return_numpy=False,
-                    specialize=False if args.generic else 'auto', **cfg)
-    nu = env.spec.nu
-    # synthetic actions resident in HBM: a ring of pre-generated batches
-    ring = 64
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    actions = (torch.rand(ring, N, nu, device=dev, dtype=dtype, generator=gen) * 2 - 1)
-    env.reset_tensors()
-    # outputs a rollout collector consumes (obs, reward, done, flags, constraint values, mse, terminal obs,
-    # fused episode statistics); the optional debugging outputs (env.state copy, noisy action) are not bound
-    lean_out, lean_c = env.bind_outputs(state=None, noisy_action=None)
-
-    def run_steps(k0, k):
-        for t in range(k0, k0 + k):
-            env.step_tensors(actions[t % ring], out=lean_out, c_out=lean_c)
-
     G = max(1, min(args.graph_len, args.steps))
-    graph = None
-    if not args.no_graph:
-        # warm up on a side stream, then capture G consecutive control steps
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            run_steps(0, 8)
-        torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            run_steps(0, G)
+    hb = StepBench(torch, args.task, N, dtype, rank=rank, generic=args.generic, graph_len=G, use_graph=not args.no_graph)
 
-    def do(k):
-        if graph is None:
-            run_steps(0, k)
-            return k
-        reps = (k + G - 1) // G
-        for _ in range(reps):
-            graph.replay()
-        return reps * G
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    do(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    done_steps = do(args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / done_steps          # avg launch-to-launch period of the step kernel
+    hb.do(args.warmup)
+    # timed region: EXACTLY K steps between barrier + synchronize.  When K is small (one graph replay), the same K-step
+    # region is repeated and the median repeat is reported (every repeat is bracketed the same way).
+    repeats = 1 if args.steps >= 5000 else 31
+    samples, done_steps = [], args.steps
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        done_steps = hb.do(args.steps)
+        barrier()
+        samples.append(time.perf_counter() - t0)
+    elapsed = statistics.median(samples)
     el = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    # sanity: the simulator really advanced (episodes finished, finite rewards)
-    ok = bool(torch.isfinite(lean_out.reward).all().item()) and int(lean_out.fin_length.max().item()) > 0
-    total_env_steps = world * N * done_steps
-    value = total_env_steps / elapsed
+    period_us = hb.kernel_period_us(max(args.steps, 4000))      # launch period inside long back-to-back replays
+    ok = hb.sane()
+    value = world * N * done_steps / elapsed
+    out = None
     if rank == 0:
-        algo = ALGO_BYTES_PER_ENV_STEP.get(args.task)
-        if dtype == torch.float64 and algo:
-            algo = None
-        achieved = (algo * N / (kernel_ms * 1e-3)) / 1e9 if algo else None
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this very command
-        # (profiles/r01_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
-                traffic = json.load(f).get(f'{args.task}/{args.dtype}/{N}', {}).get('traffic_bytes_per_launch')
-        except OSError:
-            pass
         out = {
             'metric': 'env-steps/sec (whole node), Quadrotor2D-track', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': done_steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / done_steps,
@@ -233,22 +405,49 @@ def main():
             'config': {'workload': f'{args.task}: {N} envs/GPU x {world} GPU, 1 launch of the fused step kernel per '
                                    f'control step (20 engine substeps, obs/reward/done/info/constraints, auto-reset), '
                                    f'synthetic U(-1,1) actions resident in HBM, '
-                                   f'{"HIP graph of %d steps" % G if graph is not None else "per-step Python launches"}',
+                                   f'{"HIP graph of %d steps" % G if hb.graph is not None else "per-step Python launches"}',
                        'envs_per_gpu': N, 'task_yaml': f'safe_control_gym_amd/configs/{args.task}.yaml',
                        'parallelism': f'env-shard x{world}', 'finite_outputs': ok,
-                       'kernel_build': 'config-specialised' if env.specialized else 'generic',
-                       'ppo_wall_clock_to_reward': 'measured separately: examples/train_ppo.py, profiles/r01_ppo_wallclock_q2track.md'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic,
-                         'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc, bytes per launch)' if traffic else None,
-                         'kernel': 'step_kernel<QUAD_2D,float>', 'avg_launch_us': kernel_ms * 1e3,
-                         'algorithmic_bytes_per_env_step': algo},
+                       'kernel_build': 'config-specialised' if hb.env.specialized else 'generic',
+                       'timing': f'median of {repeats} timed repeats of the {done_steps}-step region' if repeats > 1 else 'one timed region',
+                       'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))]},
+            'roofline': roofline_of(args.task, args.dtype, N, period_us),
         }
+    full = not args.no_secondary and args.task == 'quadrotor_2D_track' and args.dtype == 'f32'
+    if rank == 0 and world == 1 and full:
+        try:
+            fb = StepBench(torch, args.task, N, torch.float64, graph_len=500)
+            fb.do(500)
+            us = fb.kernel_period_us(3000)
+            out['f64'] = {'avg_launch_us': us, 'ms_per_step': us * 1e-3, 'env_steps_per_s': N / (us * 1e-6),
+                          'note': 'same workload on the float64 kernels (the reference computes in float64); bytes per env-step double, '
+                                  'algorithmic 2 x 187 - 10 = 364 B', 'frac': (364 * N / (us * 1e-6)) / 1e9 / HBM_PEAK_GBS,
+                          'finite_outputs': fb.sane()}
+            fb.env.close()
+        except Exception as exc:                                    # noqa: BLE001
+            out['f64'] = {'error': repr(exc)[:200]}
+        out['secondary'] = secondary_env_kernels(torch, N)
+        try:
+            out['gae'] = gae_leg(torch)
+        except Exception as exc:                                    # noqa: BLE001
+            out['gae'] = {'error': repr(exc)[:200]}
+        try:
+            out['fused_rollout'] = fused_rollout_leg(torch, N)
+        except Exception as exc:                                    # noqa: BLE001
+            out['fused_rollout'] = {'error': repr(exc)[:200]}
+    hb.env.close()
+    if full and args.ppo_seeds > 0 and (world == 1 or backend == 'nccl' or os.environ.get('SCG_BENCH_PPO_GLOO')):
+        try:
+            res = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds)
+        except Exception as exc:                                    # noqa: BLE001
+            res = {'error': repr(exc)[:300]}
+        if rank == 0:
+            out['ppo'] = res
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(args.task, cfg, env_id, args.cpu_seconds, N)
+            out['cpu_baseline'] = cpu_baseline(args.task, hb.cfg, hb.env_id, args.cpu_seconds, N)
             out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
         print(json.dumps(out))
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -29,9 +29,12 @@ typedef struct {
 /* The shape this library was compiled for (obs_dim, hidden, act_dim, activation 0 tanh | 1 relu | 2 leaky_relu). */
 void scg_learn_shape(int32_t* obs_dim, int32_t* hidden, int32_t* act_dim, int32_t* activation);
 
-/* MLP.forward on a batch (neural_networks.py:45-54): d_x [m][obs_dim] -> d_out [m][nout], nout = act_dim or 1. */
+/* MLP.forward on a batch (neural_networks.py:45-54): d_x [m][obs_dim] -> d_out [m][nout], nout = act_dim or 1.
+ * d_row_mask (nullable, [m] bytes): sparse evaluation — rows are processed in tiles of 32; a tile without a non-zero mask
+ * byte is skipped and its outputs are written as 0 (used for the critic's values of the few time-limit-truncated
+ * terminal observations of a rollout, ppo.py:276-283). */
 int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m, float* d_out,
-                    void* stream);
+                    const uint8_t* d_row_mask, void* stream);
 
 /* One minibatch of PPOAgent.update up to (and including) the gradients — replaces compute_policy_loss,
  * compute_value_loss, both backward passes and the approx-KL of ppo_utils.py:82-131:

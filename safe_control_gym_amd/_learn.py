@@ -77,7 +77,7 @@ def lib(obs_dim, hidden, act_dim, activation):
     D.scg_learn_last_error.restype = C.c_char_p
     D.scg_ppo_grad_workspace_bytes.restype = C.c_size_t
     D.scg_ppo_grad_workspace_bytes.argtypes = [C.c_int]
-    D.scg_mlp_forward.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    D.scg_mlp_forward.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     D.scg_ppo_grad.argtypes = [C.POINTER(PpoGradArgs), C.c_void_p]
     D.scg_adam_gated.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -79,7 +79,8 @@ __device__ __forceinline__ void load_x(const float* __restrict__ obs, int sample
 // ------------------------------------------------------------------ batched forward (inference / tests)
 template <int NOUT>
 __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
-                                                          const float* __restrict__ xin, int M, float* __restrict__ out) {
+                                                          const float* __restrict__ xin, int M, float* __restrict__ out,
+                                                          const uint8_t* __restrict__ row_mask) {
     using L = MlpLds<NIN, HID, NOUT>;
     extern __shared__ __align__(16) float lds[];
     const MlpWeights w = weights_of(params, lay);
@@ -92,6 +93,16 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
         int s = tile * 32 + c;
         const bool live = s < M;
         s = live ? s : M - 1;
+        if (row_mask) {                 // sparse evaluation: a 32-row tile without a flagged row is skipped (its outputs are 0)
+            const bool want = live && row_mask[s] != 0;
+            if (__ballot(want) == 0ull) {
+                if (live && h == 0) {
+#pragma unroll
+                    for (int k = 0; k < NOUT; ++k) out[(size_t)s * NOUT + k] = 0.0f;
+                }
+                continue;
+            }
+        }
         float x[L::L1Q];
         load_x<L::L1Q>(xin, s, h, x);
         f32x16 h1[NT], h2[NT];
@@ -477,18 +488,18 @@ __global__ void adam_count_kernel(const AdamArgs A) {
 
 // ------------------------------------------------------------------ C ABI
 extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m,
-                               float* d_out, void* stream) {
+                               float* d_out, const uint8_t* d_row_mask, void* stream) {
     if (!d_params || !layout || !d_x || !d_out || m <= 0) return fail(-1, "scg_mlp_forward: bad argument");
     const int grid = std::min(256, (m + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
     if (nout == NU) {
         const size_t bytes = MlpLds<NIN, HID, NU>::END * sizeof(float);
         HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        mlp_forward_kernel<NU><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out);
+        mlp_forward_kernel<NU><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else if (nout == 1) {
         const size_t bytes = MlpLds<NIN, HID, 1>::END * sizeof(float);
         HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        mlp_forward_kernel<1><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out);
+        mlp_forward_kernel<1><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else {
         return fail(-1, "scg_mlp_forward: this library serves nout = act_dim or 1");
     }

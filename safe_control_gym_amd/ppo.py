@@ -402,9 +402,12 @@ class PPOAgent:
             raise ValueError('checkpoint carries torch.optim state only (saved with cuda_graphs off); load it with '
                              "extra={'cuda_graphs': False} or re-save — the flat Adam moments would silently restart from zero")
 
-    def update(self, data, generator=None):
+    def update(self, data, generator=None, perms=None):
         """`data`: dict of flat [M, .] tensors (obs, act, logp, adv, ret, v).  Epochs x shuffled minibatches, drop last
-        (ppo_utils.py:113-146, :358-371).  Returns the reference's averaged loss statistics."""
+        (ppo_utils.py:113-146, :358-371).  Returns the reference's averaged loss statistics.
+        perms (tests): one index permutation of range(M) per epoch instead of torch.randperm (eager path)."""
+        if perms is not None:
+            assert not self.use_graphs, 'explicit permutations are an eager-path (test) facility'
         if self.use_fused and self.ac.actor.action_modifier is None:
             return self._update_fused(data, generator)
         if self.use_graphs:
@@ -419,8 +422,9 @@ class PPOAgent:
             self._bucket = parallel.FlatBucket(params, n_scalars=1)
         stats = torch.zeros(4, device=data['obs'].device)
         n_actor_steps = 0
-        for _ in range(cfg.opt_epochs):
-            perm = torch.randperm(M, device=data['obs'].device, generator=generator)[:n_mb * mb].view(n_mb, mb)
+        for ep in range(cfg.opt_epochs):
+            perm = (torch.as_tensor(perms[ep], device=data['obs'].device) if perms is not None
+                    else torch.randperm(M, device=data['obs'].device, generator=generator))[:n_mb * mb].view(n_mb, mb)
             for idx in perm:
                 batch = {k: v[idx] for k, v in data.items()}
                 policy_loss, entropy_loss, approx_kl = policy_loss_terms(self.ac, batch, cfg.clip_param)
@@ -562,8 +566,9 @@ class PPO:
                         W3=a_lay.W3, b3=a_lay.b3, logstd_off=ls_off, hidden=self.cfg.hidden_dim,
                         activation=L.POLICY_ACTS[self.cfg.activation], deterministic=int(deterministic))
 
-    def _critic_batch(self, x, out):
-        """out[m] = critic(x[m]) through the MFMA forward kernel (scg_mlp_forward)."""
+    def _critic_batch(self, x, out, row_mask=None):
+        """out[m] = critic(x[m]) through the MFMA forward kernel (scg_mlp_forward); row_mask (uint8 [m]): only 32-row tiles
+        holding a flagged row are evaluated, the others return 0."""
         import ctypes as C
         from safe_control_gym_amd import _learn
         D = _learn.lib(self.obs_dim, self.cfg.hidden_dim, self.act_dim, self.cfg.activation)
@@ -571,7 +576,7 @@ class PPO:
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
             _learn.check(D, D.scg_mlp_forward(self.agent._flat['p'].data_ptr(), C.byref(c_lay), 1, x.data_ptr(), int(x.shape[0]),
-                                              out.data_ptr(), st))
+                                              out.data_ptr(), row_mask.data_ptr() if row_mask is not None else None, st))
 
     @torch.no_grad()
     def _collect_fused(self):
@@ -580,11 +585,13 @@ class PPO:
         self.env.rollout_policy(self._policy_struct(), T, self.obs, self.act, self.logp, self.rew, self.done, self.flags,
                                 terminal_obs=self.term_obs, episode_acc=self._episode_acc)
         self._critic_batch(self.obs.view((T + 1) * N, self.obs_dim), self._v_all.view(-1))
-        self._critic_batch(self.term_obs.view(T * N, self.obs_dim), self._tv.view(-1))
+        # time truncation is not termination (ppo.py:276-283): bootstrap with the critic's value of the terminal observation
+        # — evaluated only on the 32-row tiles that hold a truncated row
+        trunc_u8 = (self.flags & 1) & self.done
+        self._critic_batch(self.term_obs.view(T * N, self.obs_dim), self._tv.view(-1), row_mask=trunc_u8.view(-1))
         self.v.copy_(self._v_all[:T])
         mask = 1.0 - self.done.to(torch.float32)
-        trunc = (self.flags & 1).bool() & self.done.bool()
-        terminal_v = torch.where(trunc, self._tv, torch.zeros_like(self._tv))
+        terminal_v = torch.where(trunc_u8.bool(), self._tv, torch.zeros_like(self._tv))
         rew = self.rew.clone()
         ret, adv = self._gae(rew, self.v, mask, terminal_v, self._v_all[T], cfg.gamma, cfg.gae_lambda, cfg.use_gae)
         moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])

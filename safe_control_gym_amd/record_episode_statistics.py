@@ -82,8 +82,48 @@ class VecRecordEpisodeStatistics:
         self.venv.close()
 
 
-def make_vec_envs(env_id, task_config, batch_size=1, n_processes=1, seed=None, **kwargs):
-    """Counterpart of vectorized_env/__init__.py:42-66: ONE HipVecEnv holds the whole batch (n_processes is
-    accepted for call compatibility and ignored — there are no worker processes)."""
+def resolve_env_func(env_func):
+    """(env_id, task_config) behind the `env_func` every reference controller receives —
+    `partial(make, task, output_dir=..., **task_config)` (examples/rl/train_rl_model.py / rl_experiment.py:
+    train_rl_controller.py:32-36), with `make` the reference's utils.registration.make or this package's.  Also accepted: a
+    partial of an env class named CartPole / Quadrotor, and objects exposing `.env_id` / `.task_config`."""
+    import functools
+    if hasattr(env_func, 'env_id') and hasattr(env_func, 'task_config'):
+        return env_func.env_id, dict(env_func.task_config)
+    if isinstance(env_func, functools.partial):
+        kw = dict(env_func.keywords or {})
+        if env_func.args and isinstance(env_func.args[0], str):
+            return env_func.args[0], kw
+        name = getattr(env_func.func, '__name__', '').lower()
+        if name in ('cartpole', 'quadrotor'):
+            return name, kw
+    raise TypeError('make_vec_envs needs env_func = functools.partial(make, <env id>, **task_config) (what the reference\'s '
+                    'training scripts build), a partial of CartPole / Quadrotor, or an object with .env_id / .task_config')
+
+
+def make_vec_envs(env_func, env_configs=None, batch_size=1, n_processes=1, seed=None, **kwargs):
+    """Drop-in for envs/env_wrappers/vectorized_env/__init__.py:42-66 — same signature, same call sites
+    (`make_vec_envs(env_func, None, rollout_batch_size, num_workers, seed)`, controllers/ppo/ppo.py:48, sac/sac.py:50):
+    returns ONE HipVecEnv holding the whole batch instead of DummyVecEnv / SubprocVecEnv over `batch_size` Python envs.
+
+    * env_func: see resolve_env_func; keys the simulator has no use for (output_dir, gui, verbose, ...) are accepted and
+      ignored exactly like the env constructors' **kwargs upstream.
+    * env_configs: upstream's per-env "non-shareable" kwargs; a HipVecEnv shares one config, so only None / all-equal
+      entries are accepted (they are merged into the task config).
+    * n_processes: accepted for call compatibility; there are no worker processes (the batch is one kernel launch).
+    * seed: upstream seeds env `rank` with seed + rank (:28-38); here it is the Philox key, env ids are the counter.
+    Historic form `make_vec_envs(env_id: str, task_config: dict, batch_size, ...)` is still accepted."""
     from safe_control_gym_amd.vec_env import HipVecEnv
-    return HipVecEnv(env_id, batch_size, seed=0 if seed is None else seed, **{**task_config, **kwargs})
+    if isinstance(env_func, str):
+        env_id, cfg = env_func, dict(env_configs or {})
+    else:
+        env_id, cfg = resolve_env_func(env_func)
+        if env_configs is not None:
+            cfgs = list(env_configs)
+            if any(c != cfgs[0] for c in cfgs):
+                raise NotImplementedError('per-env configs differ: a HipVecEnv holds N copies of ONE task config')
+            if cfgs:
+                cfg.update(cfgs[0])
+    cfg.update(kwargs)
+    cfg.pop('seed', None)
+    return HipVecEnv(env_id, batch_size, seed=0 if seed is None else seed, **cfg)

@@ -183,10 +183,13 @@ class SACAgent:
         if 'log_alpha' in sd:
             with torch.no_grad():
                 self.log_alpha.copy_(torch.as_tensor(sd['log_alpha'], dtype=self.log_alpha.dtype).reshape(()))
-        if with_optimizers and 'actor_opt' in sd and not self.use_graphs:
+        if with_optimizers and 'actor_opt' in sd:
+            # (also with HIP graphs on: capturable Adam keeps its state in device tensors, which load_state_dict replaces —
+            #  the captured update graph aliases the old ones and is re-captured on the next update)
             self.actor_opt.load_state_dict(sd['actor_opt'])
             self.critic_opt.load_state_dict(sd['critic_opt'])
             self.alpha_opt.load_state_dict(sd['alpha_opt'])
+            self._graph = None
 
     def policy_loss(self, batch):
         obs = batch['obs']

@@ -50,9 +50,17 @@ def test_mfma_forward_equals_torch(shape):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for lay, nout, net in ((a_lay, act_dim, ag.ac.actor.pi_net), (c_lay, 1, ag.ac.critic.v_net)):
         out = torch.full((M, nout), float('nan'), device='cuda')
-        _learn.check(D, D.scg_mlp_forward(ag._flat['p'].data_ptr(), C.byref(lay), nout, x.data_ptr(), M, out.data_ptr(), st))
+        _learn.check(D, D.scg_mlp_forward(ag._flat['p'].data_ptr(), C.byref(lay), nout, x.data_ptr(), M, out.data_ptr(), None, st))
         ref = net(x)
         torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+        # sparse evaluation: flagged rows get their value, tiles without a flagged row are zero
+        mask = torch.zeros(M, dtype=torch.uint8, device='cuda')
+        mask[[5, 40, 700, 999]] = 1
+        out2 = torch.full((M, nout), float('nan'), device='cuda')
+        _learn.check(D, D.scg_mlp_forward(ag._flat['p'].data_ptr(), C.byref(lay), nout, x.data_ptr(), M, out2.data_ptr(),
+                                          mask.data_ptr(), st))
+        torch.testing.assert_close(out2[mask.bool()], ref[mask.bool()], rtol=2e-5, atol=2e-5)
+        assert torch.isfinite(out2).all() and (out2[64:640] == 0).all()
 
 
 @pytest.mark.parametrize('clipped_value', [False, True])

@@ -34,6 +34,7 @@ def test_fused_rollout_equals_step_by_step(task, hidden, act):
     done, flags = torch.zeros(K, n, dtype=torch.uint8, device=env.device), torch.zeros(K, n, dtype=torch.uint8, device=env.device)
     term, acc = torch.zeros(K, n, nobs, **f), torch.zeros(n, 8, **f)
     # (a) deterministic policy: must reproduce actor-mean actions fed to scg_step one step at a time
+    ref.reset_tensors()                             # (PPO's constructor already reset `env` once: keep the episode indices equal)
     env.reset_tensors(); o = ref.reset_tensors().clone()
     env.rollout_policy(ppo._policy_struct(True), K, obs, actb, logp, rew, done, flags, terminal_obs=term, episode_acc=acc)
     torch.cuda.synchronize()

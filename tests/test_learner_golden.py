@@ -1,0 +1,76 @@
+"""This repo's PPO / SAC learners against known answers produced by the REFERENCE's own classes
+(tests/golden/make_learner.py: controllers/ppo/ppo_utils.py PPOAgent.update, PPOBuffer, MLPActorCritic.step,
+compute_returns_and_advantages; controllers/sac/sac_utils.py SACAgent.update, SACBuffer) on fixed data: same initial
+weights, same minibatch index batches, same torch seed -> same final weights, optimiser step counts and loss statistics.
+Eager CPU path here; tests/test_gpu_learn.py and tests/test_gpu_rl.py pin the fused / graphed GPU paths to it."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'learner.npz'))
+
+
+def sd(prefix):
+    return {k[len(prefix) + 1:]: torch.as_tensor(G[k]) for k in G.files if k.startswith(prefix + '/')}
+
+
+def test_ppo_agent_update_reproduces_the_reference():
+    from safe_control_gym_amd.ppo import PPOAgent, PPOConfig
+    cfg = PPOConfig(hidden_dim=32, activation='tanh', use_clipped_value=False, clip_param=0.2, target_kl=0.02, entropy_coef=0.01,
+                    actor_lr=3e-3, critic_lr=1e-3, opt_epochs=3, mini_batch_size=64)
+    ag = PPOAgent(12, 2, cfg, 'cpu')
+    ag.ac.load_state_dict(sd('ppo/init'))
+    data = {k: torch.as_tensor(G[f'ppo/data/{k}']) for k in ('obs', 'act', 'logp', 'adv', 'ret', 'v')}
+    # the buffer's MLPActorCritic.step outputs: log-probs / values of the stored actions under the initial weights
+    from safe_control_gym_amd.ppo import normal_log_prob
+    with torch.no_grad():
+        mean, logstd = ag.ac.actor(data['obs'])
+        torch.testing.assert_close(normal_log_prob(mean, logstd, data['act']), data['logp'].reshape(-1), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(ag.ac.critic(data['obs']), data['v'], rtol=1e-5, atol=1e-5)
+    flat = {k: (v.reshape(-1) if k in ('logp', 'adv', 'ret', 'v') else v) for k, v in data.items()}
+    res = ag.update(flat, perms=G['ppo/perms'])
+    assert res['actor_steps'] == int(G['ppo/actor_adam_steps']) and res['minibatches'] == int(G['ppo/critic_adam_steps'])
+    np.testing.assert_allclose([res['policy_loss'], res['value_loss'], res['entropy_loss'], res['approx_kl']], G['ppo/results'],
+                               rtol=2e-5, atol=2e-6)
+    final = sd('ppo/final')
+    for k, v in ag.ac.state_dict().items():
+        torch.testing.assert_close(v, final[k], rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_sac_agent_update_reproduces_the_reference():
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    cfg = SACConfig(hidden_dim=32, activation='relu', gamma=0.98, tau=0.01, init_temperature=0.3, use_entropy_tuning=True,
+                    actor_lr=1e-3, critic_lr=2e-3, entropy_lr=3e-3, extra={'cuda_graphs': False})
+    low, high = torch.tensor([-1.0, 0.0]), torch.tensor([1.0, 2.0])
+    ag = SACAgent(6, 2, low, high, cfg, 'cpu')
+    ag.ac.load_state_dict(sd('sac/init'), strict=False)
+    ag.ac_targ.load_state_dict(sd('sac/init'), strict=False)
+    # SACBuffer semantics: ring of 200, five pushes of 50 (wraps), stored arrays
+    rng = np.random.default_rng(9)
+    buf = DeviceReplay(200, 6, 2, 'cpu')
+    for _ in range(5):
+        n = 50
+        b = {'obs': rng.normal(0, 1, (n, 6)), 'act': rng.uniform([-1, 0], [1, 2], (n, 2)), 'rew': rng.normal(0, 1, (n,)),
+             'next_obs': rng.normal(0, 1, (n, 6)), 'mask': (rng.uniform(size=n) > 0.1).astype(np.float32)}
+        t = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in b.items()}
+        buf.push(t['obs'], t['act'], t['rew'], t['next_obs'], t['mask'])
+    assert [buf.pos, buf.size] == G['sac/buffer/pos_size'].tolist()
+    for k in ('obs', 'act', 'rew', 'next_obs', 'mask'):
+        np.testing.assert_array_equal(getattr(buf, k).numpy().reshape(G[f'sac/buffer/{k}'].shape), G[f'sac/buffer/{k}'])
+    torch.manual_seed(13)
+    res = []
+    for idx in G['sac/indices']:
+        idx = torch.as_tensor(idx)
+        batch = {k: getattr(buf, k)[idx] for k in ('obs', 'act', 'rew', 'next_obs', 'mask')}
+        r = ag.update(batch)
+        res.append([float(r['policy_loss']), float(r['critic_loss']), float(r['entropy_loss'])])
+    np.testing.assert_allclose(res, G['sac/results'], rtol=2e-5, atol=2e-6)
+    for prefix, net in (('sac/final', ag.ac), ('sac/final_targ', ag.ac_targ)):
+        final = sd(prefix)
+        for k, v in net.state_dict().items():
+            if k in final:
+                torch.testing.assert_close(v, final[k], rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f'{prefix} {k}: {m}')
+    np.testing.assert_allclose(float(ag.log_alpha), float(G['sac/final_log_alpha']), rtol=1e-5)
