@@ -325,7 +325,7 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384):
             el = time.perf_counter() - t0
             flag = torch.tensor([1.0 if ev['ep_return'] >= 236.0 else 0.0, 1.0 if el > budget_s else 0.0], device=env.device)
             if world > 1:                               # rank 0 decides for everybody
-                dist.broadcast(flag, src=0)
+                parallel.broadcast_(flag, 0)
             if flag[0].item() > 0:
                 reached = el
                 break

@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--respect-yaml-init', action='store_true',
                     help='honour init_state_randomization_info of the YAML (the reference class ignores it)')
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--save-final', default=None, help='write <path>.rank<r>.pt: final flat parameters + this rank\'s first rollout observations')
     ap.add_argument('--no-graphs', action='store_true', help='eager PyTorch update / rollout instead of HIP-graph replay')
     ap.add_argument('--no-fused-rollout', action='store_true', help='rollout / evaluation as HIP graphs of PyTorch policy + step kernel')
     ap.add_argument('--no-fused', action='store_true', help='PyTorch (graphed) minibatch update instead of the fused MFMA kernels')
@@ -69,6 +70,7 @@ def main():
                      rollout_batch_size=args.envs, rollout_steps=args.rollout_steps, max_env_steps=int(args.max_env_steps),
                      extra={'cuda_graphs': not args.no_graphs, 'fused_update': not args.no_fused})
     ppo = PPO(env, pcfg, seed=args.seed)
+    init_params = torch.cat([p.detach().reshape(-1) for p in ppo.agent.ac.parameters()]).cpu()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reached = None
@@ -91,6 +93,10 @@ def main():
             reached = res['wall_clock']
             break
     total = time.perf_counter() - t0
+    if args.save_final:
+        torch.save({'params': torch.cat([p.detach().reshape(-1) for p in ppo.agent.ac.parameters()]).cpu(),
+                    'init_params': init_params, 'env_id_offset': env.env_id_offset, 'first_obs': ppo.obs[0][:8].cpu(), 'iterations': it},
+                   f'{args.save_final}.rank{rank}.pt')
     if rank == 0:
         print(json.dumps({'summary': True, 'task': args.task, 'n_gpus': world, 'envs_per_gpu': args.envs,
                           'iterations': it, 'env_steps': ppo.total_steps, 'wall_clock_s': total,

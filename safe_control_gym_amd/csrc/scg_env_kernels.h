@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
 // Observation rows of one full wave -> memory as fully coalesced 16-byte stores.  Each lane holds the row of its own
 // env (NROW elements, RB = row bytes, a multiple of 16); stored lane-by-lane that is a 16-byte piece every RB bytes —
 // 64 partial cache lines per instruction, which the write path handles at a fraction of the speed of full lines
-// (profiles/r01_store_layouts.md).  The wave's rows form one contiguous 64*RB block, so the rows are transposed through
+// (profiles/r01_latency_budget.md §3).  The wave's rows form one contiguous 64*RB block, so the rows are transposed through
 // LDS (wave-private region, no workgroup barrier) and piece p of the block is written by lane p % 64.
 template <typename T, int NROW>
 __device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T* row, unsigned char* lds_wave, int lane) {

@@ -36,6 +36,33 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _through_host(t):
+    """gloo (tests: several ranks sharing one GPU) has no device collectives in this build: stage device tensors on the host."""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+def _all_reduce(t, op=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _through_host(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def broadcast_(t, src=0):
+    if world_size() > 1:
+        if _through_host(t):
+            h = t.cpu()
+            dist.broadcast(h, src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src)
+    return t
+
+
 class FlatBucket:
     """Gradients of a fixed parameter list + a few scalars packed into one contiguous fp32 buffer."""
 
@@ -62,7 +89,7 @@ class FlatBucket:
     def all_reduce_mean(self):
         w = world_size()
         if w > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+            _all_reduce(self.buf)
             self.buf.div_(w)
         return self.buf
 
@@ -78,7 +105,7 @@ class FlatBucket:
 
 def all_reduce_sum_(t):
     if world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce(t)
     return t
 
 
@@ -87,6 +114,6 @@ def broadcast_parameters(modules, src=0):
     if world_size() > 1:
         for m in modules:
             for p in m.parameters():
-                dist.broadcast(p.data, src)
+                broadcast_(p.data, src)
             for b in m.buffers():
-                dist.broadcast(b.data, src)
+                broadcast_(b.data, src)

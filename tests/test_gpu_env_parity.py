@@ -404,6 +404,7 @@ def test_full_and_partial_waves_specialised_store_paths(name, dtype):
             gpu.set_raw_state(_raw_state(oracle))
             gpu.set_counters(oracle.ctrl_step_counter, oracle.episode)
         act = rng.uniform(-1, 1, (n, oracle.action_dim))
+        prev_steps = np.asarray(oracle.ctrl_step_counter).copy()
         obs_o, rew_o, done_o, info = ovec.step(act)
         out = gpu.step_tensors(torch.as_tensor(act, dtype=dtype, device=gpu.device))
         msg = f'{name} t={t}'
@@ -419,8 +420,8 @@ def test_full_and_partial_waves_specialised_store_paths(name, dtype):
         n_done += len(d)
         if len(d):
             np.testing.assert_allclose(_np(out.terminal_obs)[d], info['terminal_observation'][d], err_msg=msg, **tol)
-            np.testing.assert_allclose(_np(out.fin_length)[d], info['episode_length'][d] if 'episode_length' in info
-                                       else _np(out.fin_length)[d], err_msg=msg)
+            # finished-episode length: the oracle's pre-reset step counter of those envs
+            np.testing.assert_array_equal(_np(out.fin_length)[d], np.asarray(prev_steps)[d] + 1, err_msg=msg)
     assert n_done > 0
     gpu.close()
 

@@ -97,6 +97,7 @@ def _dp_worker(rank, world, port, out_path):
     dist.all_gather(gathered, flat)
     if rank == 0:
         torch.save({'params': gathered, 'res': res}, out_path)
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -238,6 +239,7 @@ def _norm_worker(rank, world, port, out_path):
         nz(x[rank * 32:(rank + 1) * 32])            # each rank sees its shard; statistics are reduced over ranks
     if rank == 0:
         torch.save({'mean': nz.rms.mean, 'var': nz.rms.var, 'count': nz.rms.count}, out_path)
+    dist.barrier()
     dist.destroy_process_group()
 
 

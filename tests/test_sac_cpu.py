@@ -93,3 +93,66 @@ def test_shipped_reference_sac_actor_loads_and_acts():
     got = ac.act(torch.as_tensor(obs), deterministic=True).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
     assert np.all(np.abs(got) <= 1.0)
+
+
+
+class _SlicedNoise:
+    """torch.randn_like stand-in: call k returns rows [lo, hi) of the k-th seeded [256, d] draw, so that two ranks holding
+    half a batch each see exactly the noise one process holding the whole batch sees."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi, self.k = lo, hi, 0
+
+    def __call__(self, like):
+        g = torch.Generator().manual_seed(1000 + self.k)
+        self.k += 1
+        return torch.randn(256, like.shape[1], generator=g)[self.lo:self.hi]
+
+
+def _sac_batch():
+    g = torch.Generator().manual_seed(3)
+    return {'obs': torch.randn(256, 6, generator=g), 'act': torch.rand(256, 2, generator=g) * 2 - 1, 'rew': torch.randn(256, 1, generator=g),
+            'next_obs': torch.randn(256, 6, generator=g), 'mask': (torch.rand(256, 1, generator=g) > 0.2).float()}
+
+
+def _sac_run(lo, hi, seed):
+    from unittest import mock
+    torch.manual_seed(seed)
+    agent = SACAgent(6, 2, [-1.0, -1.0], [1.0, 1.0], SACConfig(hidden_dim=16, use_entropy_tuning=True, actor_lr=1e-2, critic_lr=1e-2, entropy_lr=1e-2),
+                     torch.device('cpu'))
+    local = {k: v[lo:hi] for k, v in _sac_batch().items()}
+    with mock.patch.object(torch, 'randn_like', _SlicedNoise(lo, hi)):
+        for _ in range(3):
+            agent.update(local)
+    return torch.cat([p.detach().reshape(-1) for p in agent.ac.parameters()] + [agent.log_alpha.detach().reshape(-1)]
+                     + [p.detach().reshape(-1) for p in agent.ac_targ.parameters()])
+
+
+def _sac_dp_worker(rank, world, port, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    flat = _sac_run(rank * 128, (rank + 1) * 128, seed=50 + rank)      # different local init: overwritten by rank 0's broadcast
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save(gathered, out_path)
+    dist.barrier()                                  # nobody tears its sockets down while a peer is still busy
+    dist.destroy_process_group()
+
+
+def test_data_parallel_sac_update_matches_single_process(tmp_path):
+    """2 gloo ranks x 128 samples, flat all-reduce of actor / critic / temperature gradients == 1 process x 256 samples
+    (three consecutive updates, entropy tuning on, Polyak targets included)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'sac_dp.pt')
+    mp.spawn(_sac_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.testing.assert_close(got[0], got[1], rtol=0, atol=0)
+    ref = _sac_run(0, 256, seed=50)
+    torch.testing.assert_close(got[0], ref, rtol=1e-4, atol=1e-5)
