@@ -234,6 +234,17 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uin
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, v, s, 0);
 }
 
+// 16-byte store.  The uniform array offset goes through the VECTOR offset here (one v_add per row, the chunk constants
+// fold into the instruction's immediate), NOT through soffset: a VMEM store of more than 64 bits reads its data VGPRs
+// over several cycles, a VALU write to them in the next issue slots can overtake the read, and LLVM (ROCm 7.2) pads
+// that hazard only when soffset is not an SGPR ("... only exists if the instruction is not using a register in the
+// soffset field", GCNHazardRecognizer) — which does not hold on MI355X: `buffer_store_dwordx4 v[42:45], v27, s[40:43],
+// s4 offen` + `v_mov_b32 v42, s6` tore 16-64 doubles out of 1.5 M on a cold first launch
+// (tests/test_gpu_parity_scale.py; tools/hazard_lint.py proves the pattern absent from every built library).
+__device__ __forceinline__ void buf_st128(u32x4 d, __amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t array_off, uint32_t k) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, lane_off + array_off + k, 0, 0);
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     // raw buffer (stride 0), no range limit, gfx9 32-bit data format word
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
@@ -268,7 +279,7 @@ struct Slot {
             Pack<per> p;
 #pragma unroll
             for (int j = 0; j < per; ++j) p.e[j] = x[c * per + j];
-            if constexpr (W == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), r, off, soff + (uint32_t)(c * W), 0);
+            if constexpr (W == 16) buf_st128(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * W));
             else if constexpr (W == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p), r, off, soff + (uint32_t)(c * W), 0);
             else buf_st(r, off, soff + (uint32_t)(c * W), p.e[0]);
         }
@@ -280,7 +291,7 @@ struct Slot {
         Pack<M> p;
 #pragma unroll
         for (int j = 0; j < M; ++j) p.e[j] = x[j];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), r, off, soff + (uint32_t)(c * 16), 0);
+        buf_st128(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * 16));
     }
     template <int N>
     __device__ __forceinline__ void load_row(U* x) const {

@@ -210,8 +210,7 @@ __device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T
 #pragma unroll
     for (int c = 0; c < RB / 16; ++c) {
         const Piece p = *reinterpret_cast<const Piece*>(lds_wave + (c * 64 + lane) * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), dst.r, block_off + (uint32_t)(lane * 16),
-                                               dst.soff + (uint32_t)(c * 1024), 0);
+        buf_st128(__builtin_bit_cast(u32x4, p), dst.r, block_off + (uint32_t)(lane * 16), dst.soff, (uint32_t)(c * 1024));
     }
 }
 
