@@ -294,7 +294,7 @@ def fused_rollout_leg(torch, n, T=32):
             'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments'}
 
 
-def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384):
+def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=65536, lr=2e-3, target_kl=0.03, epochs=4):
     """PPO wall-clock until the deterministic-policy evaluation return reaches the reference reward (236 / 250, BASELINE.md
     §2): fused rollout, fused MFMA update, fused evaluation; the clock starts after construction and includes every
     evaluation.  With several ranks: env shards + one flat gradient all-reduce per minibatch (RCCL)."""
@@ -308,14 +308,14 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384):
     for seed in range(1, seeds + 1):
         env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
         eval_env = HipVecEnv(env_id, 256, seed=seed * 111, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
-        pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=0.03,
-                         entropy_coef=0.01, opt_epochs=4, mini_batch_size=65536, actor_lr=2e-3, critic_lr=2e-3,
+        pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=target_kl,
+                         entropy_coef=0.01, opt_epochs=epochs, mini_batch_size=minibatch, actor_lr=lr, critic_lr=lr,
                          rollout_batch_size=envs, rollout_steps=32)
         ppo = PPO(env, pcfg, seed=seed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         reached, best, it = None, -1e30, 0
-        max_it = int(budget_s / 0.02)                   # iteration cap (identical on every rank: no rank leaves a collective alone)
+        max_it = int(budget_s / 0.01)                   # iteration cap (identical on every rank: no rank leaves a collective alone)
         while it < max_it:
             ppo.train_step()
             it += 1
@@ -337,7 +337,8 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384):
     return {'target_return': 236.0, 'envs_per_gpu': envs, 'rollout_steps': 32, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
             'wall_clock_to_target_s': times, 'iterations': its, 'best_eval_return': best_all, 'reached': len(ok),
             'median_s': statistics.median(ok) if ok else None, 'budget_s_per_seed': budget_s,
-            'hyper': 'MLP 12-128-128-{2,1} tanh, 4 epochs x 8 minibatches of 65 536, lr 2e-3, target_kl 0.03, GAE 0.95, gamma 0.99, ent 0.01',
+            'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {envs * 32 // minibatch} minibatches of {minibatch}, lr {lr:g}, '
+                     f'target_kl {target_kl:g}, GAE 0.95, gamma 0.99, ent 0.01',
             'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA) + fused evaluation every iteration'}
 
 

@@ -230,6 +230,78 @@ def test_rarl_alternates_protagonist_and_adversary_on_the_adversary_channel():
         RARL(_env('quadrotor_2D_track', 64), cfg)
 
 
+def test_rarl_graph_and_eager_collectors_agree_on_deterministic_quantities():
+    """The captured two-policy collection (one HIP graph: T x (protagonist, adversary, env kernel) + both GAE passes) against
+    the eager one: values are deterministic functions of the stored observations, and the adversary's returns are built
+    from -reward."""
+    from safe_control_gym_amd.ppo import PPOConfig
+    from safe_control_gym_amd.rarl import RARL
+    for graphs in (True, False):
+        env = _env('quadrotor_2D_track', 256, adversary_disturbance='action', adversary_disturbance_scale=0.1)
+        cfg = PPOConfig(hidden_dim=32, use_gae=True, opt_epochs=1, mini_batch_size=1024, rollout_steps=8, extra={'cuda_graphs': graphs})
+        r = RARL(env, cfg, seed=3)
+        assert (r._two_graph is None) and r._graph_rollout == graphs
+        (ret, adv, mom), (ret_a, adv_a, mom_a) = r.collect()
+        assert (r._two_graph is not None) == graphs
+        with torch.no_grad():
+            torch.testing.assert_close(r.v[3], r.agent.ac.critic(r.obs[3]).squeeze(-1), rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(r.v_adv[3], r.adversary.ac.critic(r.obs[3]).squeeze(-1), rtol=1e-5, atol=1e-6)
+            mean, logstd = r.adversary.ac.actor(r.obs[5])
+            lp = (-0.5 * ((r.act_adv[5] - mean) / logstd.exp()) ** 2 - logstd - 0.9189385332046727).sum(-1)
+            torch.testing.assert_close(r.logp_adv[5], lp, rtol=1e-4, atol=1e-4)
+        # the adversary's returns / advantages: ppo_utils.py:374-402 on -reward with the adversary's critic
+        with torch.no_grad():
+            crit = r.adversary.ac.critic
+            mask = 1.0 - r.done.float()
+            trunc = ((r.flags & 1).bool() & r.done.bool())
+            tv = torch.where(trunc, crit(r.term_obs).squeeze(-1), torch.zeros_like(r.rew))
+            rews = -r.rew + 0.99 * tv
+            vals = torch.cat([r.v_adv, crit(r.obs[8]).squeeze(-1)[None]])
+            run_ret, run_adv = vals[8], torch.zeros(256, device=r.device)
+            for i in reversed(range(8)):
+                run_ret = rews[i] + 0.99 * mask[i] * run_ret
+                run_adv = run_adv * 0.95 * 0.99 * mask[i] + rews[i] + 0.99 * mask[i] * vals[i + 1] - vals[i]
+                torch.testing.assert_close(ret_a[i], run_ret, rtol=1e-5, atol=1e-5)
+                torch.testing.assert_close(adv_a[i], run_adv, rtol=1e-5, atol=1e-5)
+        assert float(mom[2]) == 8 * 256 and torch.isfinite(adv).all() and torch.isfinite(adv_a).all()
+        res = r.train_step()
+        assert res['step'] == 3 * 8 * 256 and np.isfinite(res['policy_loss_adv'])
+        env.close()
+
+
+def test_rap_population_groups_and_updates():
+    """rap.py:349-470: sorted adversary index per env (contiguous groups), every env faces ITS adversary, every collection
+    starts from a reset, the protagonist learns from the whole batch and each sampled adversary from its slice."""
+    from safe_control_gym_amd.ppo import PPOConfig
+    from safe_control_gym_amd.rarl import RAP
+    env = _env('quadrotor_2D_track', 384, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05)
+    cfg = PPOConfig(hidden_dim=32, use_gae=True, opt_epochs=2, mini_batch_size=512, rollout_steps=8, actor_lr=1e-3, critic_lr=1e-3)
+    r = RAP(env, cfg, seed=4, num_adversaries=3)
+    w0 = [{k: v.clone() for k, v in a.ac.state_dict().items()} for a in r.adversaries]
+    wa = {k: v.clone() for k, v in r.agent.ac.state_dict().items()}
+    res = r.train_step()
+    idx = r.adv_index.cpu().numpy()
+    assert (np.diff(idx) >= 0).all() and set(idx) <= {0, 1, 2}
+    assert [g[0] for g in r.groups] == res['adv_indices'] == sorted(set(idx))
+    assert r.groups[0][1] == 0 and r.groups[-1][2] == 384 and all(a[2] == b[1] for a, b in zip(r.groups, r.groups[1:]))
+    for k, s, e in r.groups:
+        assert (idx[s:e] == k).all()
+        assert f'value_loss_adv{k}' in res
+    assert res['step'] == 8 * 384
+    assert any(not torch.equal(v, wa[k]) for k, v in r.agent.ac.state_dict().items())
+    for k in range(3):
+        changed = any(not torch.equal(v, w0[k][name]) for name, v in r.adversaries[k].ac.state_dict().items())
+        assert changed == (k in res['adv_indices'])
+    # a fresh collection: the stored adversary values are those of each env's own adversary
+    r.collect()
+    with torch.no_grad():
+        for k, s, e in r.groups:
+            torch.testing.assert_close(r.v_adv[2, s:e], r.adversaries[k].ac.critic(r.obs[2, s:e]).squeeze(-1), rtol=1e-5, atol=1e-6)
+    step, _ = env.get_counters()
+    assert (step <= 8).all()                        # the collection started from a reset
+    env.close()
+
+
 def test_safe_explorer_ppo_pretrain_and_step():
     """safe_ppo.py: constraint-model pre-training on random transitions (c_next = the step's pre-reset constraint values),
     then a PPO iteration whose policy mean is filtered by the safety layer with the current constraint values as input."""

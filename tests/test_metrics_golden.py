@@ -1,0 +1,29 @@
+"""episode_metrics (the device-side MetricExtractor) against metrics computed by the reference's own MetricExtractor
+(tests/golden/make_metrics.py -> metrics.npz; experiments/base_experiment.py:380-492)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from safe_control_gym_amd.ppo import episode_metrics
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'metrics.npz'))
+
+
+@pytest.mark.parametrize('case', ['one', 'three', 'many'])
+def test_episode_metrics_reproduce_metric_extractor(case):
+    tot = torch.as_tensor(G[f'{case}/totals'])
+    got = episode_metrics(tot[:, 0], tot[:, 1], tot[:, 2], tot[:, 3])
+    for k, ref in zip(G['keys'], G[f'{case}/metrics']):
+        np.testing.assert_allclose(got[str(k)], ref, rtol=1e-12, atol=1e-14, err_msg=str(k))
+
+
+def test_valid_mask_selects_finished_episodes():
+    tot = torch.as_tensor(G['many/totals'])
+    pad = torch.cat([tot, torch.full((5, 4), 123.0, dtype=tot.dtype)])
+    valid = torch.cat([torch.ones(40, dtype=torch.bool), torch.zeros(5, dtype=torch.bool)])
+    got = episode_metrics(pad[:, 0], pad[:, 1], pad[:, 2], pad[:, 3], valid=valid)
+    for k, ref in zip(G['keys'], G['many/metrics']):
+        np.testing.assert_allclose(got[str(k)], ref, rtol=1e-12, atol=1e-14, err_msg=str(k))
+    assert episode_metrics(pad[:, 0], pad[:, 1], pad[:, 2], pad[:, 3], valid=torch.zeros(45, dtype=torch.bool)) == {}
