@@ -270,6 +270,42 @@ def gae_leg(torch):
     return out
 
 
+def sequence_leg(torch, n, K=32, task='quadrotor_2D_track'):
+    """The same control steps with K of them per launch (scg_step_sequence): caller-supplied action sequences resident in
+    HBM, every per-step output (obs, reward, done, flags, terminal observation where done) written to [K]-stacked arrays,
+    state in registers between steps.  Its own algorithmic bytes: per env-step the action read and the four outputs; state,
+    counters and episode statistics move once per launch."""
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task(task)
+    env = HipVecEnv(env_id, n, seed=7, return_numpy=False, **cfg)
+    env.reset_tensors()
+    acts = torch.rand(K, n, env.spec.nu, device=env.device) * 2 - 1
+    out = env.step_sequence(acts, terminal_obs=True)
+    for _ in range(3):
+        env.step_sequence(acts, out=out)
+    reps = 40
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        env.step_sequence(acts, out=out)
+    ev[1].record()
+    torch.cuda.synchronize()
+    us = 1e3 * ev[0].elapsed_time(ev[1]) / reps
+    ok = bool(torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all())
+    spec = env.spec
+    per_step = 4 * spec.nu + 4 * spec.obs_dim + 4 + 1 + 1
+    per_launch = 2 * (4 * env._n_state_arrays() + 8) + 32              # state + counters in and out, episode statistics RMW
+    bytes_es = per_step + per_launch / K
+    rate = n * K / (us * 1e-6)
+    env.close()
+    return {'envs': n, 'steps_per_launch': K, 'us_per_launch': us, 'us_per_control_step': us / K, 'env_steps_per_s': rate,
+            'algorithmic_bytes_per_env_step': bytes_es, 'achieved_GBs': rate * bytes_es / 1e9,
+            'frac': rate * bytes_es / 1e9 / HBM_PEAK_GBS, 'finite_outputs': ok,
+            'note': 'parity: tests/test_gpu_sequence.py (bit-identical to K x scg_step); the headline above stays one launch per control step'}
+
+
 def fused_rollout_leg(torch, n, T=32):
     """K control steps per launch with the PPO actor (12 -> 128 -> 128 -> 2, tanh, exact f32 MFMA) inside the env kernel."""
     from safe_control_gym_amd.ppo import PPO, PPOConfig
@@ -432,6 +468,10 @@ def main():
             out['gae'] = gae_leg(torch)
         except Exception as exc:                                    # noqa: BLE001
             out['gae'] = {'error': repr(exc)[:200]}
+        try:
+            out['sequence'] = sequence_leg(torch, N)
+        except Exception as exc:                                    # noqa: BLE001
+            out['sequence'] = {'error': repr(exc)[:200]}
         try:
             out['fused_rollout'] = fused_rollout_leg(torch, N)
         except Exception as exc:                                    # noqa: BLE001

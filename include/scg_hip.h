@@ -253,6 +253,26 @@ int scg_step_range(scg_env* env, int first_env, int n_envs, const void* d_action
  * semantics as scg_step, state kept in registers between steps. */
 int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_out* out, void* stream);
 
+/* K control steps per launch with CALLER-SUPPLIED action sequences: exactly
+ *     for t in range(K): obs[t], rew[t], done[t], info[t] = vec_env.step(actions[t])
+ * (dummy_vec_env.py:24-41 called K times: same per-step semantics as scg_step incl. auto-reset, terminal observation and
+ * episode statistics) with the state kept in registers between steps.  For open-loop consumers: sampling-based MPC scoring
+ * candidate action sequences, replay of logged actions, system identification.  Every per-step output is [K]-stacked. */
+typedef struct {
+    const void* d_actions;      /* [K][N][action_dim] */
+    const void* d_adv_actions;  /* [K][N][adv_dim] already scaled (benchmark_env.py:216-228), or NULL */
+    void* d_obs;                /* [K][N][obs_dim]  observation returned by step t (post auto-reset) */
+    void* d_reward;             /* [K][N] */
+    uint8_t* d_done;            /* [K][N] */
+    uint8_t* d_flags;           /* [K][N] bits as in scg_step_out */
+    void* d_terminal_obs;       /* [K][N][obs_dim] written where done, or NULL */
+    void* d_mse;                /* [K][N] or NULL */
+    void* d_c_values;           /* [K][n_con_rows][N] or NULL */
+    void* d_ep_stats;           /* [N][4] running episode totals (read at launch, written back at the end) or NULL */
+    void* d_fin_stats;          /* [K][N][4] totals of the episodes that finished at step t, or NULL */
+} scg_sequence;
+int scg_step_sequence(scg_env* env, int k_steps, const scg_sequence* seq, void* stream);
+
 /* K control steps per launch with the POLICY in the loop — the rollout collector of PPO.train_step
  * (controllers/ppo/ppo.py:266-284) and the evaluation loop of PPO.run (:210-257) as ONE launch: per step the actor MLP
  * obs -> H -> H -> act_dim (ppo_utils.py:149-199; exact float32 on the matrix cores), action = mean + exp(logstd) N(0,1)

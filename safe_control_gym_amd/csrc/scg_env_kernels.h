@@ -464,6 +464,142 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
     Ops::store(P, i, e, dirty);
 }
 
+// K control steps per launch with CALLER-SUPPLIED action sequences (scg_step_sequence): the loop
+//     for t in range(K): obs[t], rew[t], done[t], info = vec_env.step(actions[t])
+// of any open-loop consumer (sampling-based MPC / MPPI scoring candidate sequences, replay of logged actions, system
+// identification, and the bench's synthetic-action workload) as ONE launch.  Per-step semantics are exactly scg_step's
+// (same EnvOps::step, auto-reset, terminal observation, episode statistics); the state stays in registers between steps, every
+// per-step output goes to a [K]-stacked array, and the action of step t+1 is requested before step t is integrated.  What
+// it removes per control step: the 1.5 us dispatch floor, the state / counter round trip and the end-of-kernel store drain.
+template <typename T>
+struct SeqArgs {
+    const T* actions;       // [K][N][nu]
+    const T* adv;           // [K][N][adv_dim] or null
+    int32_t k_steps;
+    T* obs; T* reward; uint8_t* done; uint8_t* flags;       // [K][N](x nobs)
+    T* terminal_obs;        // [K][N][nobs] or null
+    T* mse;                 // [K][N] or null
+    T* c_values;            // [K][rows][N] or null
+    T* ep_stats;            // [N][4] or null (running totals, read-modify-written once per launch)
+    T* fin_stats;           // [K][N][4] or null
+};
+
+template <int SYS, typename T, bool DIST>
+__global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
+                                                              const SeqArgs<T> A) {
+    using Ops = EnvOps<SYS, T, DIST>;
+    using D = Dims<SYS>;
+    const int i = I.env_first + blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = I.num_envs;
+    const bool live = i < I.env_end;
+    typename Ops::E e;
+#ifdef SCG_SPEC
+    constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();     // compile-time constants (see scg_spec.h)
+    const PV<T> P{kcfg, I};
+    const GoalTab<T> goal{nullptr, I.x_goal, false};
+    if (!live) return;
+    const bool full_wave = __builtin_amdgcn_read_exec() == ~0ull;
+    Ops::load_state(P, i, e);
+#else
+    extern __shared__ __align__(16) unsigned char smem[];
+    const StageRegs SR = stage_issue<T, DIST>(Cg, I);
+    {
+        const PV<T> Pg{*Cg, I};
+        if (live) Ops::load_state(Pg, i, e);
+    }
+    const CfgParams<T>* cl;
+    const GoalTab<T> goal = stage_commit<T>(smem, SR, I, cl);
+    if (!live) return;
+    const PV<T> P{*cl, I};
+#endif
+    Ops::load_params(P, i, e);
+    const RngKey key{I.key0, I.key1};
+    const int nobs = P.c.nobs;
+    const int rows = P.c.n_con_rows;
+    T ep[4] = {(T)0, (T)0, (T)0, (T)0};
+    if (A.ep_stats) slot(A.ep_stats, i, 4).template load_row<4>(ep);
+    int ad = 0;
+    if constexpr (DIST) {
+        if (A.adv && P.c.adversary_channel >= 0) ad = P.c.adversary_channel == SCG_CH_ACTION ? D::NU : D::DYN;
+    }
+    T act[D::NU], act_next[D::NU];
+#pragma unroll
+    for (int j = 0; j < D::NU; ++j) act_next[j] = A.actions[(size_t)i * D::NU + j];
+    bool dirty = false;
+    T st[D::NX];
+    for (int t = 0; t < A.k_steps; ++t) {
+#pragma unroll
+        for (int j = 0; j < D::NU; ++j) act[j] = act_next[j];
+        if (t + 1 < A.k_steps) {                        // next step's action: requested now, consumed one step later
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) act_next[j] = A.actions[((size_t)(t + 1) * N + i) * D::NU + j];
+        }
+        T advv[D::DYN > D::NU ? D::DYN : D::NU];
+        const T* advp = nullptr;
+        if constexpr (DIST) {
+            if (ad > 0) {
+                for (int j = 0; j < ad; ++j) advv[j] = A.adv[((size_t)t * N + i) * ad + j];
+                advp = advv;
+            }
+        }
+        const size_t tn = (size_t)t * N;
+        const int32_t c0 = e.step;
+        T noisy[D::NU];
+        const Slot<T> cv = A.c_values ? slot(A.c_values + (size_t)t * rows * N, i) : slot((T*)nullptr, 0);
+        typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, cv, (size_t)N);
+        slot(A.reward + tn, i).store(r.reward);
+        slot(A.done + tn, i).store((uint8_t)(r.done ? 1 : 0));
+        slot(A.flags + tn, i).store((uint8_t)r.flags);
+        if (A.mse) slot(A.mse + tn, i).store(r.mse);
+        ep[0] += r.reward;
+        ep[1] += (T)1;
+        ep[2] += (r.flags & FLAG_VIOLATION) ? (T)1 : (T)0;
+        ep[3] += r.mse;
+        if (r.done) {
+            if (A.fin_stats) slot(A.fin_stats + tn * 4, i, 4).template store_row<4>(ep);
+            ep[0] = ep[1] = ep[2] = ep[3] = (T)0;
+        }
+        const bool do_reset = r.done && P.c.auto_reset;
+        const Slot<T> o_dst = slot(A.obs + tn * nobs, i, nobs);
+        if (Ops::obs_is_row(P)) {
+            T row[2 * D::NX];
+            int nrow = Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, nullptr, row);
+            if (r.done && A.terminal_obs) Ops::store_obs_row(P, row, nrow, slot(A.terminal_obs + tn * nobs, i, nobs));
+            if (do_reset) {
+                dirty = true;
+                Ops::reset(P, i, e, key, st);
+                nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, nullptr, row);
+            }
+#ifdef SCG_SPEC
+            constexpr int kNobs = kcfg.nobs;
+            constexpr bool can_transpose = (kNobs * (int)sizeof(T)) % 16 == 0 && (kNobs == D::NX || kNobs == 2 * D::NX);
+            if constexpr (can_transpose) {
+                __shared__ __align__(16) unsigned char s_obs[BLOCK * kNobs * sizeof(T)];
+                const int lane = (int)(threadIdx.x & 63);
+                if (full_wave) store_rows_coalesced<T, kNobs>(o_dst, row, s_obs + (threadIdx.x >> 6) * (64 * kNobs * (int)sizeof(T)), lane);
+                else Ops::store_obs_row(P, row, nrow, o_dst);
+            } else {
+                Ops::store_obs_row(P, row, nrow, o_dst);
+            }
+#else
+            Ops::store_obs_row(P, row, nrow, o_dst);
+#endif
+        } else {
+            if (r.done && A.terminal_obs)
+                Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, slot(A.terminal_obs + tn * nobs, i, nobs), nullptr);
+            if (do_reset) {
+                dirty = true;
+                Ops::reset(P, i, e, key, st);
+                Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, o_dst, nullptr);
+            } else {
+                Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, o_dst, nullptr);
+            }
+        }
+    }
+    if (A.ep_stats) slot(A.ep_stats, i, 4).template store_row<4>(ep);
+    Ops::store(P, i, e, dirty);
+}
+
 #if defined(SCG_SPEC) && defined(SCG_POLICY_H)
 // ---------------------------------------------------------------------------------------------------------------
 // K control steps per launch WITH THE POLICY IN THE LOOP (PPO.train_step's collector, controllers/ppo/ppo.py:266-284, and

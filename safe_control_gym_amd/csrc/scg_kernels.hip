@@ -710,6 +710,40 @@ extern "C" int scg_rollout_random(scg_env* env, int k_steps, const scg_rollout_o
     return SCG_BY_DTYPE(env, launch_rollout, env, k_steps, out, (hipStream_t)stream);
 }
 
+template <typename T>
+static int launch_sequence(scg_env* env, int k, const scg_sequence* q, hipStream_t st) {
+    const int grid = (env->cfg.num_envs + BLOCK - 1) / BLOCK;
+    const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
+    const InstParams<T> I = inst_of<T>(env);
+    SeqArgs<T> A;
+    A.actions = (const T*)q->d_actions; A.adv = (const T*)q->d_adv_actions; A.k_steps = k;
+    A.obs = (T*)q->d_obs; A.reward = (T*)q->d_reward; A.done = q->d_done; A.flags = q->d_flags;
+    A.terminal_obs = (T*)q->d_terminal_obs; A.mse = (T*)q->d_mse; A.c_values = (T*)q->d_c_values;
+    A.ep_stats = (T*)q->d_ep_stats; A.fin_stats = (T*)q->d_fin_stats;
+    DISPATCH_SYS(env, T, (step_sequence_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, A)));
+    HIP_TRY(hipGetLastError());
+    return SCG_OK;
+}
+
+extern "C" int scg_step_sequence(scg_env* env, int k_steps, const scg_sequence* seq, void* stream) {
+    if (!env || !seq) return fail(SCG_ERR_INVALID, "NULL argument to scg_step_sequence");
+    if (k_steps <= 0) return fail(SCG_ERR_INVALID, "k_steps must be positive");
+    if (!seq->d_actions || !seq->d_obs || !seq->d_reward || !seq->d_done || !seq->d_flags)
+        return fail(SCG_ERR_INVALID, "scg_step_sequence needs d_actions, d_obs, d_reward, d_done and d_flags");
+    if (((uintptr_t)seq->d_obs | (uintptr_t)seq->d_terminal_obs | (uintptr_t)seq->d_ep_stats | (uintptr_t)seq->d_fin_stats) & 15)
+        return fail(SCG_ERR_INVALID, "per-env row outputs (obs, terminal_obs, ep/fin stats) must be 16-byte aligned");
+    {
+        const size_t esz = env->dtype == SCG_F64 ? 8 : 4;
+        int32_t nx, nu, nobs, ns, np;
+        if (scg_dims(&env->cfg, &nx, &nu, &nobs, &ns, &np) != SCG_OK) return SCG_ERR_INVALID;
+        if (((size_t)env->cfg.num_envs * nobs * esz) % 16 != 0)
+            return fail(SCG_ERR_INVALID, "num_envs x obs_dim x sizeof(T) must be a multiple of 16 (row alignment of the stacked arrays)");
+    }
+    if (!env->has_reset) return fail(SCG_ERR_STATE, "scg_reset (all envs) must be called before scg_step_sequence");
+    HIP_TRY(hipSetDevice(env->device));
+    return SCG_BY_DTYPE(env, launch_sequence, env, k_steps, seq, (hipStream_t)stream);
+}
+
 extern "C" int scg_rollout_policy(scg_env* env, const scg_policy* pol, int k_steps, const scg_policy_rollout* out, void* stream) {
     if (!env || !pol || !out) return fail(SCG_ERR_INVALID, "NULL argument to scg_rollout_policy");
 #if defined(SCG_SPEC) && defined(SCG_POLICY_H) && SCG_SPEC_DTYPE == 0

@@ -354,6 +354,39 @@ class HipVecEnv(VecEnv):
         with torch.cuda.device(self.device):
             self._chk(self._lib.scg_rollout_policy(self._h, C.byref(policy), int(k_steps), C.byref(o), self._stream()))
 
+    def step_sequence(self, actions, adv_actions=None, out=None, terminal_obs=True, mse=False, c_values=False, fin_stats=False):
+        """K control steps in ONE launch with caller-supplied actions [K, N, action_dim] (scg_step_sequence) — the same
+        results as K calls of step_tensors(actions[t]).  Returns (and fills, when passed back as `out`) a dict of
+        [K]-stacked tensors: obs [K, N, obs_dim], reward / done / flags [K, N], and on request terminal_obs, mse,
+        c_values [K, rows, N], fin_stats [K, N, 4].  adv_actions: [K, N, adv_dim], already passed through
+        set_adversary_control's clip / scale / offset."""
+        spec = self.spec
+        if actions.dim() != 3 or actions.shape[1:] != (self.num_envs, spec.nu) or actions.dtype != self.dtype or not actions.is_contiguous():
+            raise ValueError(f'actions must be a contiguous [K, {self.num_envs}, {spec.nu}] {self.dtype} tensor')
+        K = int(actions.shape[0])
+        if out is None:
+            f = dict(device=self.device, dtype=self.dtype)
+            u8 = dict(device=self.device, dtype=torch.uint8)
+            out = {'obs': torch.empty(K, self.num_envs, spec.obs_dim, **f), 'reward': torch.empty(K, self.num_envs, **f),
+                   'done': torch.empty(K, self.num_envs, **u8), 'flags': torch.empty(K, self.num_envs, **u8)}
+            if terminal_obs:
+                out['terminal_obs'] = torch.zeros(K, self.num_envs, spec.obs_dim, **f)
+            if mse:
+                out['mse'] = torch.empty(K, self.num_envs, **f)
+            if c_values and len(spec.con_rows):
+                out['c_values'] = torch.empty(K, len(spec.con_rows), self.num_envs, **f)
+            if fin_stats:
+                out['fin_stats'] = torch.zeros(K, self.num_envs, 4, **f)
+        q = L.Sequence()
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        q.d_actions, q.d_adv_actions = p(actions), p(adv_actions)
+        q.d_obs, q.d_reward, q.d_done, q.d_flags = p(out['obs']), p(out['reward']), p(out['done']), p(out['flags'])
+        q.d_terminal_obs, q.d_mse, q.d_c_values = p(out.get('terminal_obs')), p(out.get('mse')), p(out.get('c_values'))
+        q.d_ep_stats, q.d_fin_stats = p(self.ep_stats), p(out.get('fin_stats'))
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.scg_step_sequence(self._h, K, C.byref(q), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ reference VecEnv API
     def reset(self):
         obs = self.reset_tensors()

@@ -1,0 +1,78 @@
+"""scg_step_sequence: K control steps per launch with caller-supplied action sequences must give, bit for bit, what K calls
+of scg_step give (dummy_vec_env.py:24-41 called K times) — every per-step output, the episode statistics, the simulator
+state and counters afterwards — on the generic and the specialised library, float32 and float64, across auto-resets."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def _envs(task, n, dtype, specialize, **over):
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task(task)
+    cfg = dict(cfg, **over)
+    return [HipVecEnv(env_id, n, seed=9, dtype=dtype, return_numpy=False, specialize=specialize, **cfg) for _ in range(2)]
+
+
+CASES = [('quadrotor_2D_track', {}), ('cartpole_stab', {}), ('quadrotor_3D_track', {}), ('quadrotor_3D_track_disturbed', {}),
+         ('quadrotor_2D_track', {'obs_goal_horizon': 3}),                       # multi-row observations (not a register row)
+         ('quadrotor_2D_track', {'episode_len_sec': 0.3})]                      # time-limit truncations inside the sequence
+
+
+@pytest.mark.parametrize('specialize', [False, True], ids=['generic', 'specialised'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64], ids=['f32', 'f64'])
+@pytest.mark.parametrize('task,over', CASES, ids=[c[0] + ('_' + '_'.join(c[1]) if c[1] else '') for c in CASES])
+def test_sequence_equals_repeated_steps(task, over, dtype, specialize):
+    n, K = 1000, 40                                                             # 15 full waves + a ragged one
+    a, b = _envs(task, n, dtype, specialize, **over)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    acts = (torch.rand(K, n, a.spec.nu, generator=g, dtype=torch.float64) * 2 - 1).to(a.device, dtype)
+    a.reset_tensors(); b.reset_tensors()
+    seq = a.step_sequence(acts, terminal_obs=True, mse=True, c_values=True, fin_stats=True)
+    n_done = 0
+    for t in range(K):
+        out = b.step_tensors(acts[t])
+        for name, got, ref in (('obs', seq['obs'][t], out.obs), ('reward', seq['reward'][t], out.reward), ('done', seq['done'][t], out.done),
+                               ('flags', seq['flags'][t], out.flags), ('mse', seq['mse'][t], out.mse)):
+            assert torch.equal(got, ref), (name, t)
+        if 'c_values' in seq:
+            assert torch.equal(seq['c_values'][t], out.c_values), ('c_values', t)
+        d = out.done.bool()
+        n_done += int(d.sum())
+        assert torch.equal(seq['terminal_obs'][t][d], out.terminal_obs[d]), ('terminal_obs', t)
+        assert torch.equal(seq['fin_stats'][t][d], out.fin_stats[d]), ('fin_stats', t)
+    assert n_done > 0
+    assert torch.equal(a.ep_stats, b.ep_stats)
+    np.testing.assert_array_equal(a.get_raw_state(), b.get_raw_state())
+    for x, y in zip(a.get_counters(), b.get_counters()):
+        np.testing.assert_array_equal(x, y)
+    # and the next single step continues identically
+    nxt = (torch.rand(n, a.spec.nu, generator=g, dtype=torch.float64) * 2 - 1).to(a.device, dtype)
+    assert torch.equal(a.step_tensors(nxt).obs, b.step_tensors(nxt).obs)
+    a.close(); b.close()
+
+
+def test_sequence_with_adversary_channel_and_argument_checks():
+    from safe_control_gym_amd import _lib as L
+    a, b = _envs('quadrotor_2D_track', 256, torch.float32, False, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    K = 12
+    acts = (torch.rand(K, 256, 2, generator=g) * 2 - 1).to(a.device)
+    adv = (torch.rand(K, 256, a.spec.adversary_dim, generator=g) * 0.1 - 0.05).to(a.device)
+    a.reset_tensors(); b.reset_tensors()
+    seq = a.step_sequence(acts, adv_actions=adv)
+    for t in range(K):
+        out = b.step_tensors(acts[t], adv[t])
+        assert torch.equal(seq['obs'][t], out.obs) and torch.equal(seq['reward'][t], out.reward)
+    plain = _envs('quadrotor_2D_track', 256, torch.float32, False)[0]
+    plain.reset_tensors()
+    assert not torch.equal(plain.step_sequence(acts)['obs'][-1], seq['obs'][-1])      # the adversary really acted
+    with pytest.raises(ValueError):
+        a.step_sequence(acts[:, :100])
+    fresh = _envs('quadrotor_2D_track', 64, torch.float32, False)[0]
+    with pytest.raises(L.ScgError):                                                    # before reset (benchmark_env.py:230-235)
+        fresh.step_sequence(acts[:, :64].contiguous())
+    for e in (a, b, plain, fresh):
+        e.close()

@@ -67,7 +67,7 @@ def build_asm(task, dtype):
     with open(hdr, 'w') as f:
         f.write(src)
     out = f'/tmp/isa_{task}_{dtype}.s'
-    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-DSCG_SPEC', '-include', hdr, '-S',
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=on', '-std=c++17', '-DSCG_SPEC', '-include', hdr, '-S',
            '--cuda-device-only', '-o', out, os.path.join(_lib.CSRC_DIR, 'scg_kernels.hip')] + os.environ.get('SCG_EXTRA_FLAGS', '').split()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode:

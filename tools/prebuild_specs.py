@@ -20,6 +20,13 @@ def configs():
         cfg = dict(meta['config'])
         cfg.pop('seed', None)
         out.append((meta['task'], cfg))
+    # variants of the shipped task YAMLs that tests/test_gpu_sequence.py and test_gpu_parity_scale.py step
+    from safe_control_gym_amd.registration import load_task
+    env_id, q2 = load_task('quadrotor_2D_track')
+    out += [(env_id, dict(q2, obs_goal_horizon=3)), (env_id, dict(q2, episode_len_sec=0.3))]
+    for task in ('quadrotor_2D_track', 'cartpole_stab', 'quadrotor_3D_track'):
+        env_id, c = load_task(task)
+        out.append((env_id, dict(c, randomized_init=True)))
     return out
 
 

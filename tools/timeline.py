@@ -27,7 +27,7 @@ if sys.argv[1] == 'hash':
     print(H)
 elif sys.argv[1] == 'build':
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-w', '-DSCG_SPEC',
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=on', '-std=c++17', '-fPIC', '-shared', '-w', '-DSCG_SPEC',
                            '-DSCG_EXP_TIMELINE'] + sys.argv[2:] + ['-include', f'{SPEC}/scg_spec_{H}.h', '-o', VARIANT,
                            f'{ROOT}/safe_control_gym_amd/csrc/scg_kernels.hip'])
 else:
