@@ -44,12 +44,13 @@ def main():
     ap.add_argument('--save-final', default=None, help='write <path>.rank<r>.pt: final flat parameters + this rank\'s first rollout observations')
     ap.add_argument('--no-graphs', action='store_true', help='eager PyTorch update / rollout instead of HIP-graph replay')
     ap.add_argument('--no-fused-rollout', action='store_true', help='rollout / evaluation as HIP graphs of PyTorch policy + step kernel')
+    ap.add_argument('--sync-eval', action='store_true', help='evaluate on the training stream (blocking) instead of on a second stream')
     ap.add_argument('--no-fused', action='store_true', help='PyTorch (graphed) minibatch update instead of the fused MFMA kernels')
     args = ap.parse_args()
 
     import torch
     from safe_control_gym_amd import parallel
-    from safe_control_gym_amd.ppo import PPO, PPOConfig, evaluate
+    from safe_control_gym_amd.ppo import PPO, AsyncEvaluator, PPOConfig, evaluate
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
 
@@ -76,22 +77,35 @@ def main():
     reached = None
     it = 0
     best = -1e30
+    # evaluation of weight snapshots on a second stream, looked at (without waiting) one iteration later; single-rank only:
+    # with several ranks every rank must see the same result at the same iteration
+    aev = AsyncEvaluator(ppo, eval_env) if (pol and ppo._fused_rollout and not args.sync_eval and world == 1) else None
     while ppo.total_steps < args.max_env_steps and time.perf_counter() - t0 < args.max_seconds:
         res = ppo.train_step()
         it += 1
         res.update(ppo.episode_stats())
-        if it % args.eval_every == 0:
+        ev = None
+        if aev is not None:
+            ev = aev.poll()
+            if it % args.eval_every == 0:
+                aev.launch(tag=it)
+        elif it % args.eval_every == 0:
             ev = evaluate(ppo.agent.ac, eval_env, policy=ppo._policy_struct(True) if pol else None)
+        if ev is not None:
             res['eval_return'] = ev['ep_return']
             res['eval_length'] = ev['ep_length']
             best = max(best, ev['ep_return'])
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         res['wall_clock'] = time.perf_counter() - t0
         if rank == 0 and not args.quiet:
             print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)
         if res.get('eval_return', -1e30) >= args.target_return:
             reached = res['wall_clock']
             break
+    if aev is not None:
+        last = aev.poll(wait=True)
+        if last is not None:
+            best = max(best, last['ep_return'])
     total = time.perf_counter() - t0
     if args.save_final:
         torch.save({'params': torch.cat([p.detach().reshape(-1) for p in ppo.agent.ac.parameters()]).cpu(),

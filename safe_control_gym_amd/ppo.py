@@ -727,6 +727,88 @@ class PPO:
 
 
 @torch.no_grad()
+def _evaluate_fused_device(env, policy, episodes_per_env=1):
+    """ONE launch on the current stream: deterministic actor inside the env kernel (scg_rollout_policy), per-env episode
+    totals accumulated in the kernel.  Returns (device tensor [episodes, mean return, length, violations, mse], per-env
+    accumulator [N, 8]) without touching the host."""
+    N, dev = env.num_envs, env.device
+    steps = int(env.spec.CTRL_STEPS) * episodes_per_env
+    buf = getattr(env, '_eval_fused', None)
+    if buf is None or buf['rew'].shape[0] != steps:
+        f = dict(device=dev, dtype=torch.float32)
+        nobs, nu = env.spec.obs_dim, env.spec.nu
+        buf = {'obs': torch.zeros(steps + 1, N, nobs, **f), 'act': torch.zeros(steps, N, nu, **f),
+               'logp': torch.zeros(steps, N, **f), 'rew': torch.zeros(steps, N, **f),
+               'done': torch.zeros(steps, N, dtype=torch.uint8, device=dev), 'flags': torch.zeros(steps, N, dtype=torch.uint8, device=dev),
+               'acc': torch.zeros(N, 8, **f)}
+        env._eval_fused = buf
+    env.reset_tensors()
+    buf['acc'].zero_()
+    env.rollout_policy(policy, steps, buf['obs'], buf['act'], buf['logp'], buf['rew'], buf['done'], buf['flags'],
+                       episode_acc=buf['acc'], max_episodes=episodes_per_env)
+    a = buf['acc']
+    n = a[:, 0].sum().clamp(min=1.0)
+    return torch.stack([a[:, 0].sum(), a[:, 1].sum() / n, a[:, 2].sum() / n, a[:, 3].sum() / n, a[:, 4].sum() / n]), a
+
+
+def _evaluate_fused_result(res, a, episodes_per_env=1):
+    out = {'episodes': res[0], 'ep_return': res[1], 'ep_length': res[2], 'ep_constraint_violation': res[3], 'ep_mse': res[4]}
+    if episodes_per_env == 1 and a is not None:
+        out['metrics'] = episode_metrics(a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 0] > 0)
+    return out
+
+
+class AsyncEvaluator:
+    """Deterministic evaluation of policy SNAPSHOTS on a second HIP stream, overlapped with training.
+
+    The fused evaluation is one launch of one or a few workgroups that runs for CTRL_STEPS sequential control steps (6.5 ms for
+    256 envs x 250 steps): it needs almost none of the chip but a third of a PPO iteration's time when it sits on the
+    training stream.  launch() copies the flat parameters (on the training stream, i.e. after the update that produced them)
+    and enqueues the evaluation on the side stream; poll() returns the result once the stream has finished it, without
+    blocking; at most one evaluation is in flight.  The reference evaluates every `eval_interval` steps on a separate
+    eval env (ppo.py:186-208); which weights get evaluated and what is measured are the same, only the waiting is gone."""
+
+    def __init__(self, ppo, eval_env):
+        if not ppo._fused_rollout or getattr(eval_env, 'policy_shape', None) != (ppo.cfg.hidden_dim, ppo.cfg.activation):
+            raise ValueError('AsyncEvaluator needs the fused rollout path (envs built with the policy shape)')
+        self.ppo, self.env, self.dev = ppo, eval_env, eval_env.device
+        self.stream = torch.cuda.Stream(self.dev)
+        self.params = ppo.agent._flat['p'].clone()
+        self.policy = ppo._policy_struct(True)
+        self.policy.d_params = self.params.data_ptr()
+        self.host = torch.zeros(5, dtype=torch.float32).pin_memory()
+        self.event, self.tag = None, None
+
+    def launch(self, tag=None):
+        """Snapshot the current weights and start evaluating them; False if the previous evaluation is still running."""
+        if self.event is not None:
+            return False
+        main = torch.cuda.current_stream(self.dev)
+        self.params.copy_(self.ppo.agent._flat['p'])
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            res, _ = _evaluate_fused_device(self.env, self.policy, 1)
+            self.host.copy_(res, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+        self.tag = tag
+        return True
+
+    def poll(self, wait=False):
+        """Result dict (+ 'tag') of the finished evaluation, or None if none has finished."""
+        if self.event is None:
+            return None
+        if wait:
+            self.event.synchronize()
+        elif not self.event.query():
+            return None
+        self.event = None
+        out = _evaluate_fused_result(self.host.tolist(), None)
+        out['tag'] = self.tag
+        return out
+
+
+@torch.no_grad()
 def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None, policy=None):
     """Deterministic policy (action = mean, ppo_utils.py:233-238) on every env of `env` until each finished
     `episodes_per_env` episodes; returns mean episode return / length / violations / mse (batched counterpart of
@@ -738,27 +820,8 @@ def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None, p
     steps = int(env.spec.CTRL_STEPS) * episodes_per_env
     dev = env.device
     if policy is not None and obs_normalizer is None and getattr(env, 'policy_shape', None) is not None:
-        # ONE launch: deterministic actor inside the env kernel, per-env episode totals accumulated in the kernel
-        buf = getattr(env, '_eval_fused', None)
-        if buf is None:
-            f = dict(device=dev, dtype=torch.float32)
-            nobs, nu = env.spec.obs_dim, env.spec.nu
-            buf = {'obs': torch.zeros(steps + 1, N, nobs, **f), 'act': torch.zeros(steps, N, nu, **f),
-                   'logp': torch.zeros(steps, N, **f), 'rew': torch.zeros(steps, N, **f),
-                   'done': torch.zeros(steps, N, dtype=torch.uint8, device=dev), 'flags': torch.zeros(steps, N, dtype=torch.uint8, device=dev),
-                   'acc': torch.zeros(N, 8, **f)}
-            env._eval_fused = buf
-        env.reset_tensors()
-        buf['acc'].zero_()
-        env.rollout_policy(policy, steps, buf['obs'], buf['act'], buf['logp'], buf['rew'], buf['done'], buf['flags'],
-                           episode_acc=buf['acc'], max_episodes=episodes_per_env)
-        a = buf['acc']
-        n = a[:, 0].sum().clamp(min=1.0)
-        res = torch.stack([a[:, 0].sum(), a[:, 1].sum() / n, a[:, 2].sum() / n, a[:, 3].sum() / n, a[:, 4].sum() / n]).tolist()
-        out = {'episodes': res[0], 'ep_return': res[1], 'ep_length': res[2], 'ep_constraint_violation': res[3], 'ep_mse': res[4]}
-        if episodes_per_env == 1:
-            out['metrics'] = episode_metrics(a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 0] > 0)
-        return out
+        res, a = _evaluate_fused_device(env, policy, episodes_per_env)
+        return _evaluate_fused_result(res.tolist(), a, episodes_per_env)
     use_graph = (dev.type == 'cuda') if use_graph is None else use_graph
     cache = getattr(env, '_eval_cache', None)
     key = (id(ac), episodes_per_env, bool(use_graph), id(obs_normalizer))

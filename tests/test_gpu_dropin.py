@@ -83,3 +83,52 @@ def test_reference_controllers_run_on_hipvecenv(algo):
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'run_reference_ppo_on_hip.py'), '--algo', algo],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and 'OK: the reference' in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_controller_ids_drive_training_like_train_rl_controller():
+    """examples/rl/train_rl_controller.py:32-60: make(algo, env_func, training, checkpoint_path, output_dir, seed, **algo_config),
+    reset / learn / save / load / run / close — with the reference's controller ids and YAML keys."""
+    torch = pytest.importorskip('torch')
+    import tempfile
+    from safe_control_gym_amd.registration import get_config, load_task, make
+    env_id, cfg = load_task('quadrotor_2D_track')
+    env_func = functools.partial(make, env_id, output_dir='/tmp/scg', **cfg)
+    assert get_config('ppo')['opt_epochs'] == 10 and get_config('sac')['hidden_dim'] == 256            # the YAML defaults
+    with tempfile.TemporaryDirectory() as out:
+        algo_cfg = dict(hidden_dim=128, activation='tanh', use_gae=True, rollout_batch_size=1024, rollout_steps=16, opt_epochs=2,
+                        mini_batch_size=4096, actor_lr=1e-3, critic_lr=1e-3, max_env_steps=4 * 1024 * 16, eval_batch_size=16,
+                        eval_interval=2 * 1024 * 16, eval_save_best=True, log_interval=1024 * 16)
+        ctrl = make('ppo', env_func, training=True, checkpoint_path=os.path.join(out, 'model_latest.pt'), output_dir=out, seed=3, **algo_cfg)
+        assert ctrl.impl._fused_rollout and ctrl.rollout_steps == 16 and ctrl.target_kl == 0.01      # defaults + overrides as attributes
+        ctrl.reset()
+        hist = ctrl.learn()
+        assert ctrl.total_steps == 4 * 1024 * 16 and len(hist) == 4
+        assert os.path.exists(os.path.join(out, 'model_latest.pt')) and os.path.exists(os.path.join(out, 'model_best.pt'))
+        res = ctrl.run(n_episodes=16)
+        assert res['ep_returns'].shape == (16,) and (res['ep_lengths'] > 0).all() and res['mse'].shape == (16,)
+        act = ctrl.select_action(np.zeros(12))
+        assert act.shape == (2,)
+        w = {k: v.clone() for k, v in ctrl.agent.ac.state_dict().items()}
+        ctrl.close()
+        test = make('ppo', env_func, training=False, checkpoint_path=os.path.join(out, 'model_latest.pt'), output_dir=out, seed=3, **algo_cfg)
+        test.load(os.path.join(out, 'model_latest.pt'))
+        for k, v in test.agent.ac.state_dict().items():
+            assert torch.equal(v, w[k]), k
+        res2 = test.run(n_episodes=16)
+        test.close()
+        again = make('ppo', env_func, training=False, checkpoint_path=os.path.join(out, 'model_latest.pt'), output_dir=out, seed=3, **algo_cfg)
+        again.load(os.path.join(out, 'model_latest.pt'))
+        np.testing.assert_array_equal(again.run(n_episodes=16)['ep_returns'], res2['ep_returns'])     # same weights, same eval seeds
+        again.close()
+        sac = make('sac', env_func, training=True, output_dir=out, seed=1, hidden_dim=64, rollout_batch_size=256, warm_up_steps=512,
+                   train_interval=256, train_batch_size=256, max_env_steps=256 * 8, max_buffer_size=10000)
+        sac.reset(); sac.learn()
+        assert sac.total_steps == 256 * 8 and sac.run(n_episodes=8)['ep_returns'].shape == (8,)
+        sac.save(os.path.join(out, 'sac.pt')); sac.load(os.path.join(out, 'sac.pt')); sac.close()
+    adv_func = functools.partial(make, env_id, **dict(cfg, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05))
+    rap = make('rap', adv_func, seed=2, hidden_dim=32, use_gae=True, rollout_batch_size=256, rollout_steps=8, opt_epochs=1,
+               mini_batch_size=512, max_env_steps=2 * 256 * 8, num_adversaries=3)
+    rap.learn()
+    assert rap.total_steps == 2 * 256 * 8 and len(rap.impl.adversaries) == 3
+    rap.close()

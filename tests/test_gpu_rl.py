@@ -325,3 +325,35 @@ def test_safe_explorer_ppo_pretrain_and_step():
     env.close()
     with pytest.raises(ValueError):
         SafeExplorerPPO(_env('quadrotor_2D_track', 64, constraints=None), cfg)
+
+
+def test_async_evaluator_matches_blocking_evaluation_and_overlaps_training():
+    """ppo.AsyncEvaluator: the snapshot evaluated on the side stream is the weights at launch() time (training may already
+    have moved on), the numbers equal a blocking evaluate() of those weights, and at most one evaluation is in flight."""
+    from safe_control_gym_amd.ppo import PPO, AsyncEvaluator, PPOConfig, evaluate
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task('quadrotor_2D_track')
+    pol = (128, 'tanh')
+    env = HipVecEnv(env_id, 2048, seed=3, return_numpy=False, policy=pol, **cfg)
+    ev_env = HipVecEnv(env_id, 256, seed=5, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
+    ev_env2 = HipVecEnv(env_id, 256, seed=5, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
+    ppo = PPO(env, PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, opt_epochs=2, mini_batch_size=16384, rollout_steps=16,
+                             actor_lr=2e-3, critic_lr=2e-3, target_kl=0.03), seed=3)
+    assert ppo._fused_rollout
+    aev = AsyncEvaluator(ppo, ev_env)
+    assert aev.poll() is None
+    ppo.train_step()
+    ref0 = evaluate(ppo.agent.ac, ev_env2, policy=ppo._policy_struct(True))          # blocking, weights after iteration 1
+    assert aev.launch(tag=1)
+    assert not aev.launch(tag=99)                                                      # one in flight
+    ppo.train_step(); ppo.train_step()                                                 # training moves the weights on
+    got = aev.poll(wait=True)
+    assert got['tag'] == 1
+    for k in ('episodes', 'ep_return', 'ep_length', 'ep_mse', 'ep_constraint_violation'):
+        assert got[k] == pytest.approx(ref0[k], rel=1e-6), k
+    ref2 = evaluate(ppo.agent.ac, ev_env2, policy=ppo._policy_struct(True))
+    assert ref2['ep_return'] != ref0['ep_return']                                      # (they did move)
+    assert aev.launch(tag=3) and aev.poll(wait=True)['ep_return'] == pytest.approx(ref2['ep_return'], rel=1e-6)
+    for e in (env, ev_env, ev_env2):
+        e.close()
