@@ -28,7 +28,7 @@ class PpoGradArgs(C.Structure):
 
 
 def supported(obs_dim, hidden, act_dim, activation):
-    return (1 <= obs_dim <= 32 and hidden % 32 == 0 and 32 <= hidden <= 128 and act_dim in (1, 2, 4) and activation in ACTS)
+    return (1 <= obs_dim <= 31 and hidden % 32 == 0 and 32 <= hidden <= 128 and act_dim in (1, 2, 4) and activation in ACTS)
 
 
 def source_hash():
@@ -53,7 +53,7 @@ def build(obs_dim, hidden, act_dim, activation, force=False):
     os.makedirs(L.SPEC_DIR, exist_ok=True)
     cmd = [L._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DSCG_L_NIN={obs_dim}',
            f'-DSCG_L_H={hidden}', f'-DSCG_L_NU={act_dim}', f'-DSCG_L_ACT={ACTS[activation]}',
-           f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL', '-o', so, SRC]
+           f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL', '-o', so, SRC] + os.environ.get('SCG_LEARN_FLAGS', '').split()
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise L.ScgError('hipcc failed (learner build):\n' + res.stdout + res.stderr)

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
     const GoalTab<T> goal{nullptr, I.x_goal, false};
     {
         const MlpWeights w{A.params + A.W1, A.params + A.b1, A.params + A.W2, A.params + A.b2, A.params + A.W3, A.params + A.b3};
-        mlp_fill_lds<NIN, HID, NU, 16>(lds, w, threadIdx.x, blockDim.x);
+        mlp_fill_lds<NIN, HID, NU, 16>(lds, w, threadIdx.x);
     }
     __syncthreads();
     const int N = I.num_envs;

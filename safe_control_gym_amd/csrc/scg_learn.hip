@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restric
     using L = MlpLds<NIN, HID, NOUT>;
     extern __shared__ __align__(16) float lds[];
     const MlpWeights w = weights_of(params, lay);
-    mlp_fill_lds<NIN, HID, NOUT>(lds, w, threadIdx.x, blockDim.x);
+    mlp_fill_lds<NIN, HID, NOUT>(lds, w, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -134,6 +134,16 @@ template <int NOUT> constexpr int partial_small() { return GradLds<NOUT>::END; }
 template <int NOUT> constexpr int partial_words() { return GradLds<NOUT>::END + HID * HID; }
 constexpr int PARTIAL_STRIDE = partial_words<(NU > 1 ? NU : 1)>();      // actor's is the longer one
 
+constexpr int W1R = (NIN + 1) * HID;                                    // words of one dW1 | db1 accumulation region
+constexpr size_t grad_lds_base_words() {
+    size_t a = MlpLds<NIN, HID, NU>::END + GradLds<NU>::END;
+    size_t c = MlpLds<NIN, HID, 1>::END + GradLds<1>::END;
+    return (a > c ? a : c) + WAVES * 32 * NINP + WAVES * 4 * 32 + WAVES * 32 * 33;
+}
+// Per-wave private dW1 | db1 regions (no LDS atomics, wave-ordered sum) when they fit next to the weight image.
+constexpr bool private_dw1() { return (grad_lds_base_words() + (WAVES - 1) * W1R) * sizeof(float) <= 160 * 1024; }
+static_assert(NIN < 32, "the dW1 product appends a column of ones: NIN + 1 <= 32");
+
 struct GradArgs {
     const float* params; scg_mlp_layout actor, critic; int logstd_off;
     const float* obs; const float* act; const float* logp_old; const float* adv; const float* ret; const float* v_old;
@@ -141,6 +151,15 @@ struct GradArgs {
     float clip_param; int use_clipped_value;
     float* partials;                                    // [gridDim.x][2][PARTIAL_STRIDE]
 };
+
+// -DSCG_L_TIMING: the first wave of workgroup (0, actor) stamps s_memtime at its phase boundaries into the 8 words behind
+// the partial vectors (tools/learn_cost.py --timeline prints them); the workspace is 64 bytes longer in that build.
+#ifdef SCG_L_TIMING
+#define SCG_L_STAMP(k) do { if (ACTOR && blockIdx.x == 0 && threadIdx.x == 0) \
+    reinterpret_cast<unsigned long long*>(A.partials + (size_t)gridDim.x * 2 * PARTIAL_STRIDE)[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SCG_L_STAMP(k) do {} while (0)
+#endif
 
 template <int NOUT, bool ACTOR>
 __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
@@ -151,15 +170,24 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     float* const xs_all = gl + G::END;                                  // [WAVES][32][NINP]
     float* const dout_all = xs_all + WAVES * 32 * NINP;                 // [WAVES][NOUT][32]
     float* const scr_all = dout_all + WAVES * 4 * 32;                   // [WAVES][32 * 33]
+    float* const w1_all = scr_all + WAVES * 32 * 33;                    // [WAVES - 1][(NIN + 1) * H] (private_dw1() only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const MlpWeights w = weights_of(A.params, ACTOR ? A.actor : A.critic);
-    mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid, blockDim.x);
+    SCG_L_STAMP(0);
+    mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid);
     for (int k = tid; k < G::END; k += blockDim.x) gl[k] = 0.0f;
+    if constexpr (private_dw1()) {
+        for (int k = tid; k < (WAVES - 1) * W1R; k += blockDim.x) w1_all[k] = 0.0f;
+    }
     __syncthreads();
+    SCG_L_STAMP(1);
     float* const xs = xs_all + wave * 32 * NINP;
     float* const dout_l = dout_all + wave * 4 * 32;
     float* const scr = scr_all + wave * 32 * 33;
+    // this wave's dW1 | db1 accumulation region: [input c <= NIN][feature]; wave 0 (and every wave, when the private copies
+    // do not fit the LDS) uses the shared one
+    float* const w1 = (private_dw1() && wave > 0) ? w1_all + (wave - 1) * W1R : gl + G::DW1;
     float logstd[NOUT], inv_std[NOUT];
     if constexpr (ACTOR) {
 #pragma unroll
@@ -296,36 +324,37 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[tp][q]);
 #ifndef DBG_NO_DW1
-                // transposed through the scratch: element [out 32 tp + c][sample 2 s' + h] is read back inside a ROLLED
-                // loop over the sample pairs (an unrolled one lets the compiler pull all 48 cached-input loads up front)
+                // dW1 and db1 on the matrix cores as well: [dz1 tile (32 features x 32 samples)] x [x | 1] (32 samples x
+                // (NIN + 1) columns).  A = the transposed tile (lane = feature, register = sample pair), B = the cached
+                // inputs with a column of ones appended, D[feature][c]: c < NIN -> dW1[feature][c], c == NIN -> db1[feature].
+                // (The vector-unit form — 16 sample pairs x NIN FMAs per lane + 13 LDS atomics per input tile — was the most
+                //  expensive section of the kernel: 18 of 49 us per tile for the smallest of the three weight matrices.)
+                {
+                    float t[16], xb[16];
+                    tile_transpose(scr, acc, t, lane);
+                    // B operand: xb[s'] = [x | 1][sample 2 s' + h][column c] from the sample cache (re-read per input tile:
+                    // sixteen more registers held across the data-gradient loop spilled)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) scr[d_row(q, h) * 33 + c] = acc[q];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float sb = 0.0f, aw[NINP];
+                    for (int sp = 0; sp < 16; ++sp) xb[sp] = c < NIN ? xs[(2 * sp + h) * NINP + c] : (c == NIN ? 1.0f : 0.0f);
+                    f32x16 g1;
 #pragma unroll
-                for (int k = 0; k < NINP; ++k) aw[k] = 0.0f;
-#pragma unroll 1
-                for (int sp = 0; sp < 16; ++sp) {
-                    const float ts = scr[c * 33 + 2 * sp + h];
-                    sb += ts;
+                    for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
 #pragma unroll
-                    for (int kk = 0; kk < NINP / 4; ++kk) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + (2 * sp + h) * NINP + 4 * kk);
-                        aw[4 * kk + 0] = __builtin_fmaf(ts, xv.x, aw[4 * kk + 0]); aw[4 * kk + 1] = __builtin_fmaf(ts, xv.y, aw[4 * kk + 1]);
-                        aw[4 * kk + 2] = __builtin_fmaf(ts, xv.z, aw[4 * kk + 2]); aw[4 * kk + 3] = __builtin_fmaf(ts, xv.w, aw[4 * kk + 3]);
+                    for (int sp = 0; sp < 16; ++sp) g1 = mfma32(t[sp], xb[sp], g1);
+                    if (c <= NIN) {
+                        float* const dst = w1 + c * HID + 32 * tp + 4 * h;
+                        if constexpr (private_dw1()) {                  // this wave's own words: plain read-add-write
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                f32x4 v = *reinterpret_cast<const f32x4*>(dst + 8 * g);
+                                v += (f32x4){g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
+                                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) atomicAdd(dst + d_row(q, 0), g1[q]);
+                        }
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                sb += __shfl_xor(sb, 32, 64);
-                if (h == 0) atomicAdd(gl + G::DB1 + 32 * tp + c, sb);
-#pragma unroll
-                for (int k = 0; k < NINP; ++k) {
-                    const float v = aw[k] + __shfl_xor(aw[k], 32, 64);
-                    if (h == 0 && k < NIN) atomicAdd(gl + G::DW1 + k * HID + 32 * tp + c, v);
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
@@ -353,6 +382,7 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         }
 #endif
     }
+    SCG_L_STAMP(2);
     // ---- workgroup reduction and the partial vector
     if constexpr (ACTOR) {
 #pragma unroll
@@ -370,27 +400,44 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         if (lane == 0) { atomicAdd(gl + G::STAT + 0, v0); atomicAdd(gl + G::STAT + 1, v1); }
     }
     __syncthreads();                                                    // every wave is done with the weight image
-    float* const stg = lds + L::W2F;                                    // reuse it as the dW2 staging area (H * H words)
-    for (int k = tid; k < HID * HID; k += blockDim.x) stg[k] = 0.0f;
-    __syncthreads();
+    if constexpr (private_dw1()) {
+        for (int k = tid; k < W1R; k += blockDim.x) {
+            float v = gl[G::DW1 + k];
 #pragma unroll
-    for (int tau = 0; tau < NT; ++tau)
+            for (int wv = 0; wv < WAVES - 1; ++wv) v += w1_all[wv * W1R + k];
+            gl[G::DW1 + k] = v;
+        }
+    }
+    SCG_L_STAMP(3);
+    // The four waves' dW2 accumulators are summed IN WAVE ORDER through the (now free) weight image: wave 0 writes, waves
+    // 1..3 read-add-write, 16-byte LDS accesses.  (256 ds_add_f32 per lane from four waves onto the same words took 86 us
+    // — 27 % of the kernel at four tiles per wave — and summed in arrival order.)  Word order: [tile][lane][q].
+    float* const stg = lds + L::W2F;                                    // H * H words
+    for (int wv = 0; wv < WAVES; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-        for (int rho = 0; rho < NT; ++rho)
+            for (int tau = 0; tau < NT; ++tau)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) atomicAdd(stg + ((tau * NT + rho) * 16 + q) * 64 + lane, dW2[tau][rho][q]);
-    __syncthreads();
+                for (int rho = 0; rho < NT; ++rho) {
+                    float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {dW2[tau][rho][4 * g], dW2[tau][rho][4 * g + 1], dW2[tau][rho][4 * g + 2], dW2[tau][rho][4 * g + 3]};
+                        if (wv > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
+                        *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    SCG_L_STAMP(4);
     float* const P = A.partials + ((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE;
     for (int k = tid; k < G::END; k += blockDim.x) P[k] = gl[k];
     for (int k = tid; k < HID * HID; k += blockDim.x) P[G::END + k] = stg[k];
+    SCG_L_STAMP(5);
 }
 
-constexpr size_t grad_lds_words() {
-    constexpr int NOUT_A = NU;
-    size_t a = MlpLds<NIN, HID, NOUT_A>::END + GradLds<NOUT_A>::END;
-    size_t c = MlpLds<NIN, HID, 1>::END + GradLds<1>::END;
-    return (a > c ? a : c) + WAVES * 32 * NINP + WAVES * 4 * 32 + WAVES * 32 * 33;
-}
+constexpr size_t grad_lds_words() { return grad_lds_base_words() + (private_dw1() ? (WAVES - 1) * W1R : 0); }
 
 __global__ __launch_bounds__(64 * WAVES, 1) void ppo_grad_kernel(const GradArgs A) {
     extern __shared__ __align__(16) float lds[];
@@ -418,19 +465,30 @@ __device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay, int log
     if (k < G::DLS) return (k - G::DB3) < NOUT ? lay.b3 + (k - G::DB3) : -1;
     if (k < G::STAT) return (actor && (k - G::DLS) < NOUT) ? logstd_off + (k - G::DLS) : -1;
     if (k < G::END) return -2 - (k - G::STAT);                          // statistics slots
-    const int p = k - G::END;                                           // dW2 staging order -> W2[out][in]
-    const int lane = p & 63, q = (p >> 6) & 15, tr = p >> 10;
+    const int p = k - G::END;                                           // dW2 staging order [tile][lane][q] -> W2[out][in]
+    const int q = p & 15, lane = (p >> 4) & 63, tr = p >> 10;
     const int tau = tr / NT, rho = tr % NT;
     return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
 }
 
+// 64 partial-vector words per block, the workgroups' partials split over the block's four waves (each wave keeps several
+// independent loads in flight; one wave walking all 128 partials of a word was a 128-deep dependent-latency chain), then a
+// fixed-order sum of the four: deterministic.
 __global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
+    __shared__ float part[4][64];
     const int net = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
     const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
-    if (k >= words) return;
     float s = 0.0f;
-    for (int g = 0; g < R.n_wg; ++g) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
+    if (k < words) {
+#pragma unroll 8
+        for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
+    }
+    part[grp][kl] = s;
+    __syncthreads();
+    if (grp != 0 || k >= words) return;
+    s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
     const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
     if (d >= 0) {
         if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
@@ -494,11 +552,13 @@ extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layo
     hipStream_t st = (hipStream_t)stream;
     if (nout == NU) {
         const size_t bytes = MlpLds<NIN, HID, NU>::END * sizeof(float);
-        HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        static bool set_a = false;          // (once per process: the attribute call costs more host time than the launch)
+        if (!set_a) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_a = true; }
         mlp_forward_kernel<NU><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else if (nout == 1) {
         const size_t bytes = MlpLds<NIN, HID, 1>::END * sizeof(float);
-        HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        static bool set_c = false;
+        if (!set_c) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_c = true; }
         mlp_forward_kernel<1><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else {
         return fail(-1, "scg_mlp_forward: this library serves nout = act_dim or 1");
@@ -507,7 +567,13 @@ extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layo
     return 0;
 }
 
-extern "C" size_t scg_ppo_grad_workspace_bytes(int n_workgroups) { return (size_t)n_workgroups * 2 * PARTIAL_STRIDE * sizeof(float); }
+extern "C" size_t scg_ppo_grad_workspace_bytes(int n_workgroups) {
+    size_t b = (size_t)n_workgroups * 2 * PARTIAL_STRIDE * sizeof(float);
+#ifdef SCG_L_TIMING
+    b += 64;
+#endif
+    return b;
+}
 
 extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
     if (!a || !a->d_params || !a->d_obs || !a->d_act || !a->d_logp_old || !a->d_adv || !a->d_ret || !a->d_v_old || !a->d_idx ||
@@ -522,13 +588,14 @@ extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
     G.idx = a->d_idx; G.batch = a->batch; G.clip_param = a->clip_param; G.use_clipped_value = a->use_clipped_value;
     G.partials = (float*)a->d_workspace;
     const size_t bytes = grad_lds_words() * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static bool set_g = false;
+    if (!set_g) { HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_g = true; }
     ppo_grad_kernel<<<dim3(a->n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
     HIP_TRY(hipGetLastError());
     ReduceArgs R;
     R.partials = G.partials; R.n_wg = a->n_workgroups; R.actor = a->actor; R.critic = a->critic; R.logstd_off = a->logstd_off;
     R.n_params = a->n_params; R.entropy_coef = a->entropy_coef; R.params = a->d_params; R.grad = a->d_grad; R.stats = a->d_stats;
-    ppo_reduce_kernel<<<dim3((PARTIAL_STRIDE + 255) / 256, 2), dim3(256), 0, st>>>(R);
+    ppo_reduce_kernel<<<dim3((PARTIAL_STRIDE + 63) / 64, 2), dim3(256), 0, st>>>(R);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -84,25 +84,51 @@ struct MlpLds {
     static_assert(NIN <= 32 && H % 32 == 0 && NOUT <= 4, "unsupported MLP shape");
 };
 
-// Cooperative fill of the LDS image from torch-layout parameters (all threads of the workgroup; caller barriers after).
-// Global reads run along the rows of W (coalesced), the permutation is applied on the LDS side.
-template <int NIN, int H, int NOUT, int SS = 20>
-__device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, int tid, int nthreads) {
+// Cooperative fill of the LDS image from torch-layout parameters (all NTHR threads of the workgroup; caller barriers after).
+// Global reads run along the rows of W (coalesced), the permutation is applied on the LDS side.  Each phase issues ALL its
+// global loads before its first LDS store: written element by element (load, permute, store, next) the fill exposed one
+// memory round trip per element — with one wave per SIMD that was ~1 us x 64 iterations, a third of the gradient kernel's
+// time at four tiles per wave.
+template <int NIN, int H, int NOUT, int SS = 20, int NTHR = 256>
+__device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, int tid) {
     using L = MlpLds<NIN, H, NOUT, SS>;
-    for (int k = tid; k < L::NT * L::L1Q * 64; k += nthreads) {         // W1F[rho][q][lane(i,h)] = W1[32 rho + i][row(q,h)]
-        const int lane = k & 63, q = (k >> 6) % L::L1Q, rho = (k >> 6) / L::L1Q;
-        const int in = d_row(q, lane >> 5);
-        lds[L::W1F + k] = in < NIN ? w.W1[(32 * rho + (lane & 31)) * NIN + in] : 0.0f;
+    {                                                                   // W1F[rho][q][lane(i,h)] = W1[32 rho + i][row(q,h)]
+        constexpr int N1 = L::NT * L::L1Q * 64, IT = (N1 + NTHR - 1) / NTHR;
+        float v[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int k = tid + it * NTHR;
+            const int lane = k & 63, q = (k >> 6) % L::L1Q, rho = (k >> 6) / L::L1Q;
+            const int in = d_row(q, lane >> 5);
+            v[it] = (k < N1 && in < NIN) ? w.W1[(32 * rho + (lane & 31)) * NIN + in] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int k = tid + it * NTHR;
+            if (k < N1) lds[L::W1F + k] = v[it];
+        }
     }
-    for (int k = tid; k < H * H; k += nthreads) {                       // source order: W2[o][in], in fastest
-        const int o = k / H, in = k % H;
-        const int rho = o >> 5, i = o & 31, tau = in >> 5, r = in & 31;
-        const int q = 4 * (r >> 3) + (r & 3), h = (r >> 2) & 1;
-        lds[L::W2F + (rho * L::NT + tau) * L::TILE2 + (i + 32 * h) * L::S + q] = w.W2[k];
+    {                                                                   // source order: W2[o][in], in fastest
+        static_assert((H * H) % NTHR == 0, "workgroup size must divide H * H");
+        constexpr int IT = H * H / NTHR, CH = IT < 32 ? IT : 32;
+        static_assert(IT % CH == 0, "chunking");
+        for (int base = 0; base < IT; base += CH) {
+            float v[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = w.W2[tid + (base + j) * NTHR];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int k = tid + (base + j) * NTHR;
+                const int o = k / H, in = k % H;
+                const int rho = o >> 5, i = o & 31, tau = in >> 5, r = in & 31;
+                const int q = 4 * (r >> 3) + (r & 3), h = (r >> 2) & 1;
+                lds[L::W2F + (rho * L::NT + tau) * L::TILE2 + (i + 32 * h) * L::S + q] = v[j];
+            }
+        }
     }
-    for (int k = tid; k < NOUT * H; k += nthreads) lds[L::W3 + k] = w.W3[k];
-    for (int k = tid; k < H; k += nthreads) { lds[L::B1 + k] = w.b1[k]; lds[L::B2 + k] = w.b2[k]; }
-    for (int k = tid; k < NOUT; k += nthreads) lds[L::B3 + k] = w.b3[k];
+    for (int k = tid; k < NOUT * H; k += NTHR) lds[L::W3 + k] = w.W3[k];
+    for (int k = tid; k < H; k += NTHR) { lds[L::B1 + k] = w.b1[k]; lds[L::B2 + k] = w.b2[k]; }
+    for (int k = tid; k < NOUT; k += NTHR) lds[L::B3 + k] = w.b3[k];
 }
 
 // The 16 A operands (q = 0..15) of lane `lane` for the layer-2 tile (rho, tau): four 16-byte LDS reads.

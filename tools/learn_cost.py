@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Fixed vs per-tile cost of one scg_ppo_grad call (gradient kernel + partial-sum reduction): time it for minibatches of
+16 384 ... 262 144 rows (1 ... 16 column tiles per wave at 128 workgroups per network) and fit T = F + c * tiles."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from tests.test_gpu_learn import _agent, _data  # noqa: E402
+
+ag = _agent(12, 128, 2, 'tanh')
+M = 524288
+data = _data(12, 2, M, ag)
+rows = []
+for mb in (16384, 32768, 65536, 131072, 262144):
+    F = ag._build_fused(data, mb)
+    F['idx'].copy_(torch.randperm(M, device='cuda')[:mb].to(torch.int32))
+    for _ in range(3):
+        ag._fused_grad(F)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(20):
+        ag._fused_grad(F)
+    ev[1].record()
+    torch.cuda.synchronize()
+    us = 1e3 * ev[0].elapsed_time(ev[1]) / 20
+    tiles = mb // 32 // (F['args'].n_workgroups * 4)
+    rows.append((mb, F['args'].n_workgroups, tiles, us))
+    print(f'minibatch {mb:7d}  workgroups/net {F["args"].n_workgroups:4d}  tiles/wave {tiles:3d}  {us:8.1f} us per call')
+(m0, _, t0, u0), (m1, _, t1, u1) = rows[2], rows[4]
+c = (u1 - u0) / (t1 - t0)
+print(f'per tile {c:.1f} us, fixed {u0 - c * t0:.1f} us (from the 65 536 and 262 144 rows)')
+# the Adam kernel
+F = ag._build_fused(data, 65536)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+torch.cuda.synchronize(); ev[0].record()
+for _ in range(50):
+    ag._fused_adam(F)
+ev[1].record(); torch.cuda.synchronize()
+print(f'adam_gated: {1e3 * ev[0].elapsed_time(ev[1]) / 50:.1f} us per call')
+
+if '--timeline' in sys.argv:            # needs a library built with SCG_LEARN_FLAGS=-DSCG_L_TIMING
+    F = ag._build_fused(data, 65536)
+    F['idx'].copy_(torch.randperm(M, device='cuda')[:65536].to(torch.int32))
+    for _ in range(3):
+        ag._fused_grad(F)
+    torch.cuda.synchronize()
+    t = F['ws'][-64:].view(torch.int64)[:6].cpu().tolist()
+    names = ['fill + barrier', 'tile loop (4 tiles)', 'small-gradient atomics + barrier', 'dW2 staging (zero, ds_add, barrier)', 'partial vector write']
+    for n, a, b in zip(names, t, t[1:]):
+        print(f'  {n:40s} {(b - a) / 100.0:8.2f} us   (100 MHz counter)')
