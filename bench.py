@@ -330,7 +330,7 @@ def fused_rollout_leg(torch, n, T=32):
             'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments'}
 
 
-def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=65536, lr=2e-3, target_kl=0.03, epochs=4):
+def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=65024, lr=2e-3, target_kl=0.03, epochs=4):
     """PPO wall-clock until the deterministic-policy evaluation return reaches the reference reward (236 / 250, BASELINE.md
     §2): fused rollout, fused MFMA update; every iteration's weights are evaluated (fused deterministic rollout, 256 eval
     envs x 250 steps) on a second stream while training goes on; the clock starts after construction and stops when a

@@ -78,6 +78,10 @@ int scg_ppo_grad(const scg_ppo_grad_args* args, void* stream);
 int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor, float lr_critic,
                    float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, void* stream);
 
+/* d_out[i] = pi(i) for i < count, pi a keyed pseudo-random permutation of [0, n) (count <= n): the shuffled row indices of
+ * one epoch's minibatches (SubsetRandomSampler + BatchSampler(drop_last=True), ppo_utils.py:358-371), one launch. */
+int scg_random_permutation(int32_t* d_out, int n, int count, uint64_t key, void* stream);
+
 const char* scg_learn_last_error(void);
 const char* scg_learn_source_hash_tag(void);
 

@@ -544,7 +544,46 @@ __global__ void adam_count_kernel(const AdamArgs A) {
     }
 }
 
+// ------------------------------------------------------------------ minibatch permutation
+// out[i] = pi(i), i < count, pi a keyed pseudo-random permutation of [0, n): a 6-round Feistel network on the 2 * half
+// bits that cover n, cycle-walked back into range.  Replaces torch.randperm in the update loop (SubsetRandomSampler of
+// ppo_utils.py:358-371): a sort of 2^19 random keys is ~36 kernel launches per epoch, this is one.
+__device__ __forceinline__ uint32_t perm_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void permutation_kernel(int32_t* __restrict__ out, uint32_t n, uint32_t count, int half,
+                                                           uint32_t k0, uint32_t k1) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t mask = (1u << half) - 1u;
+    uint32_t x = i;
+    do {
+        uint32_t l = x >> half, r = x & mask;
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {
+            const uint32_t f = perm_mix(r ^ (round & 1 ? k1 : k0) ^ (0x9e3779b9u * (uint32_t)(round + 1))) & mask;
+            const uint32_t nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        x = (l << half) | r;
+    } while (x >= n);
+    out[i] = (int32_t)x;
+}
+
 // ------------------------------------------------------------------ C ABI
+extern "C" int scg_random_permutation(int32_t* d_out, int n, int count, uint64_t key, void* stream) {
+    if (!d_out || n <= 0 || count < 0 || count > n) return fail(-1, "scg_random_permutation: bad argument");
+    if (count == 0) return 0;
+    int bits = 1;
+    while (bits < 31 && (1u << bits) < (uint32_t)n) ++bits;
+    const int half = (bits + 1) / 2;
+    permutation_kernel<<<dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+        d_out, (uint32_t)n, (uint32_t)count, half, (uint32_t)key, (uint32_t)(key >> 32));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m,
                                float* d_out, const uint8_t* d_row_mask, void* stream) {
     if (!d_params || !layout || !d_x || !d_out || m <= 0) return fail(-1, "scg_mlp_forward: bad argument");

@@ -186,6 +186,7 @@ class PPOAgent:
         # modifier) keep the PyTorch update below — chosen here, visibly, not silently at run time.
         from safe_control_gym_amd import _learn
         self.obs_dim, self.act_dim = obs_dim, act_dim
+        self._perm_key, self._perm_count = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, 0
         self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
                           and _learn.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._fused = None
@@ -233,7 +234,14 @@ class PPOAgent:
         F = {'lib': D, 'data': data}
         a_lay, c_lay, ls_off, n = self._layouts()
         assert n == self._flat['n']
-        n_wg = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 2)
+        # workgroups per network: one per CU for the pair, each of 4 waves walking 32-row tiles.  Of {CU/2, CU/2 - 1} take
+        # the one with fewer tiles on the busiest wave, and on a tie the smaller: a launch that leaves two CUs free runs next
+        # to the one-workgroup evaluation kernel of AsyncEvaluator instead of queueing a workgroup behind it (the gradient
+        # workgroup needs a CU's whole LDS) — mini_batch_size = 127 x 512 = 65 024 makes that split exact on 256 CUs.
+        half = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 2)
+        tiles = mb // 32
+        busiest = lambda w: -(-tiles // (4 * w))               # noqa: E731
+        n_wg = half - 1 if (half > 1 and busiest(half - 1) <= busiest(half)) else half
         n_wg = min(n_wg, max(1, mb // 128))                     # every wave of every workgroup gets at least one tile
         F['ws'] = torch.empty(D.scg_ppo_grad_workspace_bytes(n_wg), dtype=torch.uint8, device=dev)
         F['stats'] = torch.zeros(4, device=dev)
@@ -278,6 +286,9 @@ class PPOAgent:
             self._fused = self._build_fused(static, mb)
             self._fused['key'] = (M, mb)
         F = self._fused
+        from safe_control_gym_amd import _learn
+        if 'perm' not in F or F['perm'].shape[1] != n_mb * mb:
+            F['perm'] = torch.empty(2, n_mb * mb, dtype=torch.int32, device=self.device)
         for k, v in data.items():
             if F['data'][k].data_ptr() != v.data_ptr():
                 F['data'][k].copy_(v)
@@ -285,7 +296,15 @@ class PPOAgent:
         world = parallel.world_size()
         with torch.cuda.device(self.device):
             for _ in range(cfg.opt_epochs):
-                perm = torch.randperm(M, device=self.device, generator=generator)[:n_mb * mb].to(torch.int32).view(n_mb, mb)
+                if generator is not None:       # (tests: torch's own shuffle, reproducible against the PyTorch update)
+                    perm = torch.randperm(M, device=self.device, generator=generator)[:n_mb * mb].to(torch.int32).view(n_mb, mb)
+                else:                           # one launch: keyed Feistel permutation of range(M) (csrc/scg_learn.hip)
+                    perm = F['perm'][self._perm_count % 2]          # double-buffered: the previous epoch's launches may still read theirs
+                    self._perm_count += 1
+                    key = (self._perm_key + 0x9E3779B97F4A7C15 * self._perm_count) & 0xFFFFFFFFFFFFFFFF
+                    _learn.check(F['lib'], F['lib'].scg_random_permutation(perm.data_ptr(), M, n_mb * mb, key,
+                                                                           F['C'].c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+                    perm = perm.view(n_mb, mb)
                 for j in range(n_mb):
                     F['args'].d_idx = perm[j].data_ptr()
                     self._fused_grad(F)
@@ -644,8 +663,8 @@ class PPO:
         M = self.T * self.N
         data = {'obs': self.obs[:self.T].reshape(M, self.obs_dim), 'act': self.act.reshape(M, self.act_dim),
                 'logp': self.logp.reshape(M), 'adv': adv.reshape(M), 'ret': ret.reshape(M), 'v': self.v.reshape(M)}
-        if self.agent.use_graphs:
-            torch.cuda.synchronize(self.device)
+        if self.agent.use_graphs:               # (this stream only: an evaluation running on a side stream is not waited for)
+            torch.cuda.current_stream(self.device).synchronize()
         t1 = time.perf_counter()
         res = self.agent.update(data)
         if not self._fused_rollout:             # (the fused collector re-derives obs[0] from the simulator state)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=16384)
-    ap.add_argument('--minibatch', type=int, default=65536)
+    ap.add_argument('--minibatch', type=int, default=65024)
     ap.add_argument('--seeds', type=int, default=6)
     ap.add_argument('--budget', type=float, default=10.0)
     ap.add_argument('--lr', type=float, default=2e-3)
