@@ -6,6 +6,14 @@ SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
 DST = os.path.join(ROOT, 'profiles')
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 traffic = {}
+for extra in ('ppo_iteration', 'sequence'):
+    stats = glob.glob(f'{SRC}/{extra}/**/*kernel_stats.csv', recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        keep = [r for r in rows if float(r['Percentage']) > 0.2]
+        with open(f'{DST}/{TAG}_kernel_stats_{extra}.csv', 'w', newline='') as f:
+            w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
+        print(extra, [(r['Name'][:40], r['Calls'], r['AverageNs']) for r in keep[:4]])
 for d in sorted(glob.glob(f'{SRC}/kt_*')):
     if not os.path.isdir(d):
         continue

@@ -25,5 +25,10 @@ for C in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA
   timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/diag${i}_$N -o p -- \
       python bench.py --task $T --envs $N --steps 60 --warmup 20 --no-graph $B > $OUT/diag${i}_$N.log 2>&1 < /dev/null
 done
-find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete; find $OUT -name '*.log' -size +200k -delete
+# the PPO iteration (fused rollout, learner kernels, evaluation) and the K-steps-per-launch sequence kernel
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ppo_iteration -o p -- \
+    python tools/ppo_profile.py --fused-rollout --iters 30 --minibatch 65024 > $OUT/ppo_iteration.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sequence -o p -- \
+    python -c "import torch, bench; torch.cuda.set_device(0); print(bench.sequence_leg(torch, 65536, 32))" > $OUT/sequence.log 2>&1 < /dev/null
+find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete; find $OUT -name '*.db' -delete; find $OUT -name '*.log' -size +200k -delete
 du -sh $OUT; ls $OUT | head -80
