@@ -407,6 +407,7 @@ class PPOAgent:
         sd = {'ac': self.ac.state_dict(), 'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict()}
         if self._flat is not None:      # graph / fused modes: the Adam moments live in the flat buffers (torch optimisers never step)
             sd['flat_adam'] = {k: self._flat[k].clone() for k in ('m', 'v', 'steps')}
+        sd['perm_state'] = (self._perm_key, self._perm_count)       # the fused update's keyed minibatch permutations
         return sd
 
     def load_state_dict(self, sd):
@@ -414,6 +415,8 @@ class PPOAgent:
         if 'actor_opt' in sd:
             self.actor_opt.load_state_dict(sd['actor_opt'])
             self.critic_opt.load_state_dict(sd['critic_opt'])
+        if 'perm_state' in sd:
+            self._perm_key, self._perm_count = int(sd['perm_state'][0]), int(sd['perm_state'][1])
         if 'flat_adam' in sd and self._flat is not None:
             for k, t in sd['flat_adam'].items():
                 self._flat[k].copy_(t.to(self.device))      # in place: captured graphs alias these buffers

@@ -177,6 +177,49 @@ def test_ppo_checkpoint_resume_is_exact(tmp_path):
     env_a.close(); env_b.close()
 
 
+def test_ppo_checkpoint_resume_in_fused_mode(tmp_path):
+    """The default GPU mode (fused rollout + fused update: Adam moments in the flat buffers, torch optimisers never step,
+    in-kernel Philox action noise, keyed minibatch permutations): save -> fresh env + trainer -> load -> continue follows the
+    uninterrupted run (to the float32 summation-order noise of the gradient reduction), which it cannot do if the moments,
+    step counts, env counters or permutation state were dropped."""
+    from safe_control_gym_amd.ppo import PPO, PPOConfig
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, tc = load_task('quadrotor_2D_track')
+
+    def make():
+        env = HipVecEnv(env_id, 2048, seed=6, return_numpy=False, policy=(128, 'tanh'), **tc)
+        cfg = PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, opt_epochs=2, mini_batch_size=16384, rollout_steps=16,
+                        actor_lr=1e-3, critic_lr=1e-3, target_kl=0.05)
+        return env, PPO(env, cfg, seed=6)
+
+    env_a, a = make()
+    assert a._fused_rollout and a.agent.use_fused
+    for _ in range(3):
+        a.train_step()
+    path = str(tmp_path / 'fused' / 'model.pt')
+    a.save(path)
+    a.train_step()
+    ref = torch.cat([p.detach().reshape(-1) for p in a.agent.ac.parameters()]).clone()
+    env_b, b = make()
+    b.load(path)
+    assert float(b.agent._flat['steps'][1]) == float(3 * 2 * (16 * 2048 // 16384)) and b.agent._perm_count == a.agent._perm_count - 2
+    b.train_step()
+    got = torch.cat([p.detach().reshape(-1) for p in b.agent.ac.parameters()])
+    assert float((got - ref).abs().max()) <= 2e-5, float((got - ref).abs().max())
+    torch.testing.assert_close(b.obs, a.obs, rtol=0, atol=1e-4)
+    # control: the same continuation WITHOUT the Adam moments ends somewhere else
+    env_c, c = make()
+    c.load(path)
+    for k in ('m', 'v', 'steps'):
+        c.agent._flat[k].zero_()
+    c.train_step()
+    bad = torch.cat([p.detach().reshape(-1) for p in c.agent.ac.parameters()])
+    assert float((bad - ref).abs().max()) > 1e-3
+    for e in (env_a, env_b, env_c):
+        e.close()
+
+
 def test_ppo_with_running_normalisers_graphed_and_eager():
     """norm_obs / norm_reward (ppo.yaml keys): the running statistics live on the device and update inside the captured
     rollout graph; same bookkeeping as the eager path."""
