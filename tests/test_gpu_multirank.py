@@ -43,6 +43,21 @@ def test_bench_two_ranks_on_one_gpu():
     assert 'cpu_baseline' not in r                  # rank 0 at N = 1 only
 
 
+def test_bench_ppo_leg_two_ranks_on_one_gpu():
+    """The PPO wall-clock leg of bench.py with two ranks (what the driver's N > 1 runs execute over RCCL): env shards, one
+    flat gradient all-reduce per minibatch, asynchronous evaluation per rank, rank 0's stop flag broadcast every iteration."""
+    out = _torchrun(['bench.py', '--gpus', '2', '--steps', '200', '--warmup', '50', '--ppo-seeds', '1', '--ppo-seconds', '3'],
+                    {'SCG_BENCH_BACKEND': 'gloo', 'SCG_BENCH_PPO_GLOO': '1'})
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and 'secondary' not in r and 'cpu_baseline' not in r
+    p = r['ppo']
+    assert 'error' not in p, p
+    assert p['n_gpus'] == 2 and p['seeds'] == [1] and p['iterations'][0] >= 3
+    assert p['best_eval_return'][0] > 0          # evaluations came back (the policy is far from trained in 3 s on a shared GPU)
+
+
 def test_train_ppo_two_ranks_stay_in_lock_step(tmp_path):
     base = str(tmp_path / 'final')
     _torchrun(['examples/train_ppo.py', '--envs', '2048', '--minibatch', '16384', '--rollout-steps', '32', '--max-env-steps',
