@@ -134,13 +134,15 @@ template <int NOUT> constexpr int partial_small() { return GradLds<NOUT>::END; }
 template <int NOUT> constexpr int partial_words() { return GradLds<NOUT>::END + HID * HID; }
 constexpr int PARTIAL_STRIDE = partial_words<(NU > 1 ? NU : 1)>();      // actor's is the longer one
 
-constexpr int W1R = (NIN + 1) * HID;                                    // words of one dW1 | db1 accumulation region
+constexpr int W1R = GradLds<(NU > 1 ? NU : 1)>::END;                    // words of one wave's private small-gradient vector
 constexpr size_t grad_lds_base_words() {
     size_t a = MlpLds<NIN, HID, NU>::END + GradLds<NU>::END;
     size_t c = MlpLds<NIN, HID, 1>::END + GradLds<1>::END;
     return (a > c ? a : c) + WAVES * 32 * NINP + WAVES * 4 * 32 + WAVES * 32 * 33;
 }
-// Per-wave private dW1 | db1 regions (no LDS atomics, wave-ordered sum) when they fit next to the weight image.
+// Per-wave private copies of the whole small-gradient vector (dW1, db1, db2, dW3, db3, dlogstd, statistics): every
+// accumulation is then a plain read-add-write by the owning wave, the copies are summed in wave order at the end, and the
+// kernel's result is bitwise reproducible — used when they fit next to the weight image, LDS atomics otherwise.
 constexpr bool private_dw1() { return (grad_lds_base_words() + (WAVES - 1) * W1R) * sizeof(float) <= 160 * 1024; }
 static_assert(NIN < 32, "the dW1 product appends a column of ones: NIN + 1 <= 32");
 
@@ -161,6 +163,12 @@ struct GradArgs {
 #define SCG_L_STAMP(k) do {} while (0)
 #endif
 
+// += into the wave's small-gradient vector: its own copy (plain) or the shared one (LDS atomic)
+__device__ __forceinline__ void gl_add(float* p, float v) {
+    if constexpr (private_dw1()) *p += v;
+    else atomicAdd(p, v);
+}
+
 template <int NOUT, bool ACTOR>
 __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     using L = MlpLds<NIN, HID, NOUT>;
@@ -170,7 +178,7 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     float* const xs_all = gl + G::END;                                  // [WAVES][32][NINP]
     float* const dout_all = xs_all + WAVES * 32 * NINP;                 // [WAVES][NOUT][32]
     float* const scr_all = dout_all + WAVES * 4 * 32;                   // [WAVES][32 * 33]
-    float* const w1_all = scr_all + WAVES * 32 * 33;                    // [WAVES - 1][(NIN + 1) * H] (private_dw1() only)
+    float* const w1_all = scr_all + WAVES * 32 * 33;                    // [WAVES - 1][W1R] (private_dw1() only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const MlpWeights w = weights_of(A.params, ACTOR ? A.actor : A.critic);
@@ -185,9 +193,9 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     float* const xs = xs_all + wave * 32 * NINP;
     float* const dout_l = dout_all + wave * 4 * 32;
     float* const scr = scr_all + wave * 32 * 33;
-    // this wave's dW1 | db1 accumulation region: [input c <= NIN][feature]; wave 0 (and every wave, when the private copies
-    // do not fit the LDS) uses the shared one
-    float* const w1 = (private_dw1() && wave > 0) ? w1_all + (wave - 1) * W1R : gl + G::DW1;
+    // this wave's small-gradient vector; wave 0 (and every wave, when the private copies do not fit the LDS) uses the shared one
+    float* const glw = (private_dw1() && wave > 0) ? w1_all + (wave - 1) * W1R : gl;
+    float* const w1 = glw + G::DW1;                                     // dW1 | db1: [input c <= NIN][feature]
     float logstd[NOUT], inv_std[NOUT];
     if constexpr (ACTOR) {
 #pragma unroll
@@ -262,7 +270,14 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         }
         if (h == 0) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) { dout_l[o * 32 + c] = dout[o]; atomicAdd(gl + G::DB3 + o, dout[o]); }
+            for (int o = 0; o < NOUT; ++o) dout_l[o * 32 + c] = dout[o];
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {                                // db3: sum over the tile's 32 samples (both halves hold them)
+            float v = dout[o];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) gl_add(glw + G::DB3 + o, v);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -279,7 +294,7 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
                 for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + 2 * sp + h], acc);
                 acc += __shfl_xor(acc, 32, 64);
-                if (h == 0) atomicAdd(gl + G::DW3 + o * HID + 32 * tau + c, acc);
+                if (h == 0) gl_add(glw + G::DW3 + o * HID + 32 * tau + c, acc);
             }
         }
 #endif
@@ -370,7 +385,7 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
             for (int sp = 0; sp < 16; ++sp) sb += b[sp];
             sb += __shfl_xor(sb, 32, 64);
-            if (h == 0) atomicAdd(gl + G::DB2 + 32 * rho + c, sb);
+            if (h == 0) gl_add(glw + G::DB2 + 32 * rho + c, sb);
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) {
                 float a[16];
@@ -390,22 +405,22 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
             float v = dls[a];
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0) atomicAdd(gl + G::DLS + a, v);
+            if (lane == 0) gl_add(glw + G::DLS + a, v);
         }
     }
     {
         float v0 = st_loss, v1 = st_kl;
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) { v0 += __shfl_xor(v0, m, 64); v1 += __shfl_xor(v1, m, 64); }
-        if (lane == 0) { atomicAdd(gl + G::STAT + 0, v0); atomicAdd(gl + G::STAT + 1, v1); }
+        if (lane == 0) { gl_add(glw + G::STAT + 0, v0); gl_add(glw + G::STAT + 1, v1); }
     }
     __syncthreads();                                                    // every wave is done with the weight image
     if constexpr (private_dw1()) {
-        for (int k = tid; k < W1R; k += blockDim.x) {
-            float v = gl[G::DW1 + k];
+        for (int k = tid; k < G::END; k += blockDim.x) {
+            float v = gl[k];
 #pragma unroll
             for (int wv = 0; wv < WAVES - 1; ++wv) v += w1_all[wv * W1R + k];
-            gl[G::DW1 + k] = v;
+            gl[k] = v;
         }
     }
     SCG_L_STAMP(3);

@@ -178,3 +178,22 @@ def test_random_permutation_kernel_is_a_keyed_bijection():
     _learn.check(D, D.scg_random_permutation(part.data_ptr(), 100000, 4096, 7, st))          # count < n: distinct, in range
     assert part.min() >= 0 and part.max() < 100000 and torch.unique(part).numel() == 4096
     assert D.scg_random_permutation(part.data_ptr(), 10, 11, 7, st) != 0
+
+
+def test_gradient_kernel_is_bitwise_reproducible():
+    """No atomics on the path of the 12-128-128-{2,1} pair (per-wave private accumulation, wave-ordered and fixed-order
+    sums): the same minibatch gives the same bits, launch after launch."""
+    ag = _agent(12, 128, 2, 'tanh')
+    M, mb = 131072, 65024
+    data = _data(12, 2, M, ag)
+    F = ag._build_fused(data, mb)
+    F['idx'].copy_(torch.randperm(M, device='cuda')[:mb].to(torch.int32))
+    outs = []
+    for _ in range(4):
+        ag._flat['g'].zero_()
+        ag._fused_grad(F)
+        torch.cuda.synchronize()
+        outs.append((ag._flat['g'].clone(), F['stats'].clone()))
+    for g, st in outs[1:]:
+        assert torch.equal(g, outs[0][0]) and torch.equal(st, outs[0][1])
+    assert float(outs[0][0].abs().sum()) > 0
