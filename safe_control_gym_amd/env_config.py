@@ -531,6 +531,14 @@ class EnvSpec:
             self.adversary_dim = dims[adv]
             self.adversary_action_space = Box(low=-1, high=1, shape=(self.adversary_dim,))
 
+    @property
+    def adversary_observation_space(self):
+        """benchmark_env.py:206-208: the adversary observes what the protagonist observes (read through
+        `env.get_attr('adversary_observation_space')` by rarl.py:70 / rap.py:70)."""
+        if self.adversary_disturbance is None:
+            raise AttributeError('adversary_observation_space (no adversary_disturbance configured)')
+        return self.observation_space
+
     @staticmethod
     def _compile_disturbance(spec, dim, max_step):
         kind = spec['disturbance_func']

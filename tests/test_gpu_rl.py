@@ -319,6 +319,8 @@ def test_rap_population_groups_and_updates():
     from safe_control_gym_amd.rarl import RAP
     env = _env('quadrotor_2D_track', 384, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05)
     cfg = PPOConfig(hidden_dim=32, use_gae=True, opt_epochs=2, mini_batch_size=512, rollout_steps=8, actor_lr=1e-3, critic_lr=1e-3)
+    # what rap.py:70-71 / rarl.py:70-71 read from the vectorised env
+    assert env.get_attr('adversary_observation_space')[0].shape == (12,) and env.get_attr('adversary_action_space')[0].shape == (2,)
     r = RAP(env, cfg, seed=4, num_adversaries=3)
     w0 = [{k: v.clone() for k, v in a.ac.state_dict().items()} for a in r.adversaries]
     wa = {k: v.clone() for k, v in r.agent.ac.state_dict().items()}
