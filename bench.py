@@ -272,16 +272,18 @@ def gae_leg(torch):
 
 def sequence_leg(torch, n, K=32, task='quadrotor_2D_track'):
     """The same control steps with K of them per launch (scg_step_sequence): caller-supplied action sequences resident in
-    HBM, every per-step output (obs, reward, done, flags, terminal observation where done) written to [K]-stacked arrays,
-    state in registers between steps.  Its own algorithmic bytes: per env-step the action read and the four outputs; state,
-    counters and episode statistics move once per launch."""
+    HBM, every per-step output (obs, reward, done, flags, mse, constraint values; terminal observation and episode totals
+    where done) written to [K]-stacked arrays, state in registers between steps.  Its own algorithmic bytes: per env-step
+    the action read and those outputs; state, counters and running episode statistics move once per launch."""
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task(task)
     env = HipVecEnv(env_id, n, seed=7, return_numpy=False, **cfg)
     env.reset_tensors()
     acts = torch.rand(K, n, env.spec.nu, device=env.device) * 2 - 1
-    out = env.step_sequence(acts, terminal_obs=True)
+    # every per-step output the API offers: obs, reward, done, flags, mse, constraint values, terminal observation and
+    # finished-episode statistics where done
+    out = env.step_sequence(acts, terminal_obs=True, mse=True, c_values=True, fin_stats=True)
     for _ in range(3):
         env.step_sequence(acts, out=out)
     reps = 40
@@ -295,15 +297,19 @@ def sequence_leg(torch, n, K=32, task='quadrotor_2D_track'):
     us = 1e3 * ev[0].elapsed_time(ev[1]) / reps
     ok = bool(torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all())
     spec = env.spec
-    per_step = 4 * spec.nu + 4 * spec.obs_dim + 4 + 1 + 1
+    per_step = 4 * spec.nu + 4 * spec.obs_dim + 4 + 1 + 1 + 4 + 4 * len(spec.con_rows)          # action in; obs, reward, done, flags, mse, c_values out
     per_launch = 2 * (4 * env._n_state_arrays() + 8) + 32              # state + counters in and out, episode statistics RMW
     bytes_es = per_step + per_launch / K
     rate = n * K / (us * 1e-6)
     env.close()
     return {'envs': n, 'steps_per_launch': K, 'us_per_launch': us, 'us_per_control_step': us / K, 'env_steps_per_s': rate,
             'algorithmic_bytes_per_env_step': bytes_es, 'achieved_GBs': rate * bytes_es / 1e9,
-            'frac': rate * bytes_es / 1e9 / HBM_PEAK_GBS, 'finite_outputs': ok,
-            'note': 'parity: tests/test_gpu_sequence.py (bit-identical to K x scg_step); the headline above stays one launch per control step'}
+            'frac': rate * bytes_es / 1e9 / HBM_PEAK_GBS,
+            'frac_on_per_step_bytes': rate * ALGO_BYTES_PER_ENV_STEP.get(task, 0) / 1e9 / HBM_PEAK_GBS,
+            'finite_outputs': ok,
+            'note': 'parity: tests/test_gpu_sequence.py (bit-identical to K x scg_step); the headline above stays one launch per control '
+                    'step.  frac counts the bytes THIS kernel moves (state, counters and running statistics cross HBM once per launch); '
+                    'frac_on_per_step_bytes applies SURVEY 8d / BASELINE.md 3\'s definition (per-step algorithmic bytes x env-steps/s) to this rate'}
 
 
 def fused_rollout_leg(torch, n, T=32):
