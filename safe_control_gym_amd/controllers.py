@@ -34,8 +34,12 @@ SAC_DEFAULTS = dict(hidden_dim=256, activation='relu', norm_obs=False, norm_rewa
                     tau=0.005, init_temperature=0.2, use_entropy_tuning=False, target_entropy=None, train_interval=100,
                     train_batch_size=64, actor_lr=0.001, critic_lr=0.001, entropy_lr=0.001, warm_up_steps=1000,
                     max_buffer_size=1000000, **_RUNNER)                         # controllers/sac/sac.yaml
-RARL_DEFAULTS = dict(PPO_DEFAULTS, agent_iterations=10, adversary_iterations=10)        # controllers/rarl/rarl.yaml
-RAP_DEFAULTS = dict(RARL_DEFAULTS, num_adversaries=2)                                   # controllers/rarl/rap.yaml
+# controllers/rarl/rarl.yaml (its `pretrained`, `train_protagonist`, `train_adversary` keys are read by nothing upstream either)
+RARL_DEFAULTS = dict(PPO_DEFAULTS, agent_iterations=10, adversary_iterations=10, pretrained=None, train_protagonist=True,
+                     train_adversary=True)
+RARL_DEFAULTS.pop('activation')                                                         # (rarl.yaml / rap.yaml have no such key)
+RAP_DEFAULTS = dict({k: v for k, v in RARL_DEFAULTS.items() if k not in ('pretrained', 'train_protagonist', 'train_adversary')},
+                    num_adversaries=2)                                                  # controllers/rarl/rap.yaml
 
 
 class _Deterministic:
