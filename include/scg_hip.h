@@ -270,6 +270,8 @@ typedef struct {
     void* d_c_values;           /* [K][n_con_rows][N] or NULL */
     void* d_ep_stats;           /* [N][4] running episode totals (read at launch, written back at the end) or NULL */
     void* d_fin_stats;          /* [K][N][4] totals of the episodes that finished at step t, or NULL */
+    void* d_state;              /* [K][state_dim][N] env.state after step t and auto-reset, or NULL */
+    void* d_noisy_action;       /* [K][action_dim][N] current_noisy_physical_action of step t, or NULL */
 } scg_sequence;
 int scg_step_sequence(scg_env* env, int k_steps, const scg_sequence* seq, void* stream);
 

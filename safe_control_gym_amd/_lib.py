@@ -101,7 +101,7 @@ class PolicyRollout(C.Structure):
 
 class Sequence(C.Structure):
     _fields_ = [(n, c_vp) for n in ('d_actions', 'd_adv_actions', 'd_obs', 'd_reward', 'd_done', 'd_flags', 'd_terminal_obs',
-                                    'd_mse', 'd_c_values', 'd_ep_stats', 'd_fin_stats')]
+                                    'd_mse', 'd_c_values', 'd_ep_stats', 'd_fin_stats', 'd_state', 'd_noisy_action')]
 
 
 class RolloutOut(C.Structure):

@@ -482,6 +482,8 @@ struct SeqArgs {
     T* c_values;            // [K][rows][N] or null
     T* ep_stats;            // [N][4] or null (running totals, read-modify-written once per launch)
     T* fin_stats;           // [K][N][4] or null
+    T* state;               // [K][nx][N] or null (env.state after the step and auto-reset)
+    T* noisy_action;        // [K][nu][N] or null
 };
 
 template <int SYS, typename T, bool DIST>
@@ -551,6 +553,11 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
         slot(A.done + tn, i).store((uint8_t)(r.done ? 1 : 0));
         slot(A.flags + tn, i).store((uint8_t)r.flags);
         if (A.mse) slot(A.mse + tn, i).store(r.mse);
+        if (A.noisy_action) {
+            const Slot<T> na = slot(A.noisy_action + tn * D::NU, i);
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) na.store(noisy[j], (size_t)j * N);
+        }
         ep[0] += r.reward;
         ep[1] += (T)1;
         ep[2] += (r.flags & FLAG_VIOLATION) ? (T)1 : (T)0;
@@ -594,6 +601,11 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
             } else {
                 Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, o_dst, nullptr);
             }
+        }
+        if (A.state) {
+            const Slot<T> so = slot(A.state + tn * D::NX, i);
+#pragma unroll
+            for (int k = 0; k < D::NX; ++k) so.store(st[k], (size_t)k * N);
         }
     }
     if (A.ep_stats) slot(A.ep_stats, i, 4).template store_row<4>(ep);

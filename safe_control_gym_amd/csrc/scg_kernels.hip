@@ -720,6 +720,7 @@ static int launch_sequence(scg_env* env, int k, const scg_sequence* q, hipStream
     A.obs = (T*)q->d_obs; A.reward = (T*)q->d_reward; A.done = q->d_done; A.flags = q->d_flags;
     A.terminal_obs = (T*)q->d_terminal_obs; A.mse = (T*)q->d_mse; A.c_values = (T*)q->d_c_values;
     A.ep_stats = (T*)q->d_ep_stats; A.fin_stats = (T*)q->d_fin_stats;
+    A.state = (T*)q->d_state; A.noisy_action = (T*)q->d_noisy_action;
     DISPATCH_SYS(env, T, (step_sequence_kernel<S, T, DD><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, A)));
     HIP_TRY(hipGetLastError());
     return SCG_OK;

@@ -354,11 +354,12 @@ class HipVecEnv(VecEnv):
         with torch.cuda.device(self.device):
             self._chk(self._lib.scg_rollout_policy(self._h, C.byref(policy), int(k_steps), C.byref(o), self._stream()))
 
-    def step_sequence(self, actions, adv_actions=None, out=None, terminal_obs=True, mse=False, c_values=False, fin_stats=False):
+    def step_sequence(self, actions, adv_actions=None, out=None, terminal_obs=True, mse=False, c_values=False, fin_stats=False,
+                      state=False, noisy_action=False):
         """K control steps in ONE launch with caller-supplied actions [K, N, action_dim] (scg_step_sequence) — the same
         results as K calls of step_tensors(actions[t]).  Returns (and fills, when passed back as `out`) a dict of
         [K]-stacked tensors: obs [K, N, obs_dim], reward / done / flags [K, N], and on request terminal_obs, mse,
-        c_values [K, rows, N], fin_stats [K, N, 4].  adv_actions: [K, N, adv_dim], already passed through
+        c_values [K, rows, N], fin_stats [K, N, 4], state [K, nx, N], noisy_action [K, nu, N].  adv_actions: [K, N, adv_dim], already passed through
         set_adversary_control's clip / scale / offset."""
         spec = self.spec
         if actions.dim() != 3 or actions.shape[1:] != (self.num_envs, spec.nu) or actions.dtype != self.dtype or not actions.is_contiguous():
@@ -377,12 +378,17 @@ class HipVecEnv(VecEnv):
                 out['c_values'] = torch.empty(K, len(spec.con_rows), self.num_envs, **f)
             if fin_stats:
                 out['fin_stats'] = torch.zeros(K, self.num_envs, 4, **f)
+            if state:
+                out['state'] = torch.empty(K, spec.nx, self.num_envs, **f)
+            if noisy_action:
+                out['noisy_action'] = torch.empty(K, spec.nu, self.num_envs, **f)
         q = L.Sequence()
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         q.d_actions, q.d_adv_actions = p(actions), p(adv_actions)
         q.d_obs, q.d_reward, q.d_done, q.d_flags = p(out['obs']), p(out['reward']), p(out['done']), p(out['flags'])
         q.d_terminal_obs, q.d_mse, q.d_c_values = p(out.get('terminal_obs')), p(out.get('mse')), p(out.get('c_values'))
         q.d_ep_stats, q.d_fin_stats = p(self.ep_stats), p(out.get('fin_stats'))
+        q.d_state, q.d_noisy_action = p(out.get('state')), p(out.get('noisy_action'))
         with torch.cuda.device(self.device):
             self._chk(self._lib.scg_step_sequence(self._h, K, C.byref(q), self._stream()))
         return out

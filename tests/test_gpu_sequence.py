@@ -30,12 +30,13 @@ def test_sequence_equals_repeated_steps(task, over, dtype, specialize):
     g = torch.Generator(device='cpu').manual_seed(3)
     acts = (torch.rand(K, n, a.spec.nu, generator=g, dtype=torch.float64) * 2 - 1).to(a.device, dtype)
     a.reset_tensors(); b.reset_tensors()
-    seq = a.step_sequence(acts, terminal_obs=True, mse=True, c_values=True, fin_stats=True)
+    seq = a.step_sequence(acts, terminal_obs=True, mse=True, c_values=True, fin_stats=True, state=True, noisy_action=True)
     n_done = 0
     for t in range(K):
         out = b.step_tensors(acts[t])
         for name, got, ref in (('obs', seq['obs'][t], out.obs), ('reward', seq['reward'][t], out.reward), ('done', seq['done'][t], out.done),
-                               ('flags', seq['flags'][t], out.flags), ('mse', seq['mse'][t], out.mse)):
+                               ('flags', seq['flags'][t], out.flags), ('mse', seq['mse'][t], out.mse), ('state', seq['state'][t], out.state),
+                               ('noisy_action', seq['noisy_action'][t], out.noisy_action)):
             assert torch.equal(got, ref), (name, t)
         if 'c_values' in seq:
             assert torch.equal(seq['c_values'][t], out.c_values), ('c_values', t)
