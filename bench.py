@@ -270,46 +270,53 @@ def gae_leg(torch):
     return out
 
 
-def sequence_leg(torch, n, K=32, task='quadrotor_2D_track'):
+def sequence_leg(torch, n, K=32, task='quadrotor_2D_track', K_all=8):
     """The same control steps with K of them per launch (scg_step_sequence): caller-supplied action sequences resident in
-    HBM, every per-step output (obs, reward, done, flags, mse, constraint values; terminal observation and episode totals
-    where done) written to [K]-stacked arrays, state in registers between steps.  Its own algorithmic bytes: per env-step
-    the action read and those outputs; state, counters and running episode statistics move once per launch."""
+    HBM, per-step outputs written to [K]-stacked arrays, state in registers between steps.  Two output sets: what a PPO-style
+    collector keeps (obs, reward, done, flags; terminal observation where done) and every output of scg_step (+ mse,
+    constraint values, state, noisy action, finished-episode statistics).  Bytes are this kernel's own: the action read and
+    the outputs per env-step; state, counters and running episode statistics move once per launch."""
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task(task)
     env = HipVecEnv(env_id, n, seed=7, return_numpy=False, **cfg)
-    env.reset_tensors()
-    acts = torch.rand(K, n, env.spec.nu, device=env.device) * 2 - 1
-    # every per-step output the API offers: obs, reward, done, flags, mse, constraint values, terminal observation and
-    # finished-episode statistics where done
-    out = env.step_sequence(acts, terminal_obs=True, mse=True, c_values=True, fin_stats=True)
-    for _ in range(3):
-        env.step_sequence(acts, out=out)
-    reps = 40
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    torch.cuda.synchronize()
-    ev[0].record()
-    for _ in range(reps):
-        env.step_sequence(acts, out=out)
-    ev[1].record()
-    torch.cuda.synchronize()
-    us = 1e3 * ev[0].elapsed_time(ev[1]) / reps
-    ok = bool(torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all())
     spec = env.spec
-    per_step = 4 * spec.nu + 4 * spec.obs_dim + 4 + 1 + 1 + 4 + 4 * len(spec.con_rows)          # action in; obs, reward, done, flags, mse, c_values out
-    per_launch = 2 * (4 * env._n_state_arrays() + 8) + 32              # state + counters in and out, episode statistics RMW
-    bytes_es = per_step + per_launch / K
-    rate = n * K / (us * 1e-6)
+    res = {'envs': n}
+    base = 4 * spec.nu + 4 * spec.obs_dim + 4 + 1 + 1                       # action in; obs, reward, done, flags out
+    extra = 4 + 4 * len(spec.con_rows) + 4 * spec.nx + 4 * spec.nu          # mse, constraint values, state, noisy action
+    per_launch = 2 * (4 * env._n_state_arrays() + 8) + 32                   # state + counters in and out, episode statistics RMW
+    # (K per variant: the [K]-stacked outputs of one launch should stay within the 256 MB Infinity Cache, like the 12 MB
+    #  set the per-step launches overwrite; 32 steps of every output are 457 MB and stream to HBM at 5.2 us per step)
+    for tag, kw, per_step, K in (('collector_outputs', dict(terminal_obs=True), base, K),
+                                 ('all_outputs', dict(terminal_obs=True, mse=True, c_values=True, fin_stats=True, state=True, noisy_action=True),
+                                  base + extra, K_all)):
+        acts = torch.rand(K, n, spec.nu, device=env.device) * 2 - 1
+        env.reset_tensors()
+        out = env.step_sequence(acts, **kw)
+        for _ in range(3):
+            env.step_sequence(acts, out=out)
+        reps = 40
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            env.step_sequence(acts, out=out)
+        ev[1].record()
+        torch.cuda.synchronize()
+        us = 1e3 * ev[0].elapsed_time(ev[1]) / reps
+        bytes_es = per_step + per_launch / K
+        rate = n * K / (us * 1e-6)
+        res[tag] = {'steps_per_launch': K, 'us_per_control_step': us / K, 'env_steps_per_s': rate, 'algorithmic_bytes_per_env_step': bytes_es,
+                    'stacked_output_MB_per_launch': sum(t.numel() * t.element_size() for t in out.values()) / 1e6,
+                    'frac': rate * bytes_es / 1e9 / HBM_PEAK_GBS,
+                    'frac_on_per_step_bytes': rate * ALGO_BYTES_PER_ENV_STEP.get(task, 0) / 1e9 / HBM_PEAK_GBS,
+                    'finite_outputs': bool(torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all())}
+        del out
     env.close()
-    return {'envs': n, 'steps_per_launch': K, 'us_per_launch': us, 'us_per_control_step': us / K, 'env_steps_per_s': rate,
-            'algorithmic_bytes_per_env_step': bytes_es, 'achieved_GBs': rate * bytes_es / 1e9,
-            'frac': rate * bytes_es / 1e9 / HBM_PEAK_GBS,
-            'frac_on_per_step_bytes': rate * ALGO_BYTES_PER_ENV_STEP.get(task, 0) / 1e9 / HBM_PEAK_GBS,
-            'finite_outputs': ok,
-            'note': 'parity: tests/test_gpu_sequence.py (bit-identical to K x scg_step); the headline above stays one launch per control '
-                    'step.  frac counts the bytes THIS kernel moves (state, counters and running statistics cross HBM once per launch); '
-                    'frac_on_per_step_bytes applies SURVEY 8d / BASELINE.md 3\'s definition (per-step algorithmic bytes x env-steps/s) to this rate'}
+    res['note'] = ('parity: tests/test_gpu_sequence.py (bit-identical to K x scg_step); the headline above stays one launch per control '
+                   'step.  frac counts the bytes THIS kernel moves; frac_on_per_step_bytes applies SURVEY 8d / BASELINE.md 3\'s definition '
+                   '(per-step algorithmic bytes x env-steps/s) to this rate')
+    return res
 
 
 def fused_rollout_leg(torch, n, T=32):

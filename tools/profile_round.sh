@@ -29,6 +29,6 @@ done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ppo_iteration -o p -- \
     python tools/ppo_profile.py --fused-rollout --iters 30 --minibatch 65024 > $OUT/ppo_iteration.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sequence -o p -- \
-    python -c "import torch, bench; torch.cuda.set_device(0); print(bench.sequence_leg(torch, 65536, 32))" > $OUT/sequence.log 2>&1 < /dev/null
+    python -c "import torch, bench; torch.cuda.set_device(0); print(bench.sequence_leg(torch, 65536))" > $OUT/sequence.log 2>&1 < /dev/null
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete; find $OUT -name '*.db' -delete; find $OUT -name '*.log' -size +200k -delete
 du -sh $OUT; ls $OUT | head -80
