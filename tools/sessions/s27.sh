@@ -7,5 +7,5 @@ grep -v "^$" $O/pytest.log | tail -6
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver.json 2> $O/bench_driver.err
 python -c "
 import json; d=json.loads(open('$O/bench_driver.json').read().strip().split('\n')[-1])
-print({k: d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'], d['f64']['frac'], d['sequence']['env_steps_per_s'], d['fused_rollout']['env_steps_per_s'], d['ppo']['wall_clock_to_target_s'], d['cpu_baseline']['value'])"
+print({k: d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'], d['f64']['frac'], d['sequence']['collector_outputs']['env_steps_per_s'], d['sequence']['all_outputs']['frac'], d['fused_rollout']['env_steps_per_s'], d['ppo']['wall_clock_to_target_s'], d['cpu_baseline']['value'])"
 tail -3 $O/bench_driver.err
