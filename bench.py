@@ -343,7 +343,7 @@ def fused_rollout_leg(torch, n, T=32):
             'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments'}
 
 
-def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=65024, lr=2e-3, target_kl=0.03, epochs=4):
+def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=32512, lr=2e-3, target_kl=0.03, epochs=4, rollout_steps=32):
     """PPO wall-clock until the deterministic-policy evaluation return reaches the reference reward (236 / 250, BASELINE.md
     §2): fused rollout, fused MFMA update; every iteration's weights are evaluated (fused deterministic rollout, 256 eval
     envs x 250 steps) on a second stream while training goes on; the clock starts after construction and stops when a
@@ -360,7 +360,7 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=650
         eval_env = HipVecEnv(env_id, 256, seed=seed * 111, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
         pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=target_kl,
                          entropy_coef=0.01, opt_epochs=epochs, mini_batch_size=minibatch, actor_lr=lr, critic_lr=lr,
-                         rollout_batch_size=envs, rollout_steps=32)
+                         rollout_batch_size=envs, rollout_steps=rollout_steps)
         ppo = PPO(env, pcfg, seed=seed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -393,10 +393,10 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=650
         times.append(reached); its.append(it); best_all.append(best)
         env.close(); eval_env.close()
     ok = [t for t in times if t is not None]
-    return {'target_return': 236.0, 'envs_per_gpu': envs, 'rollout_steps': 32, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
+    return {'target_return': 236.0, 'envs_per_gpu': envs, 'rollout_steps': rollout_steps, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
             'wall_clock_to_target_s': times, 'iterations': its, 'best_eval_return': best_all, 'reached': len(ok),
             'median_s': statistics.median(ok) if ok else None, 'budget_s_per_seed': budget_s,
-            'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {envs * 32 // minibatch} minibatches of {minibatch}, lr {lr:g}, '
+            'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {envs * rollout_steps // minibatch} minibatches of {minibatch}, lr {lr:g}, '
                      f'target_kl {target_kl:g}, GAE 0.95, gamma 0.99, ent 0.01',
             'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA); every iteration\'s weights evaluated by the fused '
                     'deterministic rollout on a second stream, clock stopped when a return >= target is seen'}

@@ -23,7 +23,7 @@ def main():
     ap.add_argument('--envs', type=int, default=16384)
     ap.add_argument('--rollout-steps', type=int, default=32)
     ap.add_argument('--epochs', type=int, default=4)
-    ap.add_argument('--minibatch', type=int, default=65024, help='127 x 512: the gradient kernel then fills 254 of the 256 CUs exactly')
+    ap.add_argument('--minibatch', type=int, default=32512, help='127 x 256: the gradient kernel then fills 254 of the 256 CUs exactly')
     ap.add_argument('--lr', type=float, default=2e-3)
     ap.add_argument('--critic-lr', type=float, default=None)
     ap.add_argument('--hidden', type=int, default=128)
