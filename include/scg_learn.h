@@ -73,10 +73,12 @@ int scg_ppo_grad(const scg_ppo_grad_args* args, void* stream);
 
 /* The two torch.optim.Adam steps of ppo_utils.py:126-138 on flat buffers (defaults: betas 0.9 / 0.999, eps 1e-8): elements
  * [0, n_actor) belong to the actor and step only when d_g[n] (approx_kl, possibly all-reduced) <= 1.5 target_kl (or
- * target_kl <= 0); the critic's always step.  d_steps [2]: step counts (float).  d_stats_acc [5] (nullable): running sums of
- * d_stats [4] and of the actor steps taken. */
+ * target_kl <= 0); the critic's always step.  d_steps [2]: step counts (float), advanced by this call.  d_stats_acc [5]
+ * (nullable): running sums of d_stats [4] and of the actor steps taken.  d_block_counter: one zero-initialised 32-bit word
+ * of device memory owned by the caller (the kernel's last block advances the counts and re-arms it). */
 int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor, float lr_critic,
-                   float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, void* stream);
+                   float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, uint32_t* d_block_counter,
+                   void* stream);
 
 /* d_out[i] = pi(i) for i < count, pi a keyed pseudo-random permutation of [0, n) (count <= n): the shuffled row indices of
  * one epoch's minibatches (SubsetRandomSampler + BatchSampler(drop_last=True), ppo_utils.py:358-371), one launch. */

@@ -520,42 +520,49 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
 }
 
 // Two Adam optimisers on the flat buffers (torch.optim.Adam defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay),
-// the actor's step gated by approx_kl <= 1.5 target_kl (ppo_utils.py:126-131); step counters are read here and advanced
-// by adam_count_kernel afterwards.
+// the actor's step gated by approx_kl <= 1.5 target_kl (ppo_utils.py:126-131).
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; int n; int n_actor; float lr_actor, lr_critic;
     float* steps;           // [2] actor, critic step counts (float, as the graphed torch version kept them)
     float target_kl;
     float* stats_acc; const float* stats;       // running sums over the update: 3 losses, kl, actor steps taken
+    unsigned int* done;     // block counter (0 between launches): the last block to finish advances the step counts
 };
 
+// Every thread reads the step counts before its block signs off; the LAST block to sign off advances them (and the running
+// statistics) and re-arms the counter — one launch instead of an update kernel plus a one-thread bookkeeping kernel.
 __global__ __launch_bounds__(256) void adam_gated_kernel(const AdamArgs A) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= A.n) return;
     const float kl = A.g[A.n];
     const bool gate = A.target_kl <= 0.0f || kl <= 1.5f * A.target_kl;
-    const bool critic = e >= A.n_actor;
-    if (!critic && !gate) return;
-    const float t = (critic ? A.steps[1] : A.steps[0]) + 1.0f;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    const float g = A.g[e];
-    const float m = b1 * A.m[e] + (1.0f - b1) * g;
-    const float v = b2 * A.v[e] + (1.0f - b2) * g * g;
-    A.m[e] = m; A.v[e] = v;
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float lr = critic ? A.lr_critic : A.lr_actor;
-    A.p[e] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
-}
-
-__global__ void adam_count_kernel(const AdamArgs A) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float kl = A.g[A.n];
-    const bool gate = A.target_kl <= 0.0f || kl <= 1.5f * A.target_kl;
-    A.steps[0] += gate ? 1.0f : 0.0f;
-    A.steps[1] += 1.0f;
-    if (A.stats_acc) {
-        A.stats_acc[0] += A.stats[0]; A.stats_acc[1] += A.stats[1]; A.stats_acc[2] += A.stats[2]; A.stats_acc[3] += A.stats[3];
-        A.stats_acc[4] += gate ? 1.0f : 0.0f;
+    const float t_actor = A.steps[0] + 1.0f, t_critic = A.steps[1] + 1.0f;
+    if (e < A.n) {
+        const bool critic = e >= A.n_actor;
+        if (critic || gate) {
+            const float t = critic ? t_critic : t_actor;
+            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+            const float g = A.g[e];
+            const float m = b1 * A.m[e] + (1.0f - b1) * g;
+            const float v = b2 * A.v[e] + (1.0f - b2) * g * g;
+            A.m[e] = m; A.v[e] = v;
+            const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+            const float lr = critic ? A.lr_critic : A.lr_actor;
+            A.p[e] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(A.done, 1u) == gridDim.x - 1) {
+            A.steps[0] = t_actor - (gate ? 0.0f : 1.0f);
+            A.steps[1] = t_critic;
+            if (A.stats_acc) {
+                A.stats_acc[0] += A.stats[0]; A.stats_acc[1] += A.stats[1]; A.stats_acc[2] += A.stats[2]; A.stats_acc[3] += A.stats[3];
+                A.stats_acc[4] += gate ? 1.0f : 0.0f;
+            }
+            __threadfence();
+            *A.done = 0u;
+        }
     }
 }
 
@@ -656,12 +663,10 @@ extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
 
 extern "C" int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor,
                               float lr_critic, float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats,
-                              void* stream) {
-    if (!d_p || !d_g || !d_m || !d_v || !d_steps || n <= 0) return fail(-1, "scg_adam_gated: bad argument");
-    AdamArgs A{d_p, d_g, d_m, d_v, n, n_actor, lr_actor, lr_critic, d_steps, target_kl, d_stats_acc, d_stats};
-    hipStream_t st = (hipStream_t)stream;
-    adam_gated_kernel<<<dim3((n + 255) / 256), dim3(256), 0, st>>>(A);
-    adam_count_kernel<<<dim3(1), dim3(64), 0, st>>>(A);
+                              uint32_t* d_block_counter, void* stream) {
+    if (!d_p || !d_g || !d_m || !d_v || !d_steps || !d_block_counter || n <= 0) return fail(-1, "scg_adam_gated: bad argument");
+    AdamArgs A{d_p, d_g, d_m, d_v, n, n_actor, lr_actor, lr_critic, d_steps, target_kl, d_stats_acc, d_stats, d_block_counter};
+    adam_gated_kernel<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(A);
     HIP_TRY(hipGetLastError());
     return 0;
 }

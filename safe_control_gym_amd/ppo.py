@@ -246,6 +246,7 @@ class PPOAgent:
         F['ws'] = torch.empty(D.scg_ppo_grad_workspace_bytes(n_wg), dtype=torch.uint8, device=dev)
         F['stats'] = torch.zeros(4, device=dev)
         F['stats_acc'] = torch.zeros(5, device=dev)
+        F['adam_sync'] = torch.zeros(1, dtype=torch.int32, device=dev)       # scg_adam_gated's block counter
         F['idx'] = torch.zeros(mb, dtype=torch.int32, device=dev)
         p = lambda t: t.data_ptr()                              # noqa: E731
         F['args'] = _learn.PpoGradArgs(
@@ -270,7 +271,7 @@ class PPOAgent:
         _learn.check(F['lib'], F['lib'].scg_adam_gated(
             fl['p'].data_ptr(), fl['g'].data_ptr(), fl['m'].data_ptr(), fl['v'].data_ptr(), fl['n'], fl['n_a'],
             float(cfg.actor_lr), float(cfg.critic_lr), fl['steps'].data_ptr(), float(cfg.target_kl),
-            F['stats_acc'].data_ptr(), F['stats'].data_ptr(), st))
+            F['stats_acc'].data_ptr(), F['stats'].data_ptr(), F['adam_sync'].data_ptr(), st))
 
     def _update_fused(self, data, generator=None):
         cfg = self.cfg
