@@ -65,7 +65,12 @@ class HipController:
         for k, v in cfg.items():                    # base_controller.py:40-41: algo args become attributes
             setattr(self, k, v)
         self.env_id, self.task_config = resolve_env_func(env_func)
-        self.task_config.pop('output_dir', None)
+        # keys of the reference's task YAMLs that are HipVecEnv's own named parameters or moot here: every
+        # examples/rl/config_overrides/*/*.yaml carries `seed:` inside task_config, and env_func is
+        # partial(make, task, output_dir=..., **task_config) — the controller's `seed` argument wins, as upstream
+        # (make_vec_envs(env_func, None, n, workers, seed), ppo.py:48)
+        for k in ('output_dir', 'seed', 'num_envs', 'return_numpy', 'policy', 'device'):
+            self.task_config.pop(k, None)
         self.results_dict = {}
         self._build()
 
@@ -232,15 +237,12 @@ class SAC(HipController):
     def _act_module(self):
         return self._det
 
-    def save(self, path):
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save({'agent': self.impl.agent.state_dict(), 'total_steps': self.impl.total_steps}, path)
+    def save(self, path, save_buffer=True):
+        """sac.py:119-141: agent + (training) total_steps, obs, RNG state, env random state and, with save_buffer, the replay ring."""
+        self.impl.save(path, training=self.training, save_buffer=save_buffer)
 
     def load(self, path):
-        sd = torch.load(path, map_location=self.device, weights_only=False)
-        self.impl.agent.load_state_dict(sd['agent'], with_optimizers=self.training)
-        if self.training:
-            self.impl.total_steps = int(sd.get('total_steps', 0))
+        self.impl.load(path, training=self.training)
 
 
 # (the ids 'ppo', 'sac', 'rarl', 'rap' are registered in registration.py with lazy entry points to these classes)

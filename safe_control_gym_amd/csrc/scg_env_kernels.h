@@ -686,8 +686,12 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
         // ---- rollout row obs[t]
         {
             const Slot<T> dst = slot(A.obs + (size_t)t * N * NIN, i, NIN);
-            if (full_wave) store_rows_coalesced<T, NIN>(dst, row, s_wave, lane);
-            else if (live) dst.template store_row<NIN>(row);
+            if constexpr ((NIN * (int)sizeof(T)) % 16 == 0) {              // 16-byte rows leave through the LDS transpose (as in step_kernel)
+                if (full_wave) store_rows_coalesced<T, NIN>(dst, row, s_wave, lane);
+                else if (live) dst.template store_row<NIN>(row);
+            } else {                                                       // e.g. 6-float rows (Quadrotor2D stabilisation), 2-float (1-D)
+                if (live) dst.template store_row<NIN>(row);
+            }
         }
         if (t == A.k_steps) break;
         // ---- actor forward for the wave's two 32-env column tiles (lane (c, h) owns env 32 h + c of the wave)

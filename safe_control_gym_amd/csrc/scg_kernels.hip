@@ -759,6 +759,10 @@ extern "C" int scg_rollout_policy(scg_env* env, const scg_policy* pol, int k_ste
     HIP_TRY(hipSetDevice(env->device));
     constexpr int S = SCG_SPEC_SYS;
     constexpr bool DD = SCG_SPEC_DIST != 0;
+    if constexpr ((scg_make_spec_cfg<float>().nobs * sizeof(float)) % 16 == 0) {      // rows leave as 16-byte pieces: obs[t] must stay aligned
+        if (((size_t)env->cfg.num_envs * scg_make_spec_cfg<float>().nobs * sizeof(float)) % 16 != 0)
+            return fail(SCG_ERR_INVALID, "num_envs x obs_dim x 4 must be a multiple of 16 (row alignment of the [t]-stacked obs)");
+    }
     PolicyArgs A;
     A.params = pol->d_params; A.W1 = pol->W1; A.b1 = pol->b1; A.W2 = pol->W2; A.b2 = pol->b2; A.W3 = pol->W3; A.b3 = pol->b3;
     A.logstd_off = pol->logstd_off; A.deterministic = pol->deterministic; A.k_steps = k_steps;

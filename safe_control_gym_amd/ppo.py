@@ -277,7 +277,7 @@ class PPOAgent:
         cfg = self.cfg
         M = data['obs'].shape[0]
         mb = min(cfg.mini_batch_size, M)
-        mb -= mb % 32                                           # the kernel works on 32-sample tiles (drop-last, like upstream's)
+        assert mb >= 32 and mb % 32 == 0, 'update() routes other minibatch sizes to the PyTorch path'     # 32-sample tiles
         n_mb = M // mb
         assert n_mb != 0, 'num_mini_batch is 0'
         for k, v in data.items():
@@ -421,6 +421,9 @@ class PPOAgent:
         if 'flat_adam' in sd and self._flat is not None:
             for k, t in sd['flat_adam'].items():
                 self._flat[k].copy_(t.to(self.device))      # in place: captured graphs alias these buffers
+        elif 'flat_adam' in sd and int(sd['flat_adam']['steps'].max()) > 0:
+            raise ValueError('checkpoint carries the flat Adam moments of a graph / fused-mode agent; this agent steps torch.optim '
+                             "optimisers (cuda_graphs off) and would silently restart them from zero — load it with cuda_graphs on")
         elif self._flat is not None and 'actor_opt' in sd and sd['actor_opt'].get('state'):
             raise ValueError('checkpoint carries torch.optim state only (saved with cuda_graphs off); load it with '
                              "extra={'cuda_graphs': False} or re-save — the flat Adam moments would silently restart from zero")
@@ -431,7 +434,10 @@ class PPOAgent:
         perms (tests): one index permutation of range(M) per epoch instead of torch.randperm (eager path)."""
         if perms is not None:
             assert not self.use_graphs, 'explicit permutations are an eager-path (test) facility'
-        if self.use_fused and self.ac.actor.action_modifier is None:
+        mb0 = min(self.cfg.mini_batch_size, data['obs'].shape[0])
+        # the MFMA learner works on 32-row tiles: minibatch sizes it cannot serve EXACTLY take the graphed PyTorch update
+        # (same result as the reference's minibatching) instead of being silently rounded down
+        if self.use_fused and self.ac.actor.action_modifier is None and mb0 >= 32 and mb0 % 32 == 0:
             return self._update_fused(data, generator)
         if self.use_graphs:
             return self._update_graphed(data, generator)
@@ -673,6 +679,8 @@ class PPO:
         res = self.agent.update(data)
         if not self._fused_rollout:             # (the fused collector re-derives obs[0] from the simulator state)
             self.obs[0].copy_(self.obs[self.T])
+        else:
+            self._obs_row = self.T              # the CURRENT observation is the last row the collector wrote (checkpoint 'obs')
         res.update({'step': self.total_steps, 'collect_time': t1 - t0, 'elapsed_time': time.perf_counter() - t0})
         return res
 
@@ -688,7 +696,7 @@ class PPO:
             if hasattr(nz, 'rms'):
                 state[f'{name}_normalizer_count'] = float(nz.rms.count)
         if training:
-            state.update({'total_steps': self.total_steps, 'obs': self.obs[0].cpu(),
+            state.update({'total_steps': self.total_steps, 'obs': self.obs[getattr(self, '_obs_row', 0)].cpu(),
                           'random_state': {'torch': torch.get_rng_state(),
                                            'torch_cuda': torch.cuda.get_rng_state(self.device) if self.device.type == 'cuda' else None},
                           'env_random_state': self.env.get_env_random_state()})
@@ -712,6 +720,7 @@ class PPO:
         if training and 'total_steps' in state:
             self.total_steps = state['total_steps']
             self.obs[0].copy_(state['obs'].to(self.device))
+            self._obs_row = 0
             torch.set_rng_state(state['random_state']['torch'])
             if state['random_state'].get('torch_cuda') is not None and self.device.type == 'cuda':
                 torch.cuda.set_rng_state(state['random_state']['torch_cuda'], self.device)

@@ -130,6 +130,21 @@ class DeviceReplay:
         self.size = min(self.size + n, self.capacity)
         self.size_t.fill_(float(self.size))
 
+    def state_dict(self):
+        """SACBuffer.state_dict (sac_utils.py:330-338): the filled part of the ring + the write position."""
+        n = self.size
+        return {'obs': self.obs[:n].cpu(), 'act': self.act[:n].cpu(), 'rew': self.rew[:n].cpu(), 'next_obs': self.next_obs[:n].cpu(),
+                'mask': self.mask[:n].cpu(), 'pos': self.pos, 'size': self.size}
+
+    def load_state_dict(self, sd):
+        n = int(sd['size'])
+        if n > self.capacity:
+            raise ValueError(f'checkpointed replay holds {n} transitions, capacity is {self.capacity}')
+        for k in ('obs', 'act', 'rew', 'next_obs', 'mask'):
+            getattr(self, k)[:n].copy_(sd[k].to(self.obs.device))
+        self.pos, self.size = int(sd['pos']) % self.capacity, n
+        self.size_t.fill_(float(n))
+
     def sample_static(self, batch_size):
         """Uniform sample with static shapes and no host value: usable under HIP-graph capture."""
         idx = (torch.rand(batch_size, device=self.obs.device) * self.size_t).long().clamp_(min=0)
@@ -288,6 +303,10 @@ class SAC:
         self.device = env.device
         if env.dtype != torch.float32:
             raise ValueError('the SAC collector runs on float32 environments')
+        if cfg.extra.get('norm_obs') or cfg.extra.get('norm_reward'):
+            # sac.yaml:6-9 / sac.py:66-71: running normalisers around env.step.  Not built for SAC here — refuse rather than train
+            # unnormalised behind a config that asks for them (PPO has them: normalization.py)
+            raise NotImplementedError('norm_obs / norm_reward are not implemented for the SAC collector (defaults: False)')
         spec = env.spec
         self.N, self.obs_dim, self.act_dim = env.num_envs, spec.obs_dim, spec.nu
         rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
@@ -328,6 +347,43 @@ class SAC:
             results['updates'] = n_updates
         results.update({'step': self.total_steps, 'elapsed_time': time.perf_counter() - t0})
         return results
+
+    # ---- checkpoint / resume (sac.py:119-160: same keys)
+    def save(self, path, training=True, save_buffer=True):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        state = {'agent': self.agent.state_dict()}
+        if training:
+            state.update({'total_steps': self.total_steps, 'since_update': self._since_update, 'obs': self.obs.cpu(),
+                          'random_state': {'torch': torch.get_rng_state(),
+                                           'torch_cuda': torch.cuda.get_rng_state(self.device) if self.device.type == 'cuda' else None},
+                          'env_random_state': self.env.get_env_random_state()})
+            if save_buffer:                     # (upstream: on for model_latest, off for the intermediate checkpoints)
+                state['buffer'] = self.buffer.state_dict()
+        torch.save(state, path)
+
+    def load(self, path, training=True):
+        state = torch.load(path, map_location=self.device, weights_only=False)
+        self.agent.load_state_dict(state['agent'], with_optimizers=training)
+        if training and 'total_steps' in state:
+            self.total_steps = int(state['total_steps'])
+            self._since_update = int(state.get('since_update', 0))
+            if 'obs' in state:
+                self.obs = state['obs'].to(self.device).clone()
+            if 'env_random_state' in state:
+                self.env.set_env_random_state(state['env_random_state'])
+            rs = state.get('random_state')
+            if rs:
+                torch.set_rng_state(rs['torch'].cpu())
+                if rs.get('torch_cuda') is not None and self.device.type == 'cuda':
+                    torch.cuda.set_rng_state(rs['torch_cuda'].cpu(), self.device)
+            if 'buffer' in state:
+                self.buffer.load_state_dict(state['buffer'])
+            elif self.total_steps > self.cfg.warm_up_steps:
+                import warnings
+                warnings.warn('SAC checkpoint without replay buffer (save_buffer=False): training resumes past warm-up with an '
+                              'EMPTY buffer — the first updates sample only the transitions collected since the resume')
+        return state
 
     def learn(self, max_env_steps=None, log=None):
         max_env_steps = max_env_steps or self.cfg.max_env_steps

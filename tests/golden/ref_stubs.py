@@ -29,7 +29,21 @@ import xml.etree.ElementTree as etxml
 
 import numpy as np
 
-REFERENCE_ROOT = '/root/reference'
+import os
+
+
+def reference_root():
+    """Where the reference checkout is on THIS machine: $SCG_REFERENCE_ROOT, the build container's /root/reference, or the
+    untracked scratch copy tools/stage_reference.py makes under oracle/_ref/reference (travels to the gpurun box, never in
+    git).  None when there is none."""
+    here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for cand in (os.environ.get('SCG_REFERENCE_ROOT'), '/root/reference', os.path.join(here, 'oracle', '_ref', 'reference')):
+        if cand and os.path.isdir(os.path.join(cand, 'safe_control_gym')):
+            return cand
+    return None
+
+
+REFERENCE_ROOT = reference_root() or '/root/reference'
 REAL_PYBULLET = False       # set by install(): fixtures come from a real pybullet wheel instead of oracle/bullet.py
 
 

@@ -147,6 +147,167 @@ def test_planar_quadrotor_is_the_3d_body_restricted_to_the_xz_plane():
     first_order(errs)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The other half (round 3): the DEFAULTS the product ships.  With `engine_arm: pybullet` (URDF prop offset 0.028,
+# cf2x.urdf:42-78) and `pole_inertia: box` (Bullet's collision-box inertia, cartpole.py:301-304,318-322) the step must differ
+# from the reference ODE by EXACTLY those two constants and nothing else: it converges, first order, to the flow of the
+# reference's equations with only that constant replaced — any other difference (damping, clamp, frame, sign) would leave
+# an O(1) residual — and the replaced constant's effect on the right-hand side is the analytic one (torque arm x 0.028 /
+# (L / sqrt 2) on the roll / pitch rows only; m 0.05^2 / 12 added to the pole inertia in the theta row's denominator only).
+URDF_ARM = 0.028            # cf2x.urdf:42-78 (prop offsets +-0.028 in x and y)
+POLE_BOX_WIDTH = 0.05       # cartpole URDF collision box, cartpole.py:296-304
+
+
+def f_cartpole_general(x, u, length, cart_mass, pole_mass, g, pole_inertia):
+    """cartpole.py:400-414 with the slender-rod assumption undone: 4/3 l = (I + m l^2) / (m l) for I = m (2l)^2 / 12."""
+    xd, th, thd = x[:, 1], x[:, 2], x[:, 3]
+    Mm, ml = pole_mass + cart_mass, pole_mass * length
+    sn, cs = np.sin(th), np.cos(th)
+    tmp = (u[:, 0] + ml * thd * thd * sn) / Mm
+    thdd = (g * sn - cs * tmp) / ((pole_inertia + pole_mass * length * length) / ml - ml * cs * cs / Mm)
+    return np.stack([xd, tmp - ml * thdd * cs / Mm, thd, thdd], axis=1)
+
+
+def default_constant_ode(name, meta):
+    """(f_default, f_reference): the reference ODE with ONLY the engine's constant swapped in, and the reference ODE."""
+    from oracle import bullet, symbolic
+    from oracle.envs import make_oracle_env, make_rng
+    env = make_oracle_env(meta['task'], 1, make_rng('philox', 1, 0), **dict(meta['config']))
+    f_ref = oracle_f(name, meta)
+    if name == 'cartpole':
+        m, l = env.POLE_MASS, env.EFFECTIVE_POLE_LENGTH
+        i_rod, i_box = float(bullet.pole_inertia(np.array([m]), np.array([l]), 'rod')[0]), float(bullet.pole_inertia(np.array([m]), np.array([l]), 'box')[0])
+        assert abs((i_box - i_rod) - m * POLE_BOX_WIDTH ** 2 / 12.0) < 1e-15                     # the one constant
+        f_rod = lambda x, u: f_cartpole_general(x, u, l, env.CART_MASS, m, env.GRAVITY_ACC, i_rod)   # noqa: E731
+        return (lambda x, u: f_cartpole_general(x, u, l, env.CART_MASS, m, env.GRAVITY_ACC, i_box)), f_ref, f_rod
+    mass, J, g = env.MASS, np.asarray(env.J, dtype=float).reshape(-1), env.GRAVITY_ACC
+    if name == 'quadrotor_2D':
+        return (lambda x, u: symbolic.f_quad2d(x, u, mass, J[1], URDF_ARM, g)), f_ref, None
+    return (lambda x, u: symbolic.f_quad3d(x, u, mass, np.tile(J, (x.shape[0], 1)), URDF_ARM, env.KM / env.KF, g)), f_ref, None
+
+
+def flow(f, x0, u):
+    out = np.empty_like(x0)
+    for i in range(x0.shape[0]):
+        sol = solve_ivp(lambda t, x: f(x[None], u[i:i + 1])[0], (0.0, T_END), x0[i], method='DOP853', rtol=1e-12, atol=1e-14)
+        out[i] = sol.y[:, -1]
+    return out
+
+
+@pytest.mark.parametrize('name', ['quadrotor_3D', 'quadrotor_2D', 'cartpole'])
+def test_default_constants_change_the_reference_ode_by_their_analytic_effect_only(name):
+    x0, u, meta = start_points(name)
+    f_def, f_ref, f_rod = default_constant_ode(name, meta)
+    d = f_def(x0, u) - f_ref(x0, u)
+    if name == 'cartpole':
+        np.testing.assert_allclose(f_rod(x0, u), f_ref(x0, u), rtol=0, atol=1e-13)    # undoing the rod assumption changes nothing by itself
+        assert np.all(d[:, [0, 2]] == 0.0) and np.max(np.abs(d[:, [1, 3]])) > 0       # kinematic rows untouched
+        # first order in dI: theta_ddot scales by -dI / (m l) / denominator  (6e-4 relative for the shipped pole)
+        from oracle.envs import make_oracle_env, make_rng
+        env = make_oracle_env(meta['task'], 1, make_rng('philox', 1, 0), **dict(meta['config']))
+        m, l, Mm = env.POLE_MASS, env.EFFECTIVE_POLE_LENGTH, env.POLE_MASS + env.CART_MASS
+        den = 4.0 / 3.0 * l - m * l * np.cos(x0[:, 2]) ** 2 / Mm
+        rel = -(m * POLE_BOX_WIDTH ** 2 / 12.0) / (m * l) / den
+        np.testing.assert_allclose(d[:, 3], f_ref(x0, u)[:, 3] * rel, rtol=2e-3, atol=1e-12)
+        return
+    rows = [5] if name == 'quadrotor_2D' else [9, 10]
+    others = [k for k in range(x0.shape[1]) if k not in rows]
+    assert np.all(d[:, others] == 0.0)
+    from oracle.envs import make_oracle_env, make_rng
+    env = make_oracle_env(meta['task'], 1, make_rng('philox', 1, 0), **dict(meta['config']))
+    ratio = URDF_ARM / (env.L / np.sqrt(2.0))
+    assert abs(ratio - 1.0) < 3e-3                                                    # the 0.26 % the verdict names
+    J = np.asarray(env.J, dtype=float).reshape(-1)
+    if name == 'quadrotor_2D':
+        torque = (env.L / np.sqrt(2.0)) * (u[:, 1] - u[:, 0]) / J[1]
+        np.testing.assert_allclose(d[:, 5], (ratio - 1.0) * torque, rtol=1e-9, atol=1e-12)
+    else:
+        arm = env.L / np.sqrt(2.0)
+        t0 = arm * (u[:, 0] + u[:, 1] - u[:, 2] - u[:, 3]) / J[0]
+        t1 = arm * (-u[:, 0] + u[:, 1] + u[:, 2] - u[:, 3]) / J[1]
+        np.testing.assert_allclose(d[:, 9], (ratio - 1.0) * t0, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(d[:, 10], (ratio - 1.0) * t1, rtol=1e-9, atol=1e-12)
+
+
+def test_restated_bullet_steps_with_default_constants_converge_to_the_constant_swapped_ode():
+    """oracle/bullet.py with the constants the oracle envs use by default (0.028 arm, box inertia)."""
+    from oracle import bullet
+    from oracle.envs import make_oracle_env, make_rng
+    # 3-D quadrotor
+    x0, u, meta = start_points('quadrotor_3D')
+    env = make_oracle_env('quadrotor', 1, make_rng('philox', 1, 0), **dict(meta['config']))
+    f_def, f_ref, _ = default_constant_ode('quadrotor_3D', meta)
+    ref = flow(f_def, x0, u)
+    n = x0.shape[0]
+    mass, J = np.full(n, env.MASS), np.tile(np.asarray(env.J, dtype=float).reshape(-1), (n, 1))
+    yaw = env.KM / env.KF * (-u[:, 0] + u[:, 1] - u[:, 2] + u[:, 3])
+    errs = []
+    for h in HS:
+        pos, quat, vel, om = quad3d_from_state(x0)
+        for _ in range(int(round(T_END / h))):
+            pos, quat, vel, om = bullet.quadrotor_substep(pos, quat, vel, om, u, yaw, None, mass, J, URDF_ARM, env.GRAVITY_ACC, h)
+        errs.append(np.max(np.abs(quad3d_to_state(pos, quat, vel, om) - ref)))
+    first_order(errs)
+    # and the gap to the UNSWAPPED reference flow is the constant's, to first order: (ratio - 1) x d flow / d log(arm)
+    gap = ref - flow(f_ref, x0, u)
+    assert 1e-5 < np.max(np.abs(gap)) < 5e-2
+    # cartpole
+    x0, u, meta = start_points('cartpole')
+    x0[:, 2] *= 0.5
+    env = make_oracle_env('cartpole', 1, make_rng('philox', 1, 0), **dict(meta['config']))
+    f_def, f_ref, _ = default_constant_ode('cartpole', meta)
+    ref = flow(f_def, x0, u)
+    n = x0.shape[0]
+    M, m, l = np.full(n, env.CART_MASS), np.full(n, env.POLE_MASS), np.full(n, env.EFFECTIVE_POLE_LENGTH)
+    ip = bullet.pole_inertia(m, l, 'box')
+    errs = []
+    for h in HS:
+        x, xd, th, thd = (x0[:, k].copy() for k in range(4))
+        for _ in range(int(round(T_END / h))):
+            x, xd, th, thd = bullet.cartpole_substep(x, xd, th, thd, u[:, 0], None, M, m, l, ip, env.GRAVITY_ACC, h)
+        errs.append(np.max(np.abs(np.stack([x, xd, th, thd], axis=1) - ref)))
+    first_order(errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['quadrotor_3D', 'quadrotor_2D', 'cartpole'])
+def test_hip_default_kernels_converge_to_the_constant_swapped_reference_ode(name):
+    """The float64 HIP step kernels with the DEFAULT `engine_arm` / `pole_inertia` (what the product ships and every parity
+    fixture runs): first-order convergence to the reference ODE with only that constant swapped."""
+    torch = pytest.importorskip('torch')
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    x0, u, meta = start_points(name)
+    if name == 'cartpole':
+        x0[:, 2] *= 0.5
+    f_def, _, _ = default_constant_ode(name, meta)
+    ref = flow(f_def, x0, u)
+    n = x0.shape[0]
+    errs = []
+    for pyb in (1000, 10000, 100000):
+        cfg = dict(meta['config'])
+        cfg.update(ctrl_freq=50, pyb_freq=pyb, episode_len_sec=5, normalized_rl_action_space=False, auto_reset=False,
+                   done_on_out_of_bound=False, randomized_init=False, constraints=None, cost='quadratic')
+        cfg.pop('engine_arm', None); cfg.pop('pole_inertia', None)                     # the defaults
+        env = HipVecEnv(meta['task'], n, seed=0, dtype=torch.float64, return_numpy=False, specialize=False, **cfg)
+        if name == 'cartpole':
+            assert env.spec.pole_box_width == POLE_BOX_WIDTH
+        else:
+            assert env.spec.engine_arm == URDF_ARM
+        env.reset_tensors()
+        lo, hi = np.asarray(env.spec.physical_action_bounds[0]), np.asarray(env.spec.physical_action_bounds[1])
+        ok = np.all((u >= lo) & (u <= hi), axis=1)
+        assert ok.sum() >= 3
+        raw = np.concatenate(quad3d_from_state(x0), axis=1) if name == 'quadrotor_3D' else x0
+        env.set_raw_state(raw)
+        act = torch.as_tensor(u, dtype=torch.float64, device=env.device)
+        for _ in range(int(round(T_END * 50))):
+            out = env.step_tensors(act)
+        st = out.state.t().cpu().numpy()
+        errs.append(np.max(np.abs(st[ok] - ref[ok])))
+        env.close()
+    first_order(errs)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['quadrotor_3D', 'quadrotor_2D', 'cartpole'])
 def test_hip_pyb_euler_kernels_converge_first_order_to_the_reference_ode(name):

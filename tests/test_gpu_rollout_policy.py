@@ -7,11 +7,16 @@ torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
 
-def _setup(task, n, hidden, act, seed=5):
+STAB6 = dict(task='stabilization', obs_goal_horizon=0, episode_len_sec=1.0)         # Quadrotor2D with the reference's default 6-float rows
+
+
+def _setup(task, n, hidden, act, seed=5, override=None):
     from safe_control_gym_amd.ppo import PPO, PPOConfig
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task(task)
+    if override:
+        cfg = {k: v for k, v in dict(cfg, **override).items() if k != 'task_info'}
     env = HipVecEnv(env_id, n, seed=seed, return_numpy=False, policy=(hidden, act), **cfg)
     ref = HipVecEnv(env_id, n, seed=seed, return_numpy=False, **cfg)
     assert env.policy_shape == (hidden, act)
@@ -23,11 +28,13 @@ def _setup(task, n, hidden, act, seed=5):
     return env, ref, ppo
 
 
-@pytest.mark.parametrize('task,hidden,act', [('quadrotor_2D_track', 128, 'tanh'), ('cartpole_stab', 64, 'leaky_relu'),
-                                             ('quadrotor_3D_track', 128, 'relu')])
-def test_fused_rollout_equals_step_by_step(task, hidden, act):
+@pytest.mark.parametrize('task,hidden,act,override', [('quadrotor_2D_track', 128, 'tanh', None), ('cartpole_stab', 64, 'leaky_relu', None),
+                                                      ('quadrotor_3D_track', 128, 'relu', None),
+                                                      ('quadrotor_2D_track', 64, 'tanh', STAB6)])     # rows of 24 bytes: no LDS transpose
+def test_fused_rollout_equals_step_by_step(task, hidden, act, override):
     n, K = 320, 12                                 # 5 waves: a partial workgroup as well
-    env, ref, ppo = _setup(task, n, hidden, act)
+    env, ref, ppo = _setup(task, n, hidden, act, override=override)
+    assert env.spec.obs_dim == (6 if override else env.spec.obs_dim)
     nobs, nu = env.spec.obs_dim, env.spec.nu
     f = dict(device=env.device, dtype=torch.float32)
     obs, actb, logp, rew = torch.zeros(K + 1, n, nobs, **f), torch.zeros(K, n, nu, **f), torch.zeros(K, n, **f), torch.zeros(K, n, **f)

@@ -3,8 +3,9 @@
 
     python tools/run_reference_ppo_on_hip.py [--reference /root/reference] [--algo ppo|sac] [--envs 64] [--steps 3]
 
-Needs a machine that has BOTH a HIP device and the reference checkout (the build container has no GPU, the gpurun box has no
-/root/reference: there the script prints SKIP and exits 0; tests/test_gpu_dropin.py calls it and skips likewise).
+Needs a machine that has BOTH a HIP device and the reference's Python.  The gpurun box has no /root/reference, so
+tools/stage_reference.py copies the package as untracked scratch to oracle/_ref/reference (git-ignored, ships with the
+snapshot); without either the script prints SKIP and exits 0.
 What it does — exactly the one-line change a maintainer makes in controllers/ppo/ppo.py:25 / sac/sac.py:
     from safe_control_gym.envs.env_wrappers.vectorized_env import make_vec_envs
  -> from safe_control_gym_amd.record_episode_statistics import make_vec_envs
@@ -25,19 +26,20 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--reference', default='/root/reference')
+    ap.add_argument('--reference', default=None, help='default: tests/golden/ref_stubs.reference_root()')
     ap.add_argument('--algo', default='ppo', choices=['ppo', 'sac'])
     ap.add_argument('--envs', type=int, default=64)
     ap.add_argument('--steps', type=int, default=3)
     args = ap.parse_args()
     import torch
+    from tests.golden import ref_stubs
+    args.reference = args.reference or ref_stubs.reference_root() or '/root/reference'
     if not os.path.isdir(os.path.join(args.reference, 'safe_control_gym')):
         print(f'SKIP: no reference checkout at {args.reference}')
         return 0
     if not torch.cuda.is_available():
         print('SKIP: no HIP device')
         return 0
-    from tests.golden import ref_stubs
     ref_stubs.REFERENCE_ROOT = args.reference
     ref_stubs.install()
     try:
@@ -48,12 +50,8 @@ def main():
                                                       'close': lambda s: None, 'flush': lambda s: None})
         sys.modules['torch.utils.tensorboard'] = tb
     import yaml
-    from safe_control_gym.utils.registration import make, register
-    try:
-        register(idx='quadrotor', entry_point='safe_control_gym.envs.gym_pybullet_drones.quadrotor:Quadrotor',
-                 config_entry_point='safe_control_gym.envs.gym_pybullet_drones:quadrotor.yaml')
-    except Exception:                                           # noqa: BLE001  (already registered by the package __init__)
-        pass
+    import safe_control_gym.envs  # noqa: F401  (the package __init__ registers 'cartpole' / 'quadrotor', envs/__init__.py:5-11)
+    from safe_control_gym.utils.registration import make
     from safe_control_gym_amd.record_episode_statistics import make_vec_envs
     over = yaml.safe_load(open(os.path.join(args.reference, 'examples/rl/config_overrides/quadrotor_2D/quadrotor_2D_track.yaml')))
     task_config = over['task_config']
