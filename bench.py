@@ -57,6 +57,9 @@ def parse():
     ap.add_argument('--graph-len', type=int, default=1000, help='steps captured per HIP graph')
     ap.add_argument('--ppo-seeds', type=int, default=3, help='seeds of the PPO wall-clock-to-reward leg (0 = skip)')
     ap.add_argument('--ppo-seconds', type=float, default=10.0, help='budget per seed')
+    ap.add_argument('--ppo-envs', type=int, default=65536, help='envs per GPU of the PPO leg (BASELINE config #3: 65 536)')
+    ap.add_argument('--sac-seeds', type=int, default=3, help='seeds of the SAC wall-clock-to-reward leg on config #5 (0 = skip)')
+    ap.add_argument('--sac-seconds', type=float, default=40.0, help='budget per seed')
     return ap.parse_args()
 
 
@@ -343,46 +346,100 @@ def fused_rollout_leg(torch, n, T=32):
             'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments'}
 
 
-def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=32512, lr=2e-3, target_kl=0.03, epochs=4, rollout_steps=32):
-    """PPO wall-clock until the deterministic-policy evaluation return reaches the reference reward (236 / 250, BASELINE.md
-    §2): fused rollout, fused MFMA update; every iteration's weights are evaluated (fused deterministic rollout, 256 eval
-    envs x 250 steps) on a second stream while training goes on; the clock starts after construction and stops when a
-    return >= 236 has been observed on the host.  With several ranks: env shards + one flat gradient all-reduce per minibatch (RCCL)."""
+# Evaluation protocol of the learning legs (round 3).  The deterministic policy is scored on `EVAL_ENVS` DISTINCT episodes, one per
+# eval env, each from its own randomised initial state (Philox stream per env, fresh draws at every evaluation), and the
+# target is the score of the reference's SHIPPED model measured under the very same protocol in the same run.
+# The draws are in-bounds versions of upstream's BASE table (quadrotor.py:70-135: x +-0.5, velocities +-0.01; z 1 +- 0.5 and
+# pitch +-0.1 here): upstream's own table ADDS U(0.1, 1.5) to z = 1 and U(-0.3, 0.3) to a +-0.2 rad bound, so more than half of
+# its episodes start out of bounds and end at step 1 — a score over those measures the draw, not the policy.
+EVAL_ENVS = 256
+EVAL_INIT_RAND_Q2 = {k: {'distrib': 'uniform', 'low': lo, 'high': hi} for k, (lo, hi) in {
+    'init_x': (-0.5, 0.5), 'init_x_dot': (-0.01, 0.01), 'init_z': (-0.5, 0.5), 'init_z_dot': (-0.01, 0.01),
+    'init_theta': (-0.1, 0.1), 'init_theta_dot': (-0.01, 0.01)}.items()}
+EVAL_INIT_RAND_Q3 = {k: {'distrib': 'uniform', 'low': lo, 'high': hi} for k, (lo, hi) in {
+    'init_x': (-0.5, 0.5), 'init_x_dot': (-0.01, 0.01), 'init_y': (-0.5, 0.5), 'init_y_dot': (-0.01, 0.01), 'init_z': (-0.5, 0.5),
+    'init_z_dot': (-0.01, 0.01), 'init_phi': (-0.1, 0.1), 'init_theta': (-0.1, 0.1), 'init_psi': (-0.1, 0.1),
+    'init_p': (-0.01, 0.01), 'init_q': (-0.01, 0.01), 'init_r': (-0.01, 0.01)}.items()}
+
+
+def eval_task_config(cfg, table):
+    """Task config of the evaluation env: same task, initial states drawn per episode from `table` (additive, like upstream)."""
+    return dict(cfg, randomized_init=True, respect_randomization_info=True, init_state_randomization_info=table)
+
+
+def shipped_ppo_score(torch, eval_env, tag='quadrotor_2D_track', hidden=128, act='tanh', evals=4):
+    """Deterministic-policy score of the reference's shipped PPO model (examples/rl/models/ppo/ppo_model_<tag>.pt, weights
+    committed as tests/golden/policies.npz) on `eval_env`, `evals` evaluations of EVAL_ENVS episodes each."""
+    import numpy as np
+    from safe_control_gym_amd.ppo import PPO, PPOConfig, _evaluate_fused_device
+    pol = np.load(os.path.join(ROOT, 'tests', 'golden', 'policies.npz'))
+    holder = PPO(eval_env, PPOConfig(hidden_dim=hidden, activation=act, use_gae=True, rollout_batch_size=eval_env.num_envs, rollout_steps=1,
+                                     mini_batch_size=eval_env.num_envs), seed=0)
+    holder.agent.ac.load_state_dict({k[len(tag) + 1:]: torch.as_tensor(pol[k]) for k in pol.files if k.startswith(tag + '/')})
+    scores, lengths = [], []
+    for _ in range(evals):
+        res, _ = _evaluate_fused_device(eval_env, holder._policy_struct(True), 1)
+        r = res.tolist()
+        scores.append(r[1]); lengths.append(r[2])
+    return {'mean_return': sum(scores) / len(scores), 'returns': scores, 'mean_length': sum(lengths) / len(lengths),
+            'episodes': evals * eval_env.num_envs}
+
+
+def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=32512, lr=2e-3, target_kl=0.03, epochs=4, rollout_steps=32,
+            target=None):
+    """PPO wall-clock until the deterministic-policy evaluation reaches the reference reward on BASELINE config #3's batch
+    (65 536 envs per GPU): fused rollout, fused MFMA update; every iteration's weights are evaluated on a second stream
+    (EVAL_ENVS distinct randomised-init episodes, fused deterministic rollout) while training goes on.  Target = the shipped
+    reference model's score under the same protocol, measured here first.  Two clocks per seed: until the FIRST evaluation
+    >= target is seen on the host, and until TWO CONSECUTIVE evaluations are (training continues until then or the budget).
+    With several ranks: env shards + one flat gradient all-reduce per minibatch (RCCL)."""
     from safe_control_gym_amd import parallel
     from safe_control_gym_amd.ppo import PPO, AsyncEvaluator, PPOConfig
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task('quadrotor_2D_track')
     pol = (128, 'tanh')
-    times, its, best_all = [], [], []
+    ev_cfg = eval_task_config(cfg, EVAL_INIT_RAND_Q2)
+    shipped = None
+    if target is None:
+        e0 = HipVecEnv(env_id, EVAL_ENVS, seed=4242, return_numpy=False, policy=pol, **ev_cfg)
+        shipped = shipped_ppo_score(torch, e0)
+        e0.close()
+        target = shipped['mean_return']
+        if world > 1:                                   # one number for every rank
+            t = torch.tensor([target], device='cuda', dtype=torch.float64)
+            parallel.broadcast_(t, 0)
+            target = float(t.item())
+    first, both, its, best_all, final = [], [], [], [], []
     for seed in range(1, seeds + 1):
         env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
-        eval_env = HipVecEnv(env_id, 256, seed=seed * 111, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
+        eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=seed * 111, return_numpy=False, policy=pol, **ev_cfg)
         pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=target_kl,
                          entropy_coef=0.01, opt_epochs=epochs, mini_batch_size=minibatch, actor_lr=lr, critic_lr=lr,
                          rollout_batch_size=envs, rollout_steps=rollout_steps)
         ppo = PPO(env, pcfg, seed=seed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reached, best, it = None, -1e30, 0
-        max_it = int(budget_s / 0.01)                   # iteration cap (identical on every rank: no rank leaves a collective alone)
-        # evaluation of weight snapshots on a second stream (ppo.AsyncEvaluator): every iteration's weights are evaluated,
-        # the result is looked at (without waiting) after the following iteration; the clock stops when a return >= 236 is SEEN
+        t_first, t_both, best, it, streak, last_ret = None, None, -1e30, 0, 0, None
+        max_it = int(budget_s / 0.005)                  # iteration cap (identical on every rank: no rank leaves a collective alone)
         aev = AsyncEvaluator(ppo, eval_env)
         while it < max_it:
             ppo.train_step()
             it += 1
             ev = aev.poll()
-            if ev is not None:
-                best = max(best, ev['ep_return'])
             torch.cuda.current_stream().synchronize()
             el = time.perf_counter() - t0
-            flag = torch.tensor([1.0 if (ev is not None and ev['ep_return'] >= 236.0) else 0.0, 1.0 if el > budget_s else 0.0],
-                                device=env.device)
+            if ev is not None:
+                last_ret = ev['ep_return']
+                best = max(best, last_ret)
+                streak = streak + 1 if last_ret >= target else 0
+                if streak >= 1 and t_first is None:
+                    t_first = el
+            flag = torch.tensor([1.0 if streak >= 2 else 0.0, 1.0 if el > budget_s else 0.0], device=env.device)
             if world > 1:                               # rank 0 decides for everybody
                 parallel.broadcast_(flag, 0)
             if flag[0].item() > 0:
-                reached = el
+                t_both = el
                 break
             if flag[1].item() > 0:
                 break
@@ -390,20 +447,123 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=16384, minibatch=325
         last = aev.poll(wait=True)
         if last is not None:
             best = max(best, last['ep_return'])
-        times.append(reached); its.append(it); best_all.append(best)
+            last_ret = last['ep_return']
+        first.append(t_first); both.append(t_both); its.append(it); best_all.append(best); final.append(last_ret)
         env.close(); eval_env.close()
-    ok = [t for t in times if t is not None]
-    return {'target_return': 236.0, 'envs_per_gpu': envs, 'rollout_steps': rollout_steps, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
-            'wall_clock_to_target_s': times, 'iterations': its, 'best_eval_return': best_all, 'reached': len(ok),
-            'median_s': statistics.median(ok) if ok else None, 'budget_s_per_seed': budget_s,
+    ok1, ok2 = [t for t in first if t is not None], [t for t in both if t is not None]
+    return {'target_return': target, 'target_source': 'shipped ppo_model_quadrotor_2D_track.pt under this protocol' if shipped else 'caller',
+            'shipped_model_eval': shipped, 'eval_protocol': f'{EVAL_ENVS} distinct episodes per evaluation, one per eval env, initial state = '
+            f'config init + U(x +-0.5, z +-0.5, pitch +-0.1, velocities +-0.01) per episode (fresh draws every evaluation), deterministic '
+            f'policy, mean return', 'envs_per_gpu': envs, 'rollout_steps': rollout_steps, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
+            'wall_clock_to_first_hit_s': first, 'wall_clock_to_two_consecutive_s': both, 'iterations': its, 'best_eval_return': best_all,
+            'last_eval_return': final, 'reached': len(ok1), 'reached_two_consecutive': len(ok2),
+            'median_first_hit_s': statistics.median(ok1) if ok1 else None, 'median_two_consecutive_s': statistics.median(ok2) if ok2 else None,
+            'median_s': statistics.median(ok2) if ok2 else None, 'budget_s_per_seed': budget_s,
             'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {envs * rollout_steps // minibatch} minibatches of {minibatch}, lr {lr:g}, '
                      f'target_kl {target_kl:g}, GAE 0.95, gamma 0.99, ent 0.01',
             'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA); every iteration\'s weights evaluated by the fused '
-                    'deterministic rollout on a second stream, clock stopped when a return >= target is seen'}
+                    'deterministic rollout on a second stream'}
+
+
+def sac_leg(torch, seeds, budget_s, envs=4096, batch=4096, updates_per_step=8, lr=1e-3, warm_up_steps=65536, eval_every=50,
+            buffer=4_000_000):
+    """SAC wall-clock-to-reward on BASELINE config #5's env (Quadrotor3D figure-8 tracking, white-noise dynamics disturbance,
+    constraint evaluation; `randomized_inertial_prop` OFF — upstream's additive draw doubles the mass and nothing can fly it,
+    DESIGN §7), sac.py:162-335 semantics on the HIP engine.  Target = the score of the reference's SHIPPED SAC model
+    (examples/rl/models/sac/sac_model_quadrotor_3D_track.pt, actor committed as tests/golden/sac_actor_quadrotor_3D_track.npz)
+    under the same evaluation protocol as the PPO leg (EVAL_ENVS distinct randomised-init episodes per evaluation).  The
+    evaluations run inside the clock on the training stream, every `eval_every` vector steps."""
+    import numpy as np
+    from safe_control_gym_amd.ppo import evaluate
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.sac import SAC, MLPActorCritic, SACConfig
+    from safe_control_gym_amd.vec_env import HipVecEnv
+
+    class Det:
+        def __init__(self, ac):
+            self.ac = ac
+
+        def act(self, obs):
+            return self.ac.act(obs, deterministic=True)
+
+    env_id, cfg = load_task('quadrotor_3D_track_disturbed')
+    cfg['randomized_inertial_prop'] = False
+    eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=4242, return_numpy=False, **eval_task_config(cfg, EVAL_INIT_RAND_Q3))
+    spec = eval_env.spec
+    low = torch.as_tensor(spec.action_space.low, dtype=torch.float32, device=eval_env.device)
+    high = torch.as_tensor(spec.action_space.high, dtype=torch.float32, device=eval_env.device)
+    f = np.load(os.path.join(ROOT, 'tests', 'golden', 'sac_actor_quadrotor_3D_track.npz'))
+    shipped = MLPActorCritic(spec.obs_dim, spec.nu, low, high, [128, 128], 'relu').to(eval_env.device)
+    shipped.load_state_dict({k: torch.as_tensor(f[k]) for k in f.files if k.startswith('actor.')}, strict=False)
+    det0 = Det(shipped)
+    evs = [evaluate(det0, eval_env) for _ in range(4)]
+    target = sum(e['ep_return'] for e in evs) / len(evs)
+    first, both, best_all, steps_all, grads_all, rate = [], [], [], [], [], []
+    for seed in range(1, seeds + 1):
+        env = HipVecEnv(env_id, envs, seed=seed, return_numpy=False, **cfg)
+        scfg = SACConfig(hidden_dim=128, activation='relu', train_batch_size=batch, actor_lr=lr, critic_lr=lr, warm_up_steps=warm_up_steps,
+                         train_interval=envs, max_buffer_size=buffer, extra={'updates_per_step': updates_per_step})
+        sac = SAC(env, scfg, seed=seed)
+        det = Det(sac.agent.ac)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_first, t_both, best, it, streak, n_grad = None, None, -1e30, 0, 0, 0
+        while time.perf_counter() - t0 < budget_s:
+            res = sac.train_step()
+            n_grad += int(res.get('updates', 0))
+            it += 1
+            if it % eval_every == 0:
+                e = evaluate(det, eval_env)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                best = max(best, e['ep_return'])
+                streak = streak + 1 if e['ep_return'] >= target else 0
+                if streak >= 1 and t_first is None:
+                    t_first = el
+                if streak >= 2:
+                    t_both = el
+                    break
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        first.append(t_first); both.append(t_both); best_all.append(best); steps_all.append(sac.total_steps); grads_all.append(n_grad)
+        rate.append(sac.total_steps / wall)
+        fused = bool(getattr(sac.agent, 'use_fused', False))
+        env.close()
+    eval_env.close()
+    ok1, ok2 = [t for t in first if t is not None], [t for t in both if t is not None]
+    return {'task': 'quadrotor_3D_track_disturbed (randomized_inertial_prop off)', 'target_return': target,
+            'target_source': 'shipped sac_model_quadrotor_3D_track.pt under this protocol',
+            'shipped_model_eval': {'returns': [e['ep_return'] for e in evs], 'mean_length': sum(e['ep_length'] for e in evs) / len(evs)},
+            'eval_protocol': f'{EVAL_ENVS} distinct randomised-init episodes per evaluation (x, y, z +-0.5, angles +-0.1, rates +-0.01), '
+                             f'deterministic policy, every {eval_every} vector steps inside the clock',
+            'envs': envs, 'seeds': list(range(1, seeds + 1)), 'wall_clock_to_first_hit_s': first, 'wall_clock_to_two_consecutive_s': both,
+            'best_eval_return': best_all, 'env_steps': steps_all, 'gradient_steps': grads_all, 'env_steps_per_s_incl_learning': rate,
+            'reached': len(ok1), 'reached_two_consecutive': len(ok2), 'median_first_hit_s': statistics.median(ok1) if ok1 else None,
+            'median_two_consecutive_s': statistics.median(ok2) if ok2 else None, 'median_s': statistics.median(ok2) if ok2 else None,
+            'budget_s_per_seed': budget_s, 'fused_update': fused,
+            'hyper': f'MLP 24-128-128 relu (actor + twin Q), batch {batch}, {updates_per_step} gradient steps per vector step of {envs} envs, '
+                     f'lr {lr:g}, warm-up {warm_up_steps} env steps, tau 0.005, alpha 0.2'}
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become the launcher.  Re-executes this file under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one rank per
+    GPU, exactly the driver's multi-GPU command), passes the ranks' stdout / stderr through, returns their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {" ".join(cmd[1:8])} ...', file=sys.stderr)
+    return subprocess.run(cmd).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_spawn(args))
     import torch
     import torch.distributed as dist
 
@@ -413,18 +573,30 @@ def main():
     # SCG_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices round-robin); the driver's runs use nccl (= RCCL), one rank per GPU.
     backend = os.environ.get('SCG_BENCH_BACKEND', 'nccl')
+    if world != args.gpus:
+        # the line's n_gpus must be the number of ranks that really ran: a mismatch is a launch error, not a warning
+        print(f'[bench] error: --gpus {args.gpus} but WORLD_SIZE={world} (launch with python -m torch.distributed.run '
+              f'--nproc-per-node {args.gpus}, or run plain `python bench.py --gpus {args.gpus}` and let bench.py spawn the ranks)',
+              file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
+            if torch.cuda.device_count() < world:
+                print(f'[bench] error: {world} ranks over RCCL need {world} GPUs, this node shows {torch.cuda.device_count()} '
+                      f'(SCG_BENCH_BACKEND=gloo shares devices for a control-flow test)', file=sys.stderr)
+                sys.exit(2)
             torch.cuda.set_device(local_rank)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            print(f'[bench] error: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}', file=sys.stderr)
+            sys.exit(2)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f'[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}', file=sys.stderr)
+    rccl_ranks = dist.get_world_size() if (world > 1 and backend == 'nccl') else (1 if world == 1 else 0)
     dev = torch.device('cuda', torch.cuda.current_device())
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     N = args.envs
@@ -468,7 +640,8 @@ def main():
                                    f'synthetic U(-1,1) actions resident in HBM, '
                                    f'{"HIP graph of %d steps" % G if hb.graph is not None else "per-step Python launches"}',
                        'envs_per_gpu': N, 'task_yaml': f'safe_control_gym_amd/configs/{args.task}.yaml',
-                       'parallelism': f'env-shard x{world}', 'finite_outputs': ok,
+                       'parallelism': f'env-shard x{world}', 'rccl_ranks': rccl_ranks, 'collective_backend': backend if world > 1 else None,
+                       'finite_outputs': ok,
                        'kernel_build': 'config-specialised' if hb.env.specialized else 'generic',
                        'timing': f'median of {repeats} timed repeats of the {done_steps}-step region' if repeats > 1 else 'one timed region',
                        'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))]},
@@ -503,11 +676,20 @@ def main():
     hb.env.close()
     if full and args.ppo_seeds > 0 and (world == 1 or backend == 'nccl' or os.environ.get('SCG_BENCH_PPO_GLOO')):
         try:
-            res = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds)
+            res = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds, envs=args.ppo_envs)
+            if world == 1 and args.ppo_envs != 16384:           # the small-batch point (round 2's leg) under the same protocol and target
+                res['envs_16384'] = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds, envs=16384, target=res['target_return'])
         except Exception as exc:                                    # noqa: BLE001
-            res = {'error': repr(exc)[:300]}
+            import traceback
+            res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
         if rank == 0:
             out['ppo'] = res
+    if rank == 0 and world == 1 and full and args.sac_seeds > 0:
+        try:
+            out['sac'] = sac_leg(torch, args.sac_seeds, args.sac_seconds)
+        except Exception as exc:                                    # noqa: BLE001
+            import traceback
+            out['sac'] = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.task, hb.cfg, hb.env_id, args.cpu_seconds, N)

@@ -1,0 +1,95 @@
+"""A vec env that REPLAYS recorded transitions — test infrastructure for the collector tests (tests/test_gpu_adversarial.py).
+
+It offers the slice of HipVecEnv's tensor interface the collectors in ppo.py / rarl.py / safe_explorer.py use (`spec`, `device`,
+`dtype`, `num_envs`, `reset_tensors`, `bind_outputs`, `step_tensors`, `set_adversary_control`) and, instead of simulating,
+copies step t of a recording made by the REFERENCE's collectors on the reference's envs (tests/golden/make_adversarial.py) into
+the bound outputs, while keeping what it was handed (actions, processed adversary actions) for the test to compare.  All
+copies are static-shape device ops, so a collection over it can be captured in a HIP graph like one over the simulator."""
+import types
+
+import torch
+
+from safe_control_gym_amd.vec_env import HipVecEnv, StepTensors
+
+
+class ReplayVecEnv:
+    policy_shape = None
+    auto_reset = True
+    seed_epoch = 0
+
+    def __init__(self, spec, device, obs0, next_obs, rew, done, trunc, term_obs):
+        f = dict(device=device, dtype=torch.float32)
+        self.spec, self.device, self.dtype = spec, torch.device(device), torch.float32
+        self.T, self.num_envs = next_obs.shape[0], next_obs.shape[1]
+        self.obs0 = torch.as_tensor(obs0, **f)
+        self.next_obs, self.rew, self.term_obs = (torch.as_tensor(x, **f) for x in (next_obs, rew, term_obs))
+        self.done = torch.as_tensor(done, device=device).to(torch.uint8)
+        self.flags = (torch.as_tensor(trunc, device=device).to(torch.uint8) & self.done)            # bit 0 = TimeLimit.truncated
+        N = self.num_envs
+        self.seen_act = torch.zeros(self.T, N, spec.nu, **f)
+        self.seen_adv = torch.zeros(self.T, N, max(1, spec.adversary_dim or 1), **f)
+        self._fin = torch.zeros(N, 4, **f)
+        self.out = StepTensors()
+        for k in StepTensors.__slots__:
+            setattr(self.out, k, None)
+        self.out.obs, self.out.reward = torch.zeros(N, spec.obs_dim, **f), torch.zeros(N, **f)
+        self.out.done, self.out.flags = torch.zeros(N, dtype=torch.uint8, device=device), torch.zeros(N, dtype=torch.uint8, device=device)
+        self.out.terminal_obs, self.out.fin_stats = torch.zeros(N, spec.obs_dim, **f), self._fin
+        self.t = 0
+        self._adv = None
+
+    # -- the HipVecEnv slice
+    _as_device = HipVecEnv._as_device
+    set_adversary_control = HipVecEnv.set_adversary_control          # the product's clip / scale / offset (benchmark_env.py:216-228)
+
+    def reset_tensors(self):
+        self.t = 0
+        return self.obs0
+
+    def bind_outputs(self, **tensors):
+        o = StepTensors()
+        for k in StepTensors.__slots__:
+            setattr(o, k, tensors[k] if k in tensors else getattr(self.out, k))
+        return o, None
+
+    def step_tensors(self, actions, adv_actions=None, out=None, c_out=None):
+        t = self.t % self.T
+        out = out or self.out
+        self.seen_act[t].copy_(actions)
+        if adv_actions is not None:
+            self.seen_adv[t].copy_(adv_actions)
+        out.obs.copy_(self.next_obs[t]); out.reward.copy_(self.rew[t]); out.done.copy_(self.done[t]); out.flags.copy_(self.flags[t])
+        if out.terminal_obs is not None:
+            out.terminal_obs.copy_(self.term_obs[t])
+        self.t += 1
+        return out
+
+    def close(self):
+        pass
+
+
+def forced_step(ac, rollout_obs, actions):
+    """`ac.step` replacement that returns RECORDED actions (the reference sampled them with its own torch stream) with this
+    network's value and log-prob for them.  The time index is recovered from which row of the rollout's obs buffer it is
+    handed, so warm-up calls and graph capture see consistent data."""
+    from safe_control_gym_amd.ppo import normal_log_prob
+    base, stride = rollout_obs.data_ptr(), rollout_obs[0].numel() * rollout_obs.element_size()
+
+    @torch.no_grad()
+    def step(obs, c=None):
+        t = (obs.data_ptr() - base) // stride
+        a = actions[t]
+        mean, logstd = ac.actor(obs, c)
+        return a, ac.critic(obs).squeeze(-1), normal_log_prob(mean, logstd, a)
+    return step
+
+
+def spec_for(task_overrides):
+    from safe_control_gym_amd.env_config import EnvSpec
+    from safe_control_gym_amd.registration import load_task
+    env_id, cfg = load_task('quadrotor_2D_track')
+    cfg.update(task_overrides)
+    return EnvSpec(env_id, cfg)
+
+
+__all__ = ['ReplayVecEnv', 'forced_step', 'spec_for', 'types']

@@ -43,10 +43,37 @@ def test_bench_two_ranks_on_one_gpu():
     assert 'cpu_baseline' not in r                  # rank 0 at N = 1 only
 
 
+def test_plain_python_bench_gpus_2_spawns_its_own_ranks_and_mismatches_fail():
+    """`python bench.py --gpus 2` (the shape of the driver's N = 1 command, no launcher): bench.py becomes the launcher
+    (torch.distributed.run, two ranks) instead of silently running one rank and printing n_gpus: 1; a launcher / --gpus mismatch
+    and an RCCL run with fewer GPUs than ranks exit non-zero."""
+    env = dict(os.environ, SCG_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    res = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '300', '--warmup', '50', '--no-secondary'], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['config']['parallelism'] == 'env-shard x2' and r['config']['collective_backend'] == 'gloo'
+    assert r['config']['rccl_ranks'] == 0                                           # gloo carried the collectives here, and the line says so
+    # launcher says 2 ranks, --gpus says 1
+    bad = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(_free_port()), 'bench.py', '--gpus', '1', '--steps', '50', '--warmup', '5', '--no-secondary'],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'WORLD_SIZE=2' in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
+    # RCCL needs one device per rank
+    if torch.cuda.device_count() < 2:
+        env2 = dict(env); env2.pop('SCG_BENCH_BACKEND')
+        bad = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '50', '--warmup', '5', '--no-secondary'], cwd=ROOT, env=env2,
+                             capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and 'need 2 GPUs' in bad.stderr
+
+
 def test_bench_ppo_leg_two_ranks_on_one_gpu():
     """The PPO wall-clock leg of bench.py with two ranks (what the driver's N > 1 runs execute over RCCL): env shards, one
     flat gradient all-reduce per minibatch, asynchronous evaluation per rank, rank 0's stop flag broadcast every iteration."""
-    out = _torchrun(['bench.py', '--gpus', '2', '--steps', '200', '--warmup', '50', '--ppo-seeds', '1', '--ppo-seconds', '3'],
+    out = _torchrun(['bench.py', '--gpus', '2', '--steps', '200', '--warmup', '50', '--ppo-seeds', '1', '--ppo-seconds', '3', '--ppo-envs', '16384'],
                     {'SCG_BENCH_BACKEND': 'gloo', 'SCG_BENCH_PPO_GLOO': '1'})
     lines = [l for l in out.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out
@@ -54,7 +81,8 @@ def test_bench_ppo_leg_two_ranks_on_one_gpu():
     assert r['n_gpus'] == 2 and 'secondary' not in r and 'cpu_baseline' not in r
     p = r['ppo']
     assert 'error' not in p, p
-    assert p['n_gpus'] == 2 and p['seeds'] == [1] and p['iterations'][0] >= 3
+    assert p['n_gpus'] == 2 and p['seeds'] == [1] and p['iterations'][0] >= 3 and p['envs_per_gpu'] == 16384
+    assert 200.0 < p['target_return'] < 250.0 and p['shipped_model_eval']['episodes'] == 1024    # the shipped model, randomised-init protocol
     assert p['best_eval_return'][0] > 0          # evaluations came back (the policy is far from trained in 3 s on a shared GPU)
 
 
