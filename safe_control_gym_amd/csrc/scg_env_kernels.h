@@ -633,7 +633,12 @@ struct PolicyArgs {
 };
 constexpr uint32_t RNG_CH_POLICY = 5;
 
-template <int SYS, bool DIST>
+// EPW = envs per wave.  64: lane = env, the wave runs the actor on its two 32-env column tiles one after the other.
+// 32 (shards of <= 32 768 envs, where 64 envs per wave would leave SIMDs idle: 16 384 envs = 256 waves on 1024 SIMDs):
+// lane (c, h) of both halves carries env c — the two halves simulate the same env redundantly (those lanes would idle
+// otherwise) and between them hold the two k-rows of the MFMA's B operand, so the actor is ONE tile per step with no lane
+// exchange; half 0 stores.  Twice the waves, each with half the matrix work per control step.
+template <int SYS, bool DIST, int EPW>
 __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<float> I, const PolicyArgs A) {
     using T = float;
     using Ops = EnvOps<SYS, T, DIST>;
@@ -653,11 +658,12 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
     }
     __syncthreads();
     const int N = I.num_envs;
-    const int i0 = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i0 < N;
-    const int i = live ? i0 : N - 1;                  // surplus lanes shadow the last env (they take part in the MFMAs, never store)
+    static_assert(EPW == 64 || EPW == 32, "envs per wave");
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const bool full_wave = (blockIdx.x * 256 + (threadIdx.x & ~63) + 64) <= N;
+    const int i0 = EPW == 64 ? blockIdx.x * 256 + threadIdx.x : (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
+    const bool live = i0 < N && (EPW == 64 || h == 0);
+    const int i = i0 < N ? i0 : N - 1;                // surplus lanes shadow the last env (they take part in the MFMAs, never store)
+    const bool full_wave = EPW == 64 && (blockIdx.x * 256 + (threadIdx.x & ~63) + 64) <= N;
     unsigned char* const s_wave = s_obs + (threadIdx.x >> 6) * (64 * NIN * (int)sizeof(T));
     typename Ops::E e;
     Ops::load_state(P, i, e);
@@ -701,10 +707,13 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
             const float a0 = d_row(q, 0) < NIN ? row[d_row(q, 0) < NIN ? d_row(q, 0) : 0] : 0.0f;
             const float a1 = d_row(q, 1) < NIN ? row[d_row(q, 1) < NIN ? d_row(q, 1) : 0] : 0.0f;
             xo[q] = h ? a1 : a0;                                        // my own env's rows row(q, h)
-            xr[q] = __shfl_xor(h ? a0 : a1, 32, 64);                    // the partner env's rows row(q, h)
+            if constexpr (EPW == 64) xr[q] = __shfl_xor(h ? a0 : a1, 32, 64);      // the partner env's rows row(q, h)
         }
         float mean[NU];
-        {
+        if constexpr (EPW == 32) {                                      // both halves hold env c: xo IS the B operand
+            f32x16 h1[L::NT], h2[L::NT];
+            mlp_forward_tile<NIN, HID, NU, ACT, 16>(lds, xo, h1, h2, mean, lane);
+        } else {
             float x[L1Q], out[NU];
             f32x16 h1[L::NT], h2[L::NT];
 #pragma unroll

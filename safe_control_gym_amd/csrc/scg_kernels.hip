@@ -6,6 +6,7 @@
 //                                                          -> libscg_spec_<hash>.so: one task config baked in as
 //                                                             compile-time constants (see emit_spec_source below)
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -772,9 +773,21 @@ extern "C" int scg_rollout_policy(scg_env* env, const scg_policy* pol, int k_ste
     const InstParams<float> I = inst_of<float>(env);
     constexpr int nobs = scg_make_spec_cfg<float>().nobs;
     const size_t bytes = MlpLds<nobs, SCG_POLICY_H, Dims<S>::NU, 16>::END * sizeof(float) + 4 * 64 * nobs * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    const int grid = (env->cfg.num_envs + 255) / 256;
-    rollout_policy_kernel<S, DD><<<dim3(grid), dim3(256), bytes, (hipStream_t)stream>>>(I, A);
+    // envs per wave: 32 while that still fits one wave per SIMD (4 x 256 CUs), else 64 (scg_env_kernels.h).  SCG_ROLLOUT_EPW = 32 | 64
+    // overrides (tests run both geometries on small batches; results do not depend on it: Philox streams are per env).
+    int epw = env->cfg.num_envs <= 32768 ? 32 : 64;
+    if (const char* o = getenv("SCG_ROLLOUT_EPW")) { if (atoi(o) == 32 || atoi(o) == 64) epw = atoi(o); }
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr = true;
+    }
+    if (epw == 64) {
+        rollout_policy_kernel<S, DD, 64><<<dim3((env->cfg.num_envs + 255) / 256), dim3(256), bytes, (hipStream_t)stream>>>(I, A);
+    } else {
+        rollout_policy_kernel<S, DD, 32><<<dim3((env->cfg.num_envs + 127) / 128), dim3(256), bytes, (hipStream_t)stream>>>(I, A);
+    }
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 #else

@@ -64,7 +64,7 @@ struct MlpWeights {
     const float* W3; const float* b3;      // [NOUT][H], [NOUT]
 };
 
-// LDS image of one MLP (float words).  NIN <= 32, H multiple of 32, NOUT <= 4.
+// LDS image of one MLP (float words).  NIN <= 32, H multiple of 32, NOUT <= 8 (SAC's actor head: mean | log-std).
 // SS: lane stride (words) of the layer-2 image — 20 (= 16 + 4: conflict-free b128 reads, 2-way backward gather) for the
 // learner, 16 for forward-only users that must fit a simulator's own LDS next to it (4-way conflicts on 4 reads per
 // 16 MFMAs: invisible).
@@ -81,7 +81,7 @@ struct MlpLds {
     static constexpr int B2 = B1 + H;
     static constexpr int B3 = B2 + H;
     static constexpr int END = (B3 + NOUT + 3) / 4 * 4;         // 16-byte granules
-    static_assert(NIN <= 32 && H % 32 == 0 && NOUT <= 4, "unsupported MLP shape");
+    static_assert(NIN <= 32 && H % 32 == 0 && NOUT <= 8, "unsupported MLP shape");
 };
 
 // Cooperative fill of the LDS image from torch-layout parameters (all NTHR threads of the workgroup; caller barriers after).
@@ -142,9 +142,17 @@ __device__ __forceinline__ void load_w2_tile(const float* lds, int rho, int tau,
     }
 }
 
+enum { MLP_ACT_NONE = 3 };      // (second hidden layer without activation: the reference's SAC actor trunk, sac_utils.py:190-200 over
+                                //  neural_networks.py:50-54 — MLP applies no activation after ITS last layer)
+template <>
+__device__ __forceinline__ float mlp_act<MLP_ACT_NONE>(float x) { return x; }
+template <>
+__device__ __forceinline__ float mlp_dact<MLP_ACT_NONE>(float) { return 1.0f; }
+
 // Forward pass of one 32-sample column tile.  x[q] (q < L1Q): input feature row(q, h) of this lane's sample.
-// Leaves h1, h2 (activations, D layout: [tile][q]) and out[NOUT] (identical in both lane halves).
-template <int NIN, int H, int NOUT, int ACT, int SS = 20>
+// Leaves h1, h2 (activations, D layout: [tile][q]) and out[NOUT] (identical in both lane halves).  ACT2: activation of
+// the second hidden layer when it differs from the first's.
+template <int NIN, int H, int NOUT, int ACT, int SS = 20, int ACT2 = ACT>
 __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* x, f32x16* h1, f32x16* h2, float* out, int lane) {
     using L = MlpLds<NIN, H, NOUT, SS>;
     constexpr int NT = L::NT;
@@ -183,7 +191,7 @@ __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* 
             __builtin_amdgcn_sched_barrier(0);                  // keep the scheduler from hoisting every tile's operand loads
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT>(acc[q]);
+        for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT2>(acc[q]);
         h2[rho] = acc;
     }
     // ---- output layer on the vector unit: each lane holds half of its sample's features

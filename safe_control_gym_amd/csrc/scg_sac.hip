@@ -1,0 +1,685 @@
+// scg_sac.hip — ONE gradient step of the reference's SACAgent.update (controllers/sac/sac_utils.py:110-170) as a fixed
+// sequence of MI355X kernels, compiled per network shape like scg_learn.hip:
+//     hipcc -DSCG_S_NOBS=<obs_dim> -DSCG_S_H=<hidden> -DSCG_S_NU=<act_dim> -DSCG_S_ACT=<0 tanh|1 relu|2 leaky>
+//     -> libscg_sac_<nobs>_<h>_<nu>_<act>.so       (C ABI: include/scg_sac.h)
+//
+// Why a sequence and not one kernel: the step touches five networks (actor, q1, q2, q1', q2') whose MFMA operand images
+// are ~100 KB of LDS each — one per workgroup at a time — and the phases depend on each other through tiny per-sample
+// vectors (action, log-prob, q, dq/da: a few floats per row), which cross global memory between launches.  Every kernel
+// follows scg_learn.hip's scheme: the workgroup packs ONE network into LDS (scg_mlp.h), each wave walks 32-sample column
+// tiles with the activations in registers, all matrix products on v_mfma_f32_32x32x2_f32 (exact float32).
+//   sample_kernel        batch rows ~ U[0, ring size)                                     SACBuffer.sample  (:399-413)
+//   actor_fwd_kernel     a, log pi (tanh-Gaussian, reparameterised)                       MLPActor.forward  (:185-222)
+//   q_kernel<1>          q_y(obs, a) and dq_y/da for y = 1, 2 (forward + data gradient)   compute_policy_loss (:110-127)
+//   actor_grad_kernel    d mean(alpha log pi - min q)/d(actor), forward recomputed, weight gradients
+//   adam_kernel          actor (+ log_alpha)
+//   actor_fwd_kernel     a', log pi' at next_obs with the UPDATED actor                   compute_q_loss    (:129-141)
+//   q_kernel<0>          target networks at (next_obs, a')
+//   q_kernel<2>          d[mean (q_y - target)^2]/d(q_y), y = 1, 2
+//   adam_kernel          critics + Polyak of every parameter into the target copy         (:163-168)
+// Gradient reduction: every WAVE owns one partial gradient vector in global memory (a wave usually owns one tile: plain
+// stores), reduce_kernel sums the partials in a fixed order — no atomics, bitwise reproducible.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/scg_sac.h"
+#include "scg_mlp.h"
+#include "scg_rng.h"
+
+#ifndef SCG_S_NOBS
+#error "compile with -DSCG_S_NOBS= -DSCG_S_H= -DSCG_S_NU= -DSCG_S_ACT="
+#endif
+
+using namespace scg;
+
+constexpr int NOBS = SCG_S_NOBS, HID = SCG_S_H, NU = SCG_S_NU, ACT = SCG_S_ACT;
+constexpr int NQ = NOBS + NU;                 // Q-network input: (obs, act)
+constexpr int NA = 2 * NU;                    // actor head: mu | log_std
+constexpr int NT = HID / 32;
+constexpr int WAVES = 4;
+static_assert(NU >= 1 && NU <= 4 && NQ < 32 && HID % 32 == 0 && HID <= 128, "unsupported SAC shape");
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+extern "C" const char* scg_sac_last_error(void) { return g_err.c_str(); }
+extern "C" void scg_sac_shape(int32_t* nobs, int32_t* hidden, int32_t* nu, int32_t* act) { *nobs = NOBS; *hidden = HID; *nu = NU; *act = ACT; }
+#ifndef SCG_SRC_HASH
+#define SCG_SRC_HASH 0ULL
+#endif
+#define SCG_STR2(x) #x
+#define SCG_STR(x) SCG_STR2(x)
+extern "C" const char* scg_sac_source_hash_tag(void) { return "SCG_SRC_HASH:" SCG_STR(SCG_SRC_HASH); }
+#define HIP_TRY(e) do { hipError_t _e = (e); if (_e != hipSuccess) return fail(-2, std::string(#e) + ": " + hipGetErrorString(_e)); } while (0)
+
+__host__ __device__ static inline MlpWeights weights_of(const float* p, const scg_mlp_layout& L) {
+    return MlpWeights{p + L.W1, p + L.b1, p + L.W2, p + L.b2, p + L.W3, p + L.b3};
+}
+
+constexpr float LOG_SQRT_2PI = 0.91893853320467274f, LOG2F = 0.69314718055994531f;
+
+// ------------------------------------------------------------------ partial gradient vector of one wave
+template <int NIN, int NOUT>
+struct Part {
+    static constexpr int DW1 = 0;                           // [NIN + 1][H]: column NIN is db1
+    static constexpr int DB2 = DW1 + (NIN + 1) * HID;
+    static constexpr int DW3 = DB2 + HID;                   // [NOUT][H]
+    static constexpr int DB3 = DW3 + NOUT * HID;            // [8]
+    static constexpr int STAT = DB3 + 8;                    // [4]
+    static constexpr int DW2 = STAT + 4;                    // [NT * NT tiles][64 lanes][16]
+    static constexpr int END = DW2 + HID * HID;
+};
+constexpr int PSTRIDE = (Part<NOBS, NA>::END > Part<NQ, 1>::END ? Part<NOBS, NA>::END : Part<NQ, 1>::END);
+
+__device__ __forceinline__ void padd(float* p, float v, bool first) { *p = first ? v : *p + v; }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// x[q] = input feature row(q, h) of one sample, the input being [a [NA_] | b [NB_]] (rows >= NA_ + NB_ are zero)
+template <int L1Q, int NA_, int NB_>
+__device__ __forceinline__ void load_x2(const float* __restrict__ a, const float* __restrict__ b, int h, float* x) {
+#pragma unroll
+    for (int q = 0; q < L1Q; ++q) {
+        const int f0 = d_row(q, 0), f1 = d_row(q, 1);           // compile-time after unrolling
+        const float v0 = f0 < NA_ ? a[f0 < NA_ ? f0 : 0] : (f0 < NA_ + NB_ ? b[f0 < NA_ + NB_ && f0 >= NA_ ? f0 - NA_ : 0] : 0.0f);
+        const float v1 = f1 < NA_ ? a[f1 < NA_ ? f1 : 0] : (f1 < NA_ + NB_ ? b[f1 < NA_ + NB_ && f1 >= NA_ ? f1 - NA_ : 0] : 0.0f);
+        x[q] = h ? v1 : v0;
+    }
+}
+
+// Backward pass of one 32-sample tile of an  NIN -> H (ACT) -> H (ACT2) -> NOUT  network whose forward left h1, h2 in
+// registers.  dout[o] = d loss / d out[o] of this lane's sample (identical in both lane halves).
+//   WGRAD: weight / bias gradients into the wave's partial vector P (first: plain stores, else read-add-write);  DIN: din[j] = d loss / d input[NIN - NU + j] (the action columns of a Q network).
+// Scheme and layouts as scg_learn.hip::grad_net (dW3 from transposed h2 tiles on the vector unit, dz2 in place, the layer-2
+// data gradient gathered from the forward weight image, dW1 | db1 and dW2 as MFMA products over sample pairs).
+template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN>
+__device__ __forceinline__ void backward_tile(const float* lds, float* xs, float* dout_l, float* scr, f32x16* h1, f32x16* h2,
+                                              const float* dout, int lane, float* P, bool first, float* din) {
+    using L = MlpLds<NIN, HID, NOUT>;
+    using G = Part<NIN, NOUT>;
+    constexpr int NINP = (NIN + 3) / 4 * 4;
+    const int c = lane & 31, h = lane >> 5;
+    if constexpr (WGRAD) {
+        if (h == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dout_l[o * 32 + c] = dout[o];
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {                                // db3: sum over the tile's 32 samples
+            float v = dout[o];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) padd(P + G::DB3 + o, v, first);
+        }
+        wave_sync();
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {                            // dW3[o][f] = sum_s h2[f][s] dout[o][s]
+            float t[16];
+            tile_transpose(scr, h2[tau], t, lane);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + 2 * sp + h], acc);
+                acc += __shfl_xor(acc, 32, 64);
+                if (h == 0) padd(P + G::DW3 + o * HID + 32 * tau + c, acc, first);
+            }
+        }
+    }
+    // dz2 = (W3^T dout) * act2'(h2), in place
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + L::W3 + o * HID + 32 * tau + 8 * g + 4 * h);
+                dh[0] = __builtin_fmaf(wv.x, dout[o], dh[0]); dh[1] = __builtin_fmaf(wv.y, dout[o], dh[1]);
+                dh[2] = __builtin_fmaf(wv.z, dout[o], dh[2]); dh[3] = __builtin_fmaf(wv.w, dout[o], dh[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h2[tau][4 * g + r] = dh[r] * mlp_dact<ACT2>(h2[tau][4 * g + r]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIN) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) din[j] = 0.0f;
+    }
+    {
+        const int ip = lane & 31;
+        const int qi = 4 * (ip >> 3) + (ip & 3), hi2 = (ip >> 2) & 1;
+#pragma unroll
+        for (int tp = 0; tp < NT; ++tp) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+            for (int rp = 0; rp < NT; ++rp) {
+                const float* base = lds + L::W2F + (rp * NT + tp) * L::TILE2 + 32 * hi2 * L::S + qi;
+                float a[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = base[d_row(q, h) * L::S];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = mfma32(a[q], h2[rp][q], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[tp][q]);        // dz1 tile
+            if constexpr (DIN) {
+                // d loss / d input column rr = sum_f W1[f][rr] dz1[f]; this lane holds features 32 tp + row(q, h)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    const int rr = NIN - NU + j;
+                    const int qj = 4 * (rr >> 3) + (rr & 3), hj = (rr >> 2) & 1;
+                    float s = din[j];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) s = __builtin_fmaf(lds[L::W1F + (tp * L::L1Q + qj) * 64 + d_row(q, h) + 32 * hj], acc[q], s);
+                    din[j] = s;
+                }
+            }
+            if constexpr (WGRAD) {
+                float t[16], xb[16];
+                tile_transpose(scr, acc, t, lane);
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp) xb[sp] = c < NIN ? xs[(2 * sp + h) * NINP + (c < NIN ? c : 0)] : (c == NIN ? 1.0f : 0.0f);
+                f32x16 g1;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp) g1 = mfma32(t[sp], xb[sp], g1);
+                if (c <= NIN) {
+                    float* const dst = P + G::DW1 + c * HID + 32 * tp + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
+                        if (!first) v += *reinterpret_cast<const f32x4*>(dst + 8 * g);
+                        *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (DIN) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) din[j] += __shfl_xor(din[j], 32, 64);
+    }
+    if constexpr (WGRAD) {
+#pragma unroll
+        for (int rho = 0; rho < NT; ++rho) {
+            float b[16];
+            tile_transpose(scr, h2[rho], b, lane);                      // dz2[out 32 rho + c][sample 2 s' + h]
+            float sb = 0.0f;
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp) sb += b[sp];
+            sb += __shfl_xor(sb, 32, 64);
+            if (h == 0) padd(P + G::DB2 + 32 * rho + c, sb, first);
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) {
+                float a[16];
+                tile_transpose(scr, h1[tau], a, lane);
+                // dW2 tile (in 32 tau.., out 32 rho..) of THIS sample tile straight into the wave's partial vector, in the
+                // accumulator's own [tile][lane][q] order (a wave usually owns one sample tile; keeping 16 H^2 / 1024 accumulator
+                // registers across tiles as scg_learn.hip does spilled here: the actor head is 8 outputs wide)
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+                for (int sp = 0; sp < 16; ++sp) acc = mfma32(a[sp], b[sp], acc);
+                float* const p = P + G::DW2 + ((tau * NT + rho) * 64 + lane) * 16;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    if (!first) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
+                    *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// sample cache for the dW1 product: xs[c][feature] of this wave's tile
+template <int L1Q, int NINP>
+__device__ __forceinline__ void cache_x(float* xs, const float* x, int c, int h) {
+#pragma unroll
+    for (int g = 0; g < L1Q / 4; ++g) {
+        const int r0 = 8 * g + 4 * h;
+        if (r0 < NINP) *reinterpret_cast<f32x4*>(xs + c * NINP + r0) = (f32x4){x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+    }
+}
+
+// ------------------------------------------------------------------ kernels
+struct Common {
+    const int32_t* idx; int batch; int n_part;
+    const float* obs; const float* act; const float* rew; const float* next_obs; const float* mask;
+    float low[4], high[4];
+    const float* log_alpha;                     // device scalar (d_params + n_params)
+    float gamma;
+    uint32_t k0, k1; const uint32_t* counter;
+};
+
+__global__ __launch_bounds__(256) void sample_kernel(int32_t* __restrict__ idx, const int32_t* __restrict__ ring_size, int batch,
+                                                      const int32_t* __restrict__ idx_in, uint32_t k0, uint32_t k1,
+                                                      const uint32_t* __restrict__ counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    if (idx_in) { idx[i] = idx_in[i]; return; }
+    const uint32_t n = (uint32_t)max(*ring_size, 1);
+    const U4 w = philox4x32_10(U4{*counter, (uint32_t)i, 0u, 0x5ac0u}, k0, k1);
+    idx[i] = (int32_t)int_below(w.x, n);
+}
+
+// N(0,1) draws for one batch row: Box-Muller on a Philox block (stream: 1 policy-loss action, 2 target action)
+__device__ __forceinline__ void normal4(uint32_t cnt, uint32_t row, uint32_t stream, uint32_t k0, uint32_t k1, float* n) {
+    const U4 w = philox4x32_10(U4{cnt, row, stream, 0x5ac1u}, k0, k1);
+    const float r0 = sqrtf(-2.0f * __logf(u01<float>(w.x))), r1 = sqrtf(-2.0f * __logf(u01<float>(w.z)));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u01<float>(w.y), &s0, &c0);
+    __sincosf(6.283185307179586f * u01<float>(w.w), &s1, &c1);
+    n[0] = r0 * c0; n[1] = r0 * s0; n[2] = r1 * c1; n[3] = r1 * s1;
+}
+
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// tanh-Gaussian head (sac_utils.py:203-222 / sac.py::MLPActor.forward): out = mu | log_std
+__device__ __forceinline__ void squash(const float* out, const float* eps, const float* low, const float* high, float* u, float* th, float* sig,
+                                       float* a, float& logp) {
+    logp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const float ls = fminf(fmaxf(out[NU + j], -20.0f), 2.0f);
+        sig[j] = expf(ls);
+        u[j] = __builtin_fmaf(sig[j], eps[j], out[j]);
+        th[j] = tanhf(u[j]);
+        a[j] = low[j] + 0.5f * (th[j] + 1.0f) * (high[j] - low[j]);
+        logp += -0.5f * eps[j] * eps[j] - ls - LOG_SQRT_2PI - 2.0f * (LOG2F - u[j] - softplusf(-2.0f * u[j]));
+    }
+}
+
+// actor forward on obs rows idx (use_next = 0) or next_obs rows (1): eps, action, log pi per batch row
+__global__ __launch_bounds__(64 * WAVES, 1) void actor_fwd_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
+                                                                   int use_next, const float* __restrict__ eps_in, uint32_t stream,
+                                                                   float* __restrict__ eps_out, float* __restrict__ a_out,
+                                                                   float* __restrict__ logp_out) {
+    using L = MlpLds<NOBS, HID, NA>;
+    extern __shared__ __align__(16) float lds[];
+    mlp_fill_lds<NOBS, HID, NA>(lds, weights_of(params, lay), threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32;
+    const float* src = use_next ? Cm.next_obs : Cm.obs;
+    const uint32_t cnt = *Cm.counter;
+    if (wid >= Cm.n_part) return;
+    for (int tile = wid; tile < n_tiles; tile += Cm.n_part) {
+        const int r = tile * 32 + c, s = Cm.idx[r];
+        float x[L::L1Q];
+        load_x2<L::L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
+        f32x16 h1[NT], h2[NT];
+        float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp;
+        mlp_forward_tile<NOBS, HID, NA, ACT, 20, MLP_ACT_NONE>(lds, x, h1, h2, out, lane);
+        if (eps_in) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r * NU + j];
+        } else {
+            normal4(cnt, (uint32_t)r, stream, Cm.k0, Cm.k1, eps);
+        }
+        squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { eps_out[(size_t)r * NU + j] = eps[j]; a_out[(size_t)r * NU + j] = a[j]; }
+            logp_out[r] = logp;
+        }
+    }
+}
+
+// deterministic action of a batch (evaluation): a = low + 0.5 (tanh(mu) + 1)(high - low)
+__global__ __launch_bounds__(64 * WAVES, 1) void actor_act_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
+                                                                   const float* __restrict__ obs, int m, float4 low, float4 high,
+                                                                   float* __restrict__ a_out) {
+    using L = MlpLds<NOBS, HID, NA>;
+    extern __shared__ __align__(16) float lds[];
+    mlp_fill_lds<NOBS, HID, NA>(lds, weights_of(params, lay), threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const float lo[4] = {low.x, low.y, low.z, low.w}, hi[4] = {high.x, high.y, high.z, high.w};
+    const int n_tiles = (m + 31) / 32;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        int s = tile * 32 + c;
+        const bool live = s < m;
+        s = live ? s : m - 1;
+        float x[L::L1Q];
+        load_x2<L::L1Q, NOBS, 0>(obs + (size_t)s * NOBS, nullptr, h, x);
+        f32x16 h1[NT], h2[NT];
+        float out[NA];
+        mlp_forward_tile<NOBS, HID, NA, ACT, 20, MLP_ACT_NONE>(lds, x, h1, h2, out, lane);
+        if (live && h == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) a_out[(size_t)s * NU + j] = lo[j] + 0.5f * (tanhf(out[j]) + 1.0f) * (hi[j] - lo[j]);
+        }
+    }
+}
+
+// Q networks, blockIdx.y = which (q1 / q2).
+//   MODE 0: target networks at (next_obs[idx], a_in[row])                 -> q_out[y][row]
+//   MODE 1: online networks at (obs[idx], a_in[row]), data gradient       -> q_out[y][row], dqda[y][row][NU]
+//   MODE 2: online networks at (obs[idx], act[idx]): d mean (q - y)^2 / d(theta_y) into the waves' partials,
+//           y = rew + gamma mask (min(qt1, qt2) - alpha logp_next)
+template <int MODE>
+__global__ __launch_bounds__(64 * WAVES, 1) void q_kernel(const float* __restrict__ params, const scg_mlp_layout lay1, const scg_mlp_layout lay2,
+                                                           const Common Cm, const float* __restrict__ a_in, const float* __restrict__ qt,
+                                                           const float* __restrict__ logp_next, float* __restrict__ q_out,
+                                                           float* __restrict__ dqda, float* __restrict__ partials) {
+    using L = MlpLds<NQ, HID, 1>;
+    using G = Part<NQ, 1>;
+    constexpr int NINP = (NQ + 3) / 4 * 4;
+    extern __shared__ __align__(16) float lds[];
+    const int y = blockIdx.y;
+    mlp_fill_lds<NQ, HID, 1>(lds, weights_of(params, y ? lay2 : lay1), threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32, B = Cm.batch;
+    float* const wl = lds + L::END + wave * (32 * NINP + 32 + 32 * 33);
+    float* const xs = wl; float* const dout_l = xs + 32 * NINP; float* const scr = dout_l + 32;
+    float* const P = partials ? partials + ((size_t)y * Cm.n_part + wid) * PSTRIDE : nullptr;
+    const float alpha = MODE == 2 ? expf(*Cm.log_alpha) : 0.0f;
+    const float inv_b = 1.0f / (float)B;
+    float st = 0.0f;
+    bool first = true;
+    if (wid >= Cm.n_part) return;
+    for (int tile = wid; tile < n_tiles; tile += Cm.n_part) {
+        const int r = tile * 32 + c, s = Cm.idx[r];
+        float x[L::L1Q];
+        if constexpr (MODE == 0) load_x2<L::L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+        else if constexpr (MODE == 1) load_x2<L::L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+        else load_x2<L::L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
+        f32x16 h1[NT], h2[NT];
+        float out[1];
+        mlp_forward_tile<NQ, HID, 1, ACT>(lds, x, h1, h2, out, lane);
+        if constexpr (MODE == 0) {
+            if (h == 0) q_out[(size_t)y * B + r] = out[0];
+        } else if constexpr (MODE == 1) {
+            const float dout[1] = {1.0f};
+            float din[NU];
+            backward_tile<NQ, 1, ACT, false, true>(lds, xs, dout_l, scr, h1, h2, dout, lane, nullptr, true, din);
+            if (h == 0) {
+                q_out[(size_t)y * B + r] = out[0];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) dqda[((size_t)y * B + r) * NU + j] = din[j];
+            }
+        } else {
+            cache_x<L::L1Q, NINP>(xs, x, c, h);
+            const float target = Cm.rew[s] + Cm.gamma * Cm.mask[s] * (fminf(qt[r], qt[B + r]) - alpha * logp_next[r]);
+            const float e = out[0] - target;
+            const float dout[1] = {2.0f * e * inv_b};
+            if (h == 0) st += e * e * inv_b;
+            backward_tile<NQ, 1, ACT, true, false>(lds, xs, dout_l, scr, h1, h2, dout, lane, P, first, nullptr);
+            first = false;
+        }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) st += __shfl_xor(st, m, 64);
+        if (lane == 0) { P[G::STAT] = st; P[G::STAT + 1] = 0.0f; }
+    }
+}
+
+// actor gradient of policy_loss = mean(alpha log pi - min(q1, q2)(obs, a)): forward recomputed with the stored noise
+__global__ __launch_bounds__(64 * WAVES, 1) void actor_grad_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
+                                                                    const float* __restrict__ eps_all, const float* __restrict__ qpi,
+                                                                    const float* __restrict__ dqda, float* __restrict__ partials) {
+    using L = MlpLds<NOBS, HID, NA>;
+    using G = Part<NOBS, NA>;
+    constexpr int NINP = (NOBS + 3) / 4 * 4;
+    extern __shared__ __align__(16) float lds[];
+    mlp_fill_lds<NOBS, HID, NA>(lds, weights_of(params, lay), threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32, B = Cm.batch;
+    float* const wl = lds + L::END + wave * (32 * NINP + NA * 32 + 32 * 33);
+    float* const xs = wl; float* const dout_l = xs + 32 * NINP; float* const scr = dout_l + NA * 32;
+    if (wid >= Cm.n_part) return;
+    float* const P = partials + (size_t)wid * PSTRIDE;
+    const float alpha = expf(*Cm.log_alpha), inv_b = 1.0f / (float)B;
+    float st_loss = 0.0f, st_logp = 0.0f;
+    bool first = true;
+    for (int tile = wid; tile < n_tiles; tile += Cm.n_part) {
+        const int r = tile * 32 + c, s = Cm.idx[r];
+        float x[L::L1Q];
+        load_x2<L::L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x);
+        cache_x<L::L1Q, NINP>(xs, x, c, h);
+        f32x16 h1[NT], h2[NT];
+        float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp, dout[NA];
+        mlp_forward_tile<NOBS, HID, NA, ACT, 20, MLP_ACT_NONE>(lds, x, h1, h2, out, lane);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) eps[j] = eps_all[(size_t)r * NU + j];
+        squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
+        const float q1 = qpi[r], q2 = qpi[B + r];
+        const int ysel = q2 < q1 ? 1 : 0;                                          // torch.min: gradient to the smaller (q1 on a tie)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const float dq = dqda[((size_t)ysel * B + r) * NU + j];
+            // d/du [alpha log pi - q]:  d log pi / du = 2 tanh(u);  da/du = 0.5 (high - low)(1 - tanh^2 u)
+            const float du = inv_b * (alpha * 2.0f * th[j] - dq * 0.5f * (Cm.high[j] - Cm.low[j]) * (1.0f - th[j] * th[j]));
+            const float raw = out[NU + j];
+            const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;      // torch.clamp's gradient
+            dout[j] = du;                                                           // d/d mu
+            dout[NU + j] = pass * (du * sig[j] * eps[j] - inv_b * alpha);           // d/d log_std: u = mu + exp(ls) eps;  -ls in log pi
+        }
+        if (h == 0) { st_loss += (alpha * logp - fminf(q1, q2)) * inv_b; st_logp += logp * inv_b; }
+        backward_tile<NOBS, NA, MLP_ACT_NONE, true, false>(lds, xs, dout_l, scr, h1, h2, dout, lane, P, first, nullptr);
+        first = false;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { st_loss += __shfl_xor(st_loss, m, 64); st_logp += __shfl_xor(st_logp, m, 64); }
+    if (lane == 0) { P[G::STAT] = st_loss; P[G::STAT + 1] = st_logp; }
+}
+
+// Sum of the waves' partials -> flat gradient (torch parameter order); blockIdx.y = network of the launch.
+template <int NIN, int NOUT>
+__device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay) {
+    using G = Part<NIN, NOUT>;
+    if (k < G::DB2) { const int in = k / HID, o = k % HID; return in < NIN ? lay.W1 + o * NIN + in : lay.b1 + o; }
+    if (k < G::DW3) return lay.b2 + (k - G::DB2);
+    if (k < G::DB3) return lay.W3 + (k - G::DW3);
+    if (k < G::STAT) return (k - G::DB3) < NOUT ? lay.b3 + (k - G::DB3) : -1;
+    if (k < G::DW2) return -2 - (k - G::STAT);
+    const int p = k - G::DW2;
+    const int q = p & 15, lane = (p >> 4) & 63, tr = p >> 10;
+    const int tau = tr / NT, rho = tr % NT;
+    return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
+}
+
+struct ReduceArgs {
+    const float* partials; int n_part; scg_mlp_layout lay[2]; float* grad;
+    float* stat_out;            // [2 * gridDim.y]: STAT + 0, STAT + 1 of each network
+};
+template <int NIN, int NOUT>
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
+    __shared__ float part[4][64];
+    const int net = blockIdx.y;
+    const int kl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    constexpr int words = Part<NIN, NOUT>::END;
+    float s = 0.0f;
+    if (k < words) {
+#pragma unroll 8
+        for (int g = grp; g < R.n_part; g += 4) s += R.partials[((size_t)net * R.n_part + g) * PSTRIDE + k];
+    }
+    part[grp][kl] = s;
+    __syncthreads();
+    if (grp != 0 || k >= words) return;
+    s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
+    const int d = dest_of<NIN, NOUT>(k, R.lay[net]);
+    if (d >= 0) R.grad[d] = s;
+    else if (d == -2) R.stat_out[2 * net] = s;
+    else if (d == -3) R.stat_out[2 * net + 1] = s;
+}
+
+// torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8) on elements [lo, hi) of the flat vectors; optionally the temperature
+// (element n_params, gradient from the mean log pi) and the Polyak update of the target copy over [0, n_polyak).
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; int lo, hi; float lr; const float* steps; int step_slot;
+    int alpha_on; int n_params; float lr_alpha; float target_entropy; const float* actor_stat;
+    float* target; int n_polyak; float tau;
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float t) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+    p -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
+}
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // one element per thread: Adam (if in [lo, hi)), then its soft update
+    if (i >= A.lo && i < A.hi) adam_one(A.p[i], A.g[i], A.m[i], A.v[i], A.lr, A.steps[A.step_slot] + 1.0f);
+    if (A.alpha_on && i == 0) {
+        // entropy_loss = -mean(log_alpha (log pi + target_entropy)) (sac_utils.py:124-126): d/d log_alpha = -(mean log pi + H*)
+        const int k = A.n_params;
+        adam_one(A.p[k], -(A.actor_stat[1] + A.target_entropy), A.m[k], A.v[k], A.lr_alpha, A.steps[2] + 1.0f);
+    }
+    if (A.target && i < A.n_polyak) A.target[i] = (1.0f - A.tau) * A.target[i] + A.tau * A.p[i];
+}
+
+struct FinishArgs {
+    float* steps; uint32_t* counter; float* stats; float* stats_acc; const float* actor_stat; const float* q_stat;
+    const float* log_alpha_before; int alpha_on; float target_entropy;
+};
+__global__ void finish_kernel(const FinishArgs F) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    F.steps[0] += 1.0f; F.steps[1] += 1.0f;
+    if (F.alpha_on) F.steps[2] += 1.0f;
+    *F.counter += 1u;
+    const float pl = F.actor_stat[0], ml = F.actor_stat[1];
+    const float cl = F.q_stat[0] + F.q_stat[2];
+    const float el = F.alpha_on ? -(*F.log_alpha_before) * (ml + F.target_entropy) : 0.0f;
+    F.stats[0] = pl; F.stats[1] = cl; F.stats[2] = el; F.stats[3] = ml;
+    if (F.stats_acc) { F.stats_acc[0] += pl; F.stats_acc[1] += cl; F.stats_acc[2] += el; F.stats_acc[3] += ml; }
+}
+
+// ------------------------------------------------------------------ host side
+struct Ws {      // workspace carve-up (floats)
+    size_t idx, eps, a_pi, logp, eps2, a_next, logp_next, qpi, dqda, qt, stat, la_before, partials, total;
+};
+static Ws carve(int B, int n_part) {
+    Ws w; size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 63) / 64 * 64; return at; };
+    w.idx = take(B); w.eps = take((size_t)B * NU); w.a_pi = take((size_t)B * NU); w.logp = take(B);
+    w.eps2 = take((size_t)B * NU); w.a_next = take((size_t)B * NU); w.logp_next = take(B);
+    w.qpi = take(2 * (size_t)B); w.dqda = take(2 * (size_t)B * NU); w.qt = take(2 * (size_t)B);
+    w.stat = take(8); w.la_before = take(1);
+    w.partials = take(2 * (size_t)n_part * PSTRIDE);
+    w.total = o;
+    return w;
+}
+static int n_part_of(int batch) { const int t = batch / 32; return t < 512 ? t : 512; }
+
+extern "C" size_t scg_sac_workspace_bytes(int batch) {
+    if (batch <= 0 || batch % 32) return 0;
+    return carve(batch, n_part_of(batch)).total * sizeof(float);
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+static size_t lds_actor_bytes() { return (MlpLds<NOBS, HID, NA>::END + WAVES * (32 * ((NOBS + 3) / 4 * 4) + NA * 32 + 32 * 33)) * sizeof(float); }
+static size_t lds_q_bytes() { return (MlpLds<NQ, HID, 1>::END + WAVES * (32 * ((NQ + 3) / 4 * 4) + 32 + 32 * 33)) * sizeof(float); }
+
+// One-time kernel attributes (dynamic LDS above 64 KB).  Call once before capturing scg_sac_update into a HIP graph: the
+// attribute calls are not stream operations.  scg_sac_update calls it itself otherwise.
+extern "C" int scg_sac_prepare(void) {
+    static bool done = false;
+    if (done) return 0;
+    const size_t lds_a = lds_actor_bytes(), lds_q = lds_q_bytes();
+    if (lds_a > 160 * 1024 || lds_q > 160 * 1024) return fail(-1, "scg_sac: network image does not fit the LDS");
+    if (set_lds(actor_fwd_kernel, lds_a) || set_lds(actor_grad_kernel, lds_a) || set_lds(q_kernel<0>, lds_q) || set_lds(q_kernel<1>, lds_q) ||
+        set_lds(q_kernel<2>, lds_q) || set_lds(actor_act_kernel, lds_a)) return -2;
+    done = true;
+    return 0;
+}
+
+extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
+    if (!a || !a->d_params || !a->d_target || !a->d_grad || !a->d_m || !a->d_v || !a->d_steps || !a->d_obs || !a->d_act || !a->d_rew ||
+        !a->d_next_obs || !a->d_mask || !a->d_counter || !a->d_workspace || !a->d_stats || (!a->d_ring_size && !a->d_idx_in))
+        return fail(-1, "scg_sac_update: NULL argument");
+    if (a->batch <= 0 || a->batch % 32) return fail(-1, "scg_sac_update: the batch size must be a positive multiple of 32");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = a->batch, n_part = n_part_of(B), n_wg = (n_part + WAVES - 1) / WAVES;
+    const Ws w = carve(B, n_part);
+    float* W = (float*)a->d_workspace;
+    int32_t* idx = (int32_t*)(W + w.idx);
+    const size_t lds_a = lds_actor_bytes(), lds_q = lds_q_bytes();
+    if (int rc = scg_sac_prepare()) return rc;
+    Common Cm;
+    Cm.idx = idx; Cm.batch = B; Cm.n_part = n_part; Cm.obs = a->d_obs; Cm.act = a->d_act; Cm.rew = a->d_rew; Cm.next_obs = a->d_next_obs;
+    Cm.mask = a->d_mask; Cm.log_alpha = a->d_params + a->n_params; Cm.gamma = a->gamma;
+    for (int j = 0; j < 4; ++j) { Cm.low[j] = a->act_low[j]; Cm.high[j] = a->act_high[j]; }
+    Cm.k0 = (uint32_t)a->seed; Cm.k1 = (uint32_t)(a->seed >> 32); Cm.counter = a->d_counter;
+    float* stat = W + w.stat;
+    // 0. minibatch rows; remember log_alpha as the policy loss sees it (entropy_loss is reported with that value)
+    sample_kernel<<<dim3((B + 255) / 256), dim3(256), 0, st>>>(idx, a->d_ring_size, B, a->d_idx_in, Cm.k0, Cm.k1, a->d_counter);
+    HIP_TRY(hipMemcpyAsync(W + w.la_before, a->d_params + a->n_params, sizeof(float), hipMemcpyDeviceToDevice, st));
+    // 1. a, log pi at obs
+    actor_fwd_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, 0, a->d_eps_in, 1u, W + w.eps, W + w.a_pi, W + w.logp);
+    // 2. q1, q2 and dq/da at (obs, a)
+    q_kernel<1><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_params, a->q1, a->q2, Cm, W + w.a_pi, nullptr, nullptr, W + w.qpi, W + w.dqda, nullptr);
+    // 3. actor gradient
+    actor_grad_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, W + w.eps, W + w.qpi, W + w.dqda, W + w.partials);
+    {
+        ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->actor; R.lay[1] = a->actor; R.grad = a->d_grad; R.stat_out = stat;
+        reduce_kernel<NOBS, NA><<<dim3((Part<NOBS, NA>::END + 63) / 64, 1), dim3(256), 0, st>>>(R);
+    }
+    // 4. actor (+ temperature) step
+    {
+        AdamArgs A{a->d_params, a->d_grad, a->d_m, a->d_v, 0, a->n_actor, a->actor_lr, a->d_steps, 0,
+                   a->use_entropy_tuning, a->n_params, a->entropy_lr, a->target_entropy, stat, nullptr, 0, 0.0f};
+        adam_kernel<<<dim3((a->n_actor + 255) / 256), dim3(256), 0, st>>>(A);
+    }
+    // 5. a', log pi' at next_obs with the updated actor
+    actor_fwd_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, 1, a->d_eps_next_in, 2u, W + w.eps2, W + w.a_next, W + w.logp_next);
+    // 6. target networks
+    q_kernel<0><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_target, a->q1, a->q2, Cm, W + w.a_next, nullptr, nullptr, W + w.qt, nullptr, nullptr);
+    // 7. critic gradients
+    q_kernel<2><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_params, a->q1, a->q2, Cm, nullptr, W + w.qt, W + w.logp_next, nullptr, nullptr, W + w.partials);
+    {
+        ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->q1; R.lay[1] = a->q2; R.grad = a->d_grad; R.stat_out = stat + 2;
+        reduce_kernel<NQ, 1><<<dim3((Part<NQ, 1>::END + 63) / 64, 2), dim3(256), 0, st>>>(R);
+    }
+    // 8. critic step + Polyak averaging of every actor-critic parameter
+    {
+        AdamArgs A{a->d_params, a->d_grad, a->d_m, a->d_v, a->n_actor, a->n_params, a->critic_lr, a->d_steps, 1,
+                   0, a->n_params, 0.0f, 0.0f, stat, a->d_target, a->n_params, a->tau};
+        adam_kernel<<<dim3((a->n_params + 255) / 256), dim3(256), 0, st>>>(A);
+    }
+    {
+        FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
+        finish_kernel<<<dim3(1), dim3(64), 0, st>>>(F);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int scg_sac_act(const float* d_params, const scg_mlp_layout* actor, const float* act_low, const float* act_high, const float* d_obs,
+                           int m, float* d_act_out, void* stream) {
+    if (!d_params || !actor || !act_low || !act_high || !d_obs || !d_act_out || m <= 0) return fail(-1, "scg_sac_act: bad argument");
+    const size_t lds_a = MlpLds<NOBS, HID, NA>::END * sizeof(float);
+    if (int rc = scg_sac_prepare()) return rc;
+    float lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    for (int j = 0; j < NU; ++j) { lo[j] = act_low[j]; hi[j] = act_high[j]; }
+    const int grid = std::min(256, (m + 127) / 128);
+    actor_act_kernel<<<dim3(grid), dim3(64 * WAVES), lds_a, (hipStream_t)stream>>>(d_params, *actor, d_obs, m, make_float4(lo[0], lo[1], lo[2], lo[3]),
+                                                                                     make_float4(hi[0], hi[1], hi[2], hi[3]), d_act_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

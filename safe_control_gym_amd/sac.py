@@ -118,6 +118,7 @@ class DeviceReplay:
         self.mask = torch.ones(self.capacity, 1, **f)
         self.pos, self.size = 0, 0
         self.size_t = torch.zeros((), device=device)         # `size` as a device scalar: sampling inside a captured graph
+        self.size_i32 = torch.zeros(1, dtype=torch.int32, device=device)       # (the fused update samples in its own kernel)
 
     def push(self, obs, act, rew, next_obs, mask):
         n = obs.shape[0]
@@ -129,6 +130,7 @@ class DeviceReplay:
         self.pos = (self.pos + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
         self.size_t.fill_(float(self.size))
+        self.size_i32.fill_(self.size)
 
     def state_dict(self):
         """SACBuffer.state_dict (sac_utils.py:330-338): the filled part of the ring + the write position."""
@@ -144,6 +146,7 @@ class DeviceReplay:
             getattr(self, k)[:n].copy_(sd[k].to(self.obs.device))
         self.pos, self.size = int(sd['pos']) % self.capacity, n
         self.size_t.fill_(float(n))
+        self.size_i32.fill_(n)
 
     def sample_static(self, batch_size):
         """Uniform sample with static shapes and no host value: usable under HIP-graph capture."""
@@ -173,6 +176,15 @@ class SACAgent:
         # and the update stays eager.
         self.use_graphs = (torch.device(device).type == 'cuda' and bool(cfg.extra.get('cuda_graphs', True))
                            and parallel.world_size() == 1)
+        # Fused gradient step (csrc/scg_sac.hip, include/scg_sac.h): the whole SACAgent.update — sampling, the five network
+        # passes on the matrix cores, both Adam steps, temperature, Polyak — as 13 launches on flat parameter vectors instead
+        # of ~100 PyTorch kernels.  Chosen here, visibly: single-rank GPU runs of shapes the library serves.
+        from safe_control_gym_amd import _sac
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
+                          and _sac.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
+        self._flat = self._flatten(low, high) if self.use_fused else None
+        self._fused = None
         kw = {'capturable': True} if self.use_graphs else {}
         self.actor_opt = torch.optim.Adam(self.ac.actor.parameters(), cfg.actor_lr, **kw)
         self.critic_opt = torch.optim.Adam(list(self.ac.q1.parameters()) + list(self.ac.q2.parameters()), cfg.critic_lr, **kw)
@@ -184,12 +196,104 @@ class SACAgent:
     def alpha(self):
         return self.log_alpha.exp()
 
+    # ---- fused update ------------------------------------------------------------------------------------------
+    def _flatten(self, low, high):
+        """All trainable tensors as views of ONE flat vector [actor | q1 | q2 | log_alpha] (+ a target vector in the same
+        order, gradient scratch, Adam moments); the actor's two heads are stored as one [2 act_dim][H] matrix / [2 act_dim]
+        bias (scg_sac.h).  The torch modules keep working on the views (acting, evaluation, checkpoints)."""
+        from safe_control_gym_amd._learn import MlpLayout
+        a, dev = self.ac.actor, self.log_alpha.device
+
+        def order(ac):
+            act = ac.actor
+            return ([act.net.fcs[0].weight, act.net.fcs[0].bias, act.net.fcs[1].weight, act.net.fcs[1].bias, act.mu_layer.weight,
+                     act.log_std_layer.weight, act.mu_layer.bias, act.log_std_layer.bias],
+                    [p for f in ac.q1.q_net.fcs for p in (f.weight, f.bias)], [p for f in ac.q2.q_net.fcs for p in (f.weight, f.bias)])
+        if len(a.net.fcs) != 2 or len(self.ac.q1.q_net.fcs) != 3:
+            raise ValueError('the fused SAC update serves two hidden layers')
+        groups = order(self.ac)
+        params = [p for g in groups for p in g]
+        n = sum(p.numel() for p in params)
+        flat = torch.cat([p.data.reshape(-1) for p in params] + [self.log_alpha.data.reshape(1)]).contiguous()
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            p.data = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.log_alpha.data = flat[n:n + 1].view(())
+        targ = torch.empty(n, device=dev)
+        off = 0
+        for p in [q for g in order(self.ac_targ) for q in g]:
+            targ[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = targ[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        lay = lambda k: MlpLayout(offs[k], offs[k + 1], offs[k + 2], offs[k + 3], offs[k + 4], offs[k + 5])      # noqa: E731
+        actor_lay = MlpLayout(offs[0], offs[1], offs[2], offs[3], offs[4], offs[6])       # W3 = [mu; log_std] rows, b3 = [mu; log_std]
+        n_actor = sum(p.numel() for p in groups[0])
+        return {'p': flat, 'targ': targ, 'g': torch.zeros(n + 1, device=dev), 'm': torch.zeros(n + 1, device=dev),
+                'v': torch.zeros(n + 1, device=dev), 'steps': torch.zeros(3, device=dev), 'n': n, 'n_actor': n_actor,
+                'actor': actor_lay, 'q1': lay(8), 'q2': lay(14), 'low': [float(x) for x in low.reshape(-1)],
+                'high': [float(x) for x in high.reshape(-1)], 'counter': torch.zeros(1, dtype=torch.int32, device=dev),
+                'seed': int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF}
+
+    def _fused_args(self, buffer, batch_size, idx=None, eps=None, eps_next=None):
+        import ctypes as C
+        from safe_control_gym_amd import _sac
+        fl, cfg = self._flat, self.cfg
+        D = _sac.lib(self.obs_dim, cfg.hidden_dim, self.act_dim, cfg.activation)
+        _sac.check(D, D.scg_sac_prepare())
+        dev = fl['p'].device
+        ws = torch.empty(D.scg_sac_workspace_bytes(int(batch_size)), dtype=torch.uint8, device=dev)
+        stats, acc = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
+        a = _sac.SacArgs(d_params=p(fl['p']), d_target=p(fl['targ']), d_grad=p(fl['g']), d_m=p(fl['m']), d_v=p(fl['v']), d_steps=p(fl['steps']),
+                         actor=fl['actor'], q1=fl['q1'], q2=fl['q2'], n_actor=fl['n_actor'], n_params=fl['n'], d_obs=p(buffer.obs),
+                         d_act=p(buffer.act), d_rew=p(buffer.rew), d_next_obs=p(buffer.next_obs), d_mask=p(buffer.mask),
+                         d_ring_size=p(buffer.size_i32), batch=int(batch_size), gamma=float(cfg.gamma), tau=float(cfg.tau),
+                         actor_lr=float(cfg.actor_lr), critic_lr=float(cfg.critic_lr), entropy_lr=float(cfg.entropy_lr),
+                         use_entropy_tuning=int(bool(cfg.use_entropy_tuning)), target_entropy=float(self.target_entropy),
+                         seed=fl['seed'], d_counter=p(fl['counter']), d_idx_in=p(idx), d_eps_in=p(eps), d_eps_next_in=p(eps_next),
+                         d_workspace=p(ws), d_stats=p(stats), d_stats_acc=p(acc))
+        for j in range(self.act_dim):
+            a.act_low[j], a.act_high[j] = fl['low'][j], fl['high'][j]
+        return {'D': D, 'args': a, 'ws': ws, 'stats': stats, 'acc': acc, 'C': C, 'keep': (idx, eps, eps_next, buffer)}
+
+    def _fused_step(self, F):
+        """Enqueue ONE gradient step on the current stream."""
+        from safe_control_gym_amd import _sac
+        st = F['C'].c_void_p(torch.cuda.current_stream(self._flat['p'].device).cuda_stream)
+        _sac.check(F['D'], F['D'].scg_sac_update(F['C'].byref(F['args']), st))
+
+    def _update_fused(self, buffer, batch_size, n_updates):
+        if batch_size % 32:
+            raise ValueError('the fused SAC update needs train_batch_size to be a multiple of 32')
+        key = (id(buffer), batch_size)
+        if self._fused is None or self._fused['key'] != key:
+            self._fused = dict(self._fused_args(buffer, batch_size), key=key, graphs={})
+        F = self._fused
+        F['acc'].zero_()
+        dev = self._flat['p'].device
+        g = F['graphs'].get(n_updates)
+        if g is None:                               # n_updates steps as one HIP graph (13 launches each: host-launch bound otherwise)
+            with torch.cuda.device(dev):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(n_updates):
+                        self._fused_step(F)
+            F['graphs'][n_updates] = g
+        g.replay()
+        st = (F['acc'] / n_updates).tolist()
+        return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
+
     # same keys as the reference's SACAgent (sac_utils.py:85-108), so its checkpoints load directly; the action bounds are
     # buffers here (not in upstream's state dict), hence strict=False
     def state_dict(self):
-        return {'ac': self.ac.state_dict(), 'log_alpha': self.log_alpha.detach().clone(), 'ac_targ': self.ac_targ.state_dict(),
-                'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict(),
-                'alpha_opt': self.alpha_opt.state_dict()}
+        sd = {'ac': self.ac.state_dict(), 'log_alpha': self.log_alpha.detach().clone(), 'ac_targ': self.ac_targ.state_dict(),
+              'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict(),
+              'alpha_opt': self.alpha_opt.state_dict()}
+        if self._flat is not None:          # fused mode: the Adam moments live in the flat buffers (the torch optimisers never step)
+            sd['flat_adam'] = {k: self._flat[k].clone() for k in ('m', 'v', 'steps', 'counter')}
+        return sd
 
     def load_state_dict(self, sd, with_optimizers=True):
         self.ac.load_state_dict(sd['ac'], strict=False)
@@ -205,6 +309,13 @@ class SACAgent:
             self.critic_opt.load_state_dict(sd['critic_opt'])
             self.alpha_opt.load_state_dict(sd['alpha_opt'])
             self._graph = None
+            if self._flat is not None:
+                if 'flat_adam' in sd:
+                    for k, t in sd['flat_adam'].items():
+                        self._flat[k].copy_(t.to(self._flat[k].device))       # in place: captured graphs alias these buffers
+                elif sd['actor_opt'].get('state'):
+                    raise ValueError('checkpoint carries torch.optim state only (saved with fused_update off); load it with '
+                                     "extra={'fused_update': False} — the flat Adam moments would silently restart from zero")
 
     def policy_loss(self, batch):
         obs = batch['obs']
@@ -261,6 +372,8 @@ class SACAgent:
 
     def update_from_buffer(self, buffer, batch_size, n_updates):
         """n_updates gradient steps on fresh uniform samples; replays one captured graph per step when enabled."""
+        if self.use_fused:
+            return self._update_fused(buffer, batch_size, n_updates)
         if not self.use_graphs:
             acc = None
             for _ in range(n_updates):

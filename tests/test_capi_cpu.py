@@ -28,6 +28,28 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), f'libscg_hip.so does not export {n}'
 
 
+def test_learner_libraries_export_every_declared_symbol():
+    """include/scg_learn.h (PPO learner) and include/scg_sac.h (fused SAC step): per-shape libraries, every declared entry
+    point exported, the shape query answers with the shape they were compiled for, the ctypes structs have the C layout
+    (offset of the last field + its size == what the header's field list implies)."""
+    from safe_control_gym_amd import _learn, _sac
+    for mod, hdr_name, shape_fn, shape in ((_learn, 'scg_learn.h', 'scg_learn_shape', (12, 32, 2, 'tanh')), (_sac, 'scg_sac.h', 'scg_sac_shape', (6, 32, 2, 'relu'))):
+        so = mod.build(*shape)
+        D = C.CDLL(so)
+        hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', hdr_name)).read(), flags=re.S)
+        names = set(re.findall(r'\b(scg_[a-z_0-9]+)\s*\(', hdr))
+        assert len(names) >= 6
+        for n in names:
+            assert hasattr(D, n), f'{os.path.basename(so)} does not export {n}'
+        got = [C.c_int32() for _ in range(4)]
+        getattr(D, shape_fn)(*[C.byref(v) for v in got])
+        assert tuple(v.value for v in got) == (shape[0], shape[1], shape[2], _learn.ACTS[shape[3]])
+    # scg_sac_args: pointers 8-byte aligned, three 24-byte layouts, floats packed as declared
+    assert _sac.SacArgs.d_workspace.offset % 8 == 0 and C.sizeof(_sac.SacArgs) % 8 == 0
+    assert _sac.SacArgs.actor.offset == 6 * 8 and _sac.SacArgs.n_actor.offset == 6 * 8 + 3 * 24
+    assert _sac.SacArgs.act_high.offset - _sac.SacArgs.act_low.offset == 16
+
+
 def test_struct_layouts_agree(lib):
     from safe_control_gym_amd import _lib as L
     assert lib.scg_sizeof_config() == C.sizeof(L.Config)

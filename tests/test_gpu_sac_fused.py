@@ -1,0 +1,181 @@
+"""scg_sac_update (csrc/scg_sac.hip, include/scg_sac.h): the fused SAC gradient step against
+ (a) the REFERENCE's own SACAgent.update — tests/golden/learner.npz, produced by tests/golden/make_learner.py from
+     controllers/sac/sac_utils.py: same initial weights, same index batches, same noise -> the reference's final weights,
+     target weights, temperature and loss statistics after three updates;
+ (b) this package's eager PyTorch update (itself pinned to the reference by tests/test_learner_golden.py) at the production
+     shape (24 -> 128 -> 128, 4 actions, batch 4096): gradients of one step and parameters after several;
+ (c) itself: bitwise reproducibility, in-kernel sampling, HIP-graph capture through SACAgent.update_from_buffer."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'learner.npz'))
+
+
+def sd(prefix):
+    return {k[len(prefix) + 1:]: torch.as_tensor(G[k]) for k in G.files if k.startswith(prefix + '/')}
+
+
+class RecordNoise:
+    """Context: records every torch.randn_like draw (the actor's reparameterisation noise) / replays a given list."""
+
+    def __init__(self, replay=None):
+        self.draws, self.replay, self._orig = [], list(replay) if replay is not None else None, None
+
+    def __enter__(self):
+        self._orig = torch.randn_like
+
+        def fn(t, *a, **k):
+            x = self.replay.pop(0).to(t.device) if self.replay is not None else self._orig(t, *a, **k)
+            self.draws.append(x.detach().cpu().clone())
+            return x
+        torch.randn_like = fn
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig
+
+
+def _ring(buf_cls, dev):
+    rng = np.random.default_rng(9)
+    buf = buf_cls(200, 6, 2, dev)
+    for _ in range(5):
+        n = 50
+        b = {'obs': rng.normal(0, 1, (n, 6)), 'act': rng.uniform([-1, 0], [1, 2], (n, 2)), 'rew': rng.normal(0, 1, (n,)),
+             'next_obs': rng.normal(0, 1, (n, 6)), 'mask': (rng.uniform(size=n) > 0.1).astype(np.float32)}
+        t = {k: torch.as_tensor(v, dtype=torch.float32, device=dev) for k, v in b.items()}
+        buf.push(t['obs'], t['act'], t['rew'], t['next_obs'], t['mask'])
+    return buf
+
+
+def test_fused_update_reproduces_the_reference_sac_agent():
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    kw = dict(hidden_dim=32, activation='relu', gamma=0.98, tau=0.01, init_temperature=0.3, use_entropy_tuning=True, actor_lr=1e-3,
+              critic_lr=2e-3, entropy_lr=3e-3)
+    # the noise the reference drew: replay its update on the eager CPU path under the generator's seed and record it
+    cpu = SACAgent(6, 2, torch.tensor([-1.0, 0.0]), torch.tensor([1.0, 2.0]), SACConfig(**kw, extra={'cuda_graphs': False}), 'cpu')
+    cpu.ac.load_state_dict(sd('sac/init'), strict=False); cpu.ac_targ.load_state_dict(sd('sac/init'), strict=False)
+    cbuf = _ring(DeviceReplay, 'cpu')
+    torch.manual_seed(13)
+    with RecordNoise() as rec:
+        for idx in G['sac/indices']:
+            idx = torch.as_tensor(idx)
+            cpu.update({k: getattr(cbuf, k)[idx] for k in ('obs', 'act', 'rew', 'next_obs', 'mask')})
+    assert len(rec.draws) == 6
+    dev = torch.device('cuda', 0)
+    ag = SACAgent(6, 2, torch.tensor([-1.0, 0.0], device=dev), torch.tensor([1.0, 2.0], device=dev), SACConfig(**kw), dev)
+    assert ag.use_fused
+    ag.ac.load_state_dict(sd('sac/init'), strict=False); ag.ac_targ.load_state_dict(sd('sac/init'), strict=False)
+    buf = _ring(DeviceReplay, dev)
+    res = []
+    for k, idx in enumerate(G['sac/indices']):
+        F = ag._fused_args(buf, 64, idx=torch.as_tensor(idx, dtype=torch.int32, device=dev), eps=rec.draws[2 * k].to(dev).contiguous(),
+                           eps_next=rec.draws[2 * k + 1].to(dev).contiguous())
+        ag._fused_step(F)
+        torch.cuda.synchronize()
+        res.append(F['stats'][:3].tolist())
+    np.testing.assert_allclose(res, G['sac/results'], rtol=5e-5, atol=5e-6)
+    for prefix, net in (('sac/final', ag.ac), ('sac/final_targ', ag.ac_targ)):
+        final = sd(prefix)
+        for k, v in net.state_dict().items():
+            if k in final:
+                torch.testing.assert_close(v.cpu(), final[k], rtol=2e-4, atol=5e-6, msg=lambda m, k=k: f'{prefix} {k}: {m}')
+    np.testing.assert_allclose(float(ag.log_alpha), float(G['sac/final_log_alpha']), rtol=1e-5)
+    assert ag._flat['steps'].tolist() == [3.0, 3.0, 3.0] and int(ag._flat['counter']) == 3
+
+
+@pytest.mark.parametrize('tuning', [False, True])
+def test_fused_update_equals_the_eager_update_at_the_production_shape(tuning):
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    low, high = -torch.ones(4, device=dev), torch.ones(4, device=dev)
+    kw = dict(hidden_dim=128, activation='relu', use_entropy_tuning=tuning, actor_lr=1e-3, critic_lr=1e-3, entropy_lr=1e-3)
+    torch.manual_seed(3)
+    eager = SACAgent(24, 4, low, high, SACConfig(**kw, extra={'cuda_graphs': False}), dev)
+    fused = SACAgent(24, 4, low, high, SACConfig(**kw), dev)
+    assert fused.use_fused and not eager.use_fused
+    fused.ac.load_state_dict(eager.ac.state_dict()); fused.ac_targ.load_state_dict(eager.ac_targ.state_dict())
+    cap, B = 20000, 4096
+    buf = DeviceReplay(cap, 24, 4, dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                     # noqa: E731
+    buf.push(r(cap, 24), torch.tanh(r(cap, 4)), r(cap), r(cap, 24), (torch.rand(cap, device=dev, generator=g) > 0.05).float())
+    for step in range(3):
+        idx = torch.randint(0, cap, (B,), device=dev, generator=g)
+        eps, eps2 = r(B, 4), r(B, 4)
+        batch = {k: getattr(buf, k)[idx] for k in ('obs', 'act', 'rew', 'next_obs', 'mask')}
+        # reference gradients of this step from autograd on the eager agent's CURRENT weights
+        with RecordNoise(replay=[eps, eps2]):
+            res_e = eager.update(batch)
+        ga = torch.cat([p.grad.reshape(-1) for p in eager.ac.actor.parameters()])
+        F = fused._fused_args(buf, B, idx=idx.to(torch.int32), eps=eps, eps_next=eps2)
+        fused._fused_step(F)
+        torch.cuda.synchronize()
+        st = F['stats'].tolist()
+        np.testing.assert_allclose(st[:2], [float(res_e['policy_loss']), float(res_e['critic_loss'])], rtol=2e-4, atol=1e-5)
+        if step == 0:       # same weights on both sides: gradients comparable element by element
+            fl = fused._flat
+            names = ['net.fcs.0.weight', 'net.fcs.0.bias', 'net.fcs.1.weight', 'net.fcs.1.bias', 'mu_layer.weight', 'log_std_layer.weight',
+                     'mu_layer.bias', 'log_std_layer.bias']
+            pe = dict(eager.ac.actor.named_parameters())
+            ref = torch.cat([pe[n].grad.reshape(-1) for n in names])
+            got = fl['g'][:fl['n_actor']]
+            torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-6)
+            qe = torch.cat([p.grad.reshape(-1) for q in (eager.ac.q1, eager.ac.q2) for p in q.parameters()])
+            torch.testing.assert_close(fl['g'][fl['n_actor']:fl['n']], qe, rtol=2e-3, atol=2e-6)
+            assert ga.abs().max() > 0
+    # after three Adam steps of lr 1e-3 the two parameter sets stay together (Adam's first steps are sign-like: elements with
+    # |g| ~ 1e-8 may differ by a whole lr, hence the absolute tolerance of two steps)
+    for (k, a), b in zip(fused.ac.state_dict().items(), eager.ac.state_dict().values()):
+        assert (a - b).abs().max() <= 2.1e-3, k
+        assert (a - b).abs().mean() <= 2e-5, k
+    for (k, a), b in zip(fused.ac_targ.state_dict().items(), eager.ac_targ.state_dict().values()):
+        assert (a - b).abs().max() <= 1e-4, k
+    if tuning:
+        assert abs(float(fused.log_alpha) - float(eager.log_alpha)) < 1e-5
+
+
+def test_fused_update_samples_in_the_kernel_is_reproducible_and_learns():
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    low, high = -torch.ones(4, device=dev), torch.ones(4, device=dev)
+
+    def run(n_calls):
+        torch.manual_seed(11)
+        ag = SACAgent(24, 4, low, high, SACConfig(hidden_dim=128, activation='relu'), dev)
+        buf = DeviceReplay(50000, 24, 4, dev)
+        g = torch.Generator(device=dev).manual_seed(2)
+        obs = torch.randn(30000, 24, device=dev, generator=g)
+        act = torch.rand(30000, 4, device=dev, generator=g) * 2 - 1
+        # a learnable signal: reward = -|a - tanh(obs[:4])|^2, episodes end immediately (mask 0): Q -> reward, actor -> tanh(obs[:4])
+        rew = -((act - torch.tanh(obs[:, :4])) ** 2).sum(-1)
+        buf.push(obs, act, rew, torch.randn(30000, 24, device=dev, generator=g), torch.zeros(30000, device=dev))
+        out = []
+        for _ in range(n_calls):
+            out.append(ag.update_from_buffer(buf, 4096, 8))         # 8 gradient steps per call, one captured graph
+        return ag, out, obs
+
+    a1, o1, obs = run(40)
+    a2, o2, _ = run(40)
+    assert o1 == o2                                                             # bitwise: fixed-order reductions, counter-based draws
+    assert torch.equal(a1._flat['p'], a2._flat['p']) and int(a1._flat['counter']) == 320 and a1._flat['steps'].tolist()[:2] == [320.0, 320.0]
+    assert o1[-1]['critic_loss'] < 0.2 * o1[0]['critic_loss']
+    with torch.no_grad():
+        a = a1.ac.act(obs[:2048], deterministic=True)
+        err0 = ((torch.zeros_like(a) - torch.tanh(obs[:2048, :4])) ** 2).sum(-1).mean()
+        err = ((a - torch.tanh(obs[:2048, :4])) ** 2).sum(-1).mean()
+    assert err < 0.5 * err0, (float(err), float(err0))
+    # the batched deterministic actor of the library == the torch module on the same flat weights
+    import ctypes as C
+    from safe_control_gym_amd import _sac
+    D = _sac.lib(24, 128, 4, 'relu')
+    out = torch.empty(2048, 4, device=dev)
+    lo, hi = (C.c_float * 4)(-1, -1, -1, -1), (C.c_float * 4)(1, 1, 1, 1)
+    _sac.check(D, D.scg_sac_act(a1._flat['p'].data_ptr(), C.byref(a1._flat['actor']), lo, hi, obs[:2048].contiguous().data_ptr(), 2048,
+                                out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, a, rtol=1e-4, atol=1e-5)
