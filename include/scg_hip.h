@@ -190,7 +190,9 @@ typedef struct {
     void* d_reward;         /* [N] */
     uint8_t* d_done;        /* [N] 0/1 */
     uint8_t* d_flags;       /* [N] bit0 TimeLimit.truncated, bit1 constraint_violation, bit2 out_of_bounds,
-                                   bit3 goal_reached */
+                                   bit3 goal_reached, bit4 ground_contact (quadrotors: z at / below the reference world's
+                                   ground plane, base_aviary.py:107,219-220 — Bullet's contact response is not modelled, the
+                                   flag marks steps from which the trajectory is no longer the reference's) */
     void* d_c_values;       /* [n_con_rows][N]  info['constraint_values'] of the step (pre-reset), one row per
                                    constraint so that every wave stores contiguous 256-byte segments;
                                    at reset: the state rows, densely in rows 0..n_state_con_rows-1 */

@@ -29,7 +29,7 @@ DIST_NONE, DIST_IMPULSE, DIST_STEP, DIST_UNIFORM, DIST_WHITE, DIST_PERIODIC = ra
 CH_ACTION, CH_DYNAMICS, CH_OBSERVATION = 0, 1, 2
 RAND_NONE, RAND_UNIFORM, RAND_NORMAL, RAND_CHOICE = range(4)
 ROW_SPARSE, ROW_DENSE, ROW_ABS, ROW_QUADRATIC = range(4)
-FLAG_TRUNCATED, FLAG_VIOLATION, FLAG_OOB, FLAG_GOAL = 1, 2, 4, 8
+FLAG_TRUNCATED, FLAG_VIOLATION, FLAG_OOB, FLAG_GOAL, FLAG_GROUND = 1, 2, 4, 8, 16
 
 c_i32, c_u64, c_f64, c_vp = C.c_int32, C.c_uint64, C.c_double, C.c_void_p
 

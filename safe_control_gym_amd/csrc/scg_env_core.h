@@ -354,7 +354,11 @@ struct OutTabPtr { char* ptr[OUT_COUNT]; };                       // ... of the 
 template <bool ONE> struct OutTabOf { using type = OutTabPtr; };
 template <> struct OutTabOf<true> { using type = OutTabOne; };
 
-enum : uint8_t { FLAG_TRUNCATED = 1, FLAG_VIOLATION = 2, FLAG_OOB = 4, FLAG_GOAL = 8 };
+enum : uint8_t { FLAG_TRUNCATED = 1, FLAG_VIOLATION = 2, FLAG_OOB = 4, FLAG_GOAL = 8, FLAG_GROUND = 16 };
+// FLAG_GROUND (quadrotors): the body reached the ground plane of the reference's world — plane.urdf at GROUND_PLANE_Z = -0.05
+// (base_aviary.py:107,219-220), collision cylinder of cf2x.urdf:31-36 half-height 0.0125 => contact at z <= -0.0375.  Bullet's
+// contact response is NOT modelled (the shipped tasks end the episode out of bounds at z < 0 first); with
+// `done_on_out_of_bound: False` or bounds that admit z < 0 the simulated body would fall through, so the step says so.
 
 template <int SYS, typename T>
 struct Env {
@@ -1512,6 +1516,10 @@ SCG_BOX_UNROLL
             }
             if (oob) flags |= FLAG_OOB;
             done = done || (oob && !goal);
+        }
+        if constexpr (SYS != SCG_CARTPOLE) {
+            constexpr int ZI = SYS == SCG_QUAD_1D ? 0 : (SYS == SCG_QUAD_2D ? 2 : 4);
+            if (st[ZI] <= (T)-0.0375) flags |= FLAG_GROUND;
         }
         // ---- _get_info: mse
         T mse = (T)0;

@@ -196,6 +196,13 @@ __device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T
     static_assert(RB % 16 == 0, "row pitch must be a multiple of 16 bytes");
     constexpr int per = 16 / (int)sizeof(T);
     struct Piece { T e[per]; };
+    if constexpr (RB == 16) {           // a 16-byte row per lane IS the contiguous block (CartPole's float obs): no transpose to do
+        Piece p;
+#pragma unroll
+        for (int j = 0; j < per; ++j) p.e[j] = row[j];
+        buf_st128(__builtin_bit_cast(u32x4, p), dst.r, dst.off, dst.soff, 0u);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < RB / 16; ++c) {
         Piece p;

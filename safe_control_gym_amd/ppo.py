@@ -528,6 +528,7 @@ class PPO:
         # policy shape (HipVecEnv(..., policy=(hidden, activation))), the flat parameter vector, no normalisers.
         self._fused_rollout = (self.agent.use_fused and bool(cfg.extra.get('fused_rollout', True)) and not self._normalise
                                and getattr(env, 'policy_shape', None) == (cfg.hidden_dim, cfg.activation))
+        self._ret_adv = None
         if self._fused_rollout:
             self._episode_acc = torch.zeros(N, 8, **f)
             self._v_all = torch.zeros(T + 1, N, **f)
@@ -622,7 +623,9 @@ class PPO:
         mask = 1.0 - self.done.to(torch.float32)
         terminal_v = torch.where(trunc_u8.bool(), self._tv, torch.zeros_like(self._tv))
         rew = self.rew.clone()
-        ret, adv = self._gae(rew, self.v, mask, terminal_v, self._v_all[T], cfg.gamma, cfg.gae_lambda, cfg.use_gae)
+        if self._ret_adv is None:
+            self._ret_adv = (torch.empty_like(rew), torch.empty_like(rew))
+        ret, adv = self._gae(rew, self.v, mask, terminal_v, self._v_all[T], cfg.gamma, cfg.gae_lambda, cfg.use_gae, out=self._ret_adv)
         moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])
         tot = self._episode_acc.sum(0)
         self.ep_count += tot[0]; self.ep_return_sum += tot[1]; self.ep_length_sum += tot[2]; self.ep_violation_sum += tot[3]

@@ -108,8 +108,9 @@ def make_vec_envs(env_func, env_configs=None, batch_size=1, n_processes=1, seed=
 
     * env_func: see resolve_env_func; keys the simulator has no use for (output_dir, gui, verbose, ...) are accepted and
       ignored exactly like the env constructors' **kwargs upstream.
-    * env_configs: upstream's per-env "non-shareable" kwargs; a HipVecEnv shares one config, so only None / all-equal
-      entries are accepted (they are merged into the task config).
+    * env_configs: upstream's per-env "non-shareable" kwargs (env k = env_func(**env_configs[k])).  None / all-equal entries are
+      merged into the task config of ONE HipVecEnv; entries that differ are grouped by identical config into one HipVecEnv per
+      group behind vec_env.GroupedVecEnv (each env keeps its own config across auto-resets, as upstream's env objects do).
     * n_processes: accepted for call compatibility; there are no worker processes (the batch is one kernel launch).
     * seed: upstream seeds env `rank` with seed + rank (:28-38); here it is the Philox key, env ids are the counter.
     Historic form `make_vec_envs(env_id: str, task_config: dict, batch_size, ...)` is still accepted."""
@@ -119,11 +120,51 @@ def make_vec_envs(env_func, env_configs=None, batch_size=1, n_processes=1, seed=
     else:
         env_id, cfg = resolve_env_func(env_func)
         if env_configs is not None:
-            cfgs = list(env_configs)
-            if any(c != cfgs[0] for c in cfgs):
-                raise NotImplementedError('per-env configs differ: a HipVecEnv holds N copies of ONE task config')
+            cfgs = [dict(c) for c in env_configs]
+            if cfgs and len(cfgs) != batch_size:
+                raise ValueError(f'env_configs has {len(cfgs)} entries for batch_size {batch_size}')
+            if any(not _same_config(c, cfgs[0]) for c in cfgs):
+                return _grouped(env_id, cfg, cfgs, kwargs, 0 if seed is None else seed)
             if cfgs:
                 cfg.update(cfgs[0])
     cfg.update(kwargs)
     cfg.pop('seed', None)
     return HipVecEnv(env_id, batch_size, seed=0 if seed is None else seed, **cfg)
+
+
+def _same_config(a, b):
+    import numpy as np
+    if a.keys() != b.keys():
+        return False
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, np.ndarray) or isinstance(y, np.ndarray):
+            if not np.array_equal(np.asarray(x), np.asarray(y)):
+                return False
+        elif x != y:
+            return False
+    return True
+
+
+def _grouped(env_id, base_cfg, cfgs, kwargs, seed):
+    """One HipVecEnv per distinct per-env config (first-occurrence order); env k of group g gets the Philox stream of global
+    env id k (env_id_offset = its first member, members keep their relative order), so a grouped batch and a homogeneous one
+    draw the same numbers for the same env index whenever the groups are contiguous."""
+    from safe_control_gym_amd.vec_env import GroupedVecEnv, HipVecEnv
+    reps, members = [], []
+    for k, c in enumerate(cfgs):
+        for g, r in enumerate(reps):
+            if _same_config(c, r):
+                members[g].append(k)
+                break
+        else:
+            reps.append(c)
+            members.append([k])
+    groups = []
+    for r, idx in zip(reps, members):
+        c = dict(base_cfg)
+        c.update(r)
+        c.update(kwargs)
+        c.pop('seed', None)
+        groups.append((HipVecEnv(env_id, len(idx), seed=seed, env_id_offset=idx[0], **c), idx))
+    return GroupedVecEnv(groups)

@@ -10,11 +10,12 @@ import torch
 from safe_control_gym_amd import _lib as L
 
 
-def gae_returns(rew, v, mask, terminal_v, last_v, gamma=0.99, gae_lambda=0.95, use_gae=True):
+def gae_returns(rew, v, mask, terminal_v, last_v, gamma=0.99, gae_lambda=0.95, use_gae=True, out=None):
     """rew, v, mask, terminal_v: [T, N] contiguous device tensors; last_v: [N].
 
     Like the reference, ``rew`` is updated in place with ``gamma * terminal_v`` (time-limit bootstrap,
-    ppo_utils.py:389).  Returns (ret, adv), both [T, N]."""
+    ppo_utils.py:389).  Returns (ret, adv), both [T, N]; ``out=(ret, adv)`` writes into caller-owned buffers (a collector
+    that calls this every iteration keeps them: no allocator traffic between the kernels)."""
     if not rew.is_cuda:
         raise L.ScgError('gae_returns needs device tensors; there is no CPU fallback')
     T, N = rew.shape
@@ -26,8 +27,13 @@ def gae_returns(rew, v, mask, terminal_v, last_v, gamma=0.99, gae_lambda=0.95, u
             raise ValueError('all GAE buffers must be contiguous, same dtype and device')
     if not rew.is_contiguous():
         raise ValueError('rew must be contiguous')
-    ret = torch.empty_like(rew)
-    adv = torch.empty_like(rew)
+    if out is None:
+        ret, adv = torch.empty_like(rew), torch.empty_like(rew)
+    else:
+        ret, adv = out
+        for t in (ret, adv):
+            if t.shape != rew.shape or t.dtype != dt or not t.is_contiguous() or t.device != rew.device:
+                raise ValueError('out buffers must match rew (shape, dtype, device, contiguous)')
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
     with torch.cuda.device(rew.device):
         stream = C.c_void_p(torch.cuda.current_stream(rew.device).cuda_stream)

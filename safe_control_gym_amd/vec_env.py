@@ -111,6 +111,11 @@ class StepTensors:
     def goal_reached(self):
         return (self.flags & L.FLAG_GOAL) != 0
 
+    @property
+    def ground_contact(self):
+        """Quadrotors: z at / below the reference world's ground plane (contact is not modelled: see scg_hip.h, bit4)."""
+        return (self.flags & L.FLAG_GROUND) != 0
+
 
 class LazyInfoList(Sequence):
     """``info['n']``: behaves like the reference's tuple of per-env dicts
@@ -152,6 +157,8 @@ class LazyInfoList(Sequence):
             step['out_of_bounds'] = bool(flags & L.FLAG_OOB)
         if spec.TASK == 'stabilization' and spec.COST == 'quadratic':
             step['goal_reached'] = bool(flags & L.FLAG_GOAL)
+        if flags & L.FLAG_GROUND:           # (extension key, only present when raised: the body is at the unmodelled ground plane)
+            step['ground_contact'] = True
         if h['done'][i]:
             step['current_step'] = int(h['fin_length'][i])
             if flags & L.FLAG_TRUNCATED or step['current_step'] >= spec.CTRL_STEPS:
@@ -564,3 +571,104 @@ class HipVecEnv(VecEnv):
             self.close()
         except Exception:                               # noqa: BLE001
             pass
+
+
+class GroupedVecEnv(VecEnv):
+    """Heterogeneous `env_configs` of make_vec_envs (envs/env_wrappers/vectorized_env/__init__.py:42-66: upstream builds env k as
+    `env_func(**env_configs[k])`): the envs are grouped by identical config, every group is ONE HipVecEnv (one kernel launch per
+    group and control step), and this wrapper scatters / gathers rows in the caller's env order.  Each env therefore keeps
+    its OWN config across auto-resets exactly as upstream's per-env objects do (own init_state, inertial_prop, episode
+    length, constraints ...); only the observation / action dimensions must agree.  Reference (NumPy) API; a homogeneous batch
+    should use HipVecEnv directly (one launch, device tensors)."""
+
+    def __init__(self, groups):
+        """groups: list of (HipVecEnv, indices of its envs in the caller's order)."""
+        self.groups = [(env, np.asarray(idx, dtype=np.int64)) for env, idx in groups]
+        n = sum(len(idx) for _, idx in self.groups)
+        order = np.concatenate([idx for _, idx in self.groups])
+        if sorted(order.tolist()) != list(range(n)):
+            raise ValueError('group indices must partition range(num_envs)')
+        first = self.groups[0][0]
+        for env, _ in self.groups[1:]:
+            if env.observation_space.shape != first.observation_space.shape or env.action_space.shape != first.action_space.shape:
+                raise ValueError('env_configs differ in observation / action dimensions: they cannot share one batch')
+        VecEnv.__init__(self, n, first.observation_space, first.action_space)
+        self.spec, self.device, self.dtype = first.spec, first.device, first.dtype
+        self._where = np.empty((n, 2), dtype=np.int64)                      # env -> (group, row)
+        for g, (_, idx) in enumerate(self.groups):
+            self._where[idx, 0], self._where[idx, 1] = g, np.arange(len(idx))
+
+    def _merge_info(self, infos):
+        merged = [None] * self.num_envs
+        for (_, idx), info in zip(self.groups, infos):
+            lst = info['n']
+            for j, i in enumerate(idx):
+                merged[i] = lst[j]
+        return {'n': merged}
+
+    def reset(self):
+        obs, infos = np.empty((self.num_envs,) + self.observation_space.shape, dtype=np.float64), []
+        for env, idx in self.groups:
+            o, info = env.reset()
+            obs[idx] = o if isinstance(o, np.ndarray) else o.cpu().numpy()
+            infos.append(info)
+        return obs, self._merge_info(infos)
+
+    def step_async(self, actions):
+        actions = np.asarray(actions)
+        for env, idx in self.groups:
+            env.step_async(actions[idx])
+
+    def step_wait(self):
+        N = self.num_envs
+        obs = np.empty((N,) + self.observation_space.shape, dtype=np.float64)
+        rew, done, infos = np.empty(N, dtype=np.float64), np.empty(N, dtype=bool), []
+        for env, idx in self.groups:
+            o, r, d, info = env.step_wait()
+            conv = (lambda t: t if isinstance(t, np.ndarray) else t.cpu().numpy())
+            obs[idx], rew[idx], done[idx] = conv(o), conv(r), conv(d)
+            infos.append(info)
+        return obs, rew, done, self._merge_info(infos)
+
+    def _by_group(self, indices):
+        sel = list(self._get_indices(indices))
+        per = {}
+        for pos, i in enumerate(sel):
+            g, r = self._where[i]
+            per.setdefault(int(g), []).append((pos, int(r)))
+        return sel, per
+
+    def get_attr(self, attr_name, indices=None):
+        sel, per = self._by_group(indices)
+        out = [None] * len(sel)
+        for g, items in per.items():
+            vals = self.groups[g][0].get_attr(attr_name, [r for _, r in items])
+            for (pos, _), v in zip(items, vals):
+                out[pos] = v
+        return out
+
+    def set_attr(self, attr_name, values, indices=None):
+        raise NotImplementedError('per-env attribute mutation is not supported (configs are fixed at construction)')
+
+    def env_method(self, method_name, method_args=None, method_kwargs=None, indices=None):
+        sel, per = self._by_group(indices)
+        out = [None] * len(sel)
+        for g, items in per.items():
+            env = self.groups[g][0]
+            args = [method_args[pos] for pos, _ in items] if method_args is not None else None
+            kw = [method_kwargs[pos] for pos, _ in items] if method_kwargs is not None else None
+            vals = env.env_method(method_name, args, kw, [r for _, r in items] if len(items) != env.num_envs else None)
+            for (pos, _), v in zip(items, vals):
+                out[pos] = v
+        return out
+
+    def get_env_random_state(self):
+        return [env.get_env_random_state()[0] for env, _ in self.groups]
+
+    def set_env_random_state(self, worker_random_states):
+        for (env, _), st in zip(self.groups, worker_random_states):
+            env.set_env_random_state([st])
+
+    def close_extras(self):
+        for env, _ in self.groups:
+            env.close()

@@ -40,8 +40,41 @@ def test_make_vec_envs_dropin_and_the_train_step_protocol():
     n = 96
     env = make_vec_envs(env_func, None, n, 4, 3)                               # the call of ppo.py:48 (n_processes is moot)
     assert isinstance(env, HipVecEnv) and env.num_envs == n
-    with pytest.raises(NotImplementedError):
-        make_vec_envs(env_func, [{'ctrl_freq': 50}] + [{'ctrl_freq': 25}] * (n - 1), n, 1, 3)
+    # heterogeneous env_configs (upstream: env k = env_func(**env_configs[k])): grouped by identical config, one HipVecEnv per group
+    from safe_control_gym_amd.vec_env import GroupedVecEnv
+    per_env = [dict(randomized_init=False, init_state={'init_x': 0.3, 'init_z': 1.2}) if k % 3 == 0 else
+               (dict(randomized_init=False, episode_len_sec=0.1) if k % 3 == 1 else dict(randomized_init=False)) for k in range(12)]
+    het = make_vec_envs(env_func, per_env, 12, 1, 3)
+    assert isinstance(het, GroupedVecEnv) and het.num_envs == 12 and len(het.groups) == 3
+    o, info = het.reset()
+    assert o.shape == (12, 12) and len(info['n']) == 12
+    np.testing.assert_allclose(o[0::3, 0], 0.3, atol=1e-6); np.testing.assert_allclose(o[0::3, 2], 1.2, atol=1e-6)      # own init_state
+    np.testing.assert_allclose(o[2::3, 0], 0.0, atol=1e-6); np.testing.assert_allclose(o[2::3, 2], 1.0, atol=1e-6)      # the YAML's
+    singles = [make_vec_envs(env_func, [c] * 4, 4, 1, 3) for c in (per_env[0], per_env[1], per_env[2])]
+    for s_env in singles:
+        s_env.reset()
+    rng_h = np.random.default_rng(1)
+    n_trunc_short = 0
+    for t in range(8):
+        a = rng_h.normal(0, 0.2, size=(12, 2))
+        o, r, d, info = het.step(a)
+        for g, s_env in enumerate(singles):                    # every group == a homogeneous batch of that config on the same actions
+            o1, r1, d1, _ = s_env.step(a[g::3])
+            np.testing.assert_array_equal(d[g::3], d1)
+            np.testing.assert_allclose(r[g::3][~d1], r1[~d1], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(o[g::3][~d1], o1[~d1], rtol=1e-6, atol=1e-7)     # (post-reset rows draw per-env-id streams)
+        for k in range(12):
+            if d[k]:
+                assert 'terminal_info' in info['n'][k]
+                n_trunc_short += int(k % 3 == 1 and bool(info['n'][k]['terminal_info'].get('TimeLimit.truncated', False)))
+    assert n_trunc_short >= 4                                  # the 0.1 s (5-step) episodes of group 1 hit THEIR time limit, the others not
+    assert het.get_attr('CTRL_STEPS') == [250, 5, 250] * 4
+    st = het.get_env_random_state(); het.set_env_random_state(st)
+    het.close()
+    for s_env in singles:
+        s_env.close()
+    with pytest.raises(ValueError):                                             # structurally different observations cannot share a batch
+        make_vec_envs(env_func, [{'obs_goal_horizon': 1}] + [{'obs_goal_horizon': 3}] * (n - 1), n, 1, 3)
     env = VecRecordEpisodeStatistics(env, 10)
     env.add_tracker('constraint_violation', 0)
     env.add_tracker('mse', 0, mode='queue')

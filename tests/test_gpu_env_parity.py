@@ -115,7 +115,7 @@ def test_f64_kernels_free_running_vs_oracle(name, specialize):
         gpu._adv = None
         msg = f'{name} t={t}'
         np.testing.assert_array_equal(_np(out.done).astype(bool), done_o, err_msg=msg)
-        mask = 0xFF if 'out_of_bounds' in info else 0x03
+        mask = 0x0F if 'out_of_bounds' in info else 0x03           # (bit4 = ground_contact, an extension: tested on its own below)
         np.testing.assert_array_equal(_np(out.flags).astype(np.uint8) & mask, _flags(info) & mask, err_msg=msg)
         np.testing.assert_allclose(_np(out.reward), rew_o, err_msg=msg, **tol)
         np.testing.assert_allclose(_np(out.obs), obs_o, err_msg=msg, **tol)
@@ -454,3 +454,35 @@ def test_reset_draw_word_layouts(with_normal):
         np.testing.assert_allclose(gpu.get_params(), _params(oracle), rtol=1e-12)
         assert len(np.unique(np.round(oracle.state[:, 2], 6))) == 3           # the choice draw
         gpu.close()
+
+
+def test_ground_plane_flag_marks_the_unmodelled_contact():
+    """base_aviary.py:107,219-220: the reference's world has a ground plane at z = -0.05; Bullet's contact response is not
+    modelled here.  With `done_on_out_of_bound: False` (the config of the quadrotor_2D_adversary fixture) a falling body would
+    pass through it: the step raises bit4 / info['ground_contact'] from the control step on which z <= -0.0375 (plane + the
+    collision cylinder's half height), never before, and not for CartPole."""
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task('quadrotor_2D_track')
+    cfg = dict(cfg, done_on_out_of_bound=False, randomized_init=False, normalized_rl_action_space=False, episode_len_sec=2,
+               init_state={'init_x': 0.0, 'init_z': 0.3}, constraints=None)
+    env = HipVecEnv(env_id, 8, seed=0, dtype=torch.float64, return_numpy=True, **cfg)
+    env.reset()
+    act = np.zeros((8, 2))                                   # motors off: free fall from z = 0.3
+    first = None
+    for t in range(40):
+        obs, rew, done, info = env.step(act)
+        z = obs[:, 2]
+        g = env.out.ground_contact.cpu().numpy()
+        np.testing.assert_array_equal(g, z <= -0.0375)
+        assert ('ground_contact' in info['n'][0]) == bool(g[0])
+        if g.any() and first is None:
+            first = t
+    assert first is not None and 10 < first < 20             # 0.3375 m of free fall: t = sqrt(2 h / g) = 0.26 s = 13 control steps
+    env.close()
+    env_id, cfg = load_task('cartpole_stab')
+    cp = HipVecEnv(env_id, 4, seed=0, return_numpy=False, **cfg)
+    cp.reset_tensors()
+    out = cp.step_tensors(torch.zeros(4, 1, device=cp.device))
+    assert not bool(out.ground_contact.any())
+    cp.close()

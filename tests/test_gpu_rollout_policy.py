@@ -31,8 +31,10 @@ def _setup(task, n, hidden, act, seed=5, override=None):
 @pytest.mark.parametrize('task,hidden,act,override', [('quadrotor_2D_track', 128, 'tanh', None), ('cartpole_stab', 64, 'leaky_relu', None),
                                                       ('quadrotor_3D_track', 128, 'relu', None),
                                                       ('quadrotor_2D_track', 64, 'tanh', STAB6)])     # rows of 24 bytes: no LDS transpose
-def test_fused_rollout_equals_step_by_step(task, hidden, act, override):
-    n, K = 320, 12                                 # 5 waves: a partial workgroup as well
+@pytest.mark.parametrize('epw', ['64', '32'])         # envs per wave: lane = env / lane pair = env (shards <= 32 768 envs by default)
+def test_fused_rollout_equals_step_by_step(task, hidden, act, override, epw, monkeypatch):
+    monkeypatch.setenv('SCG_ROLLOUT_EPW', epw)
+    n, K = 320, 12                                 # 5 / 10 waves: a partial workgroup as well
     env, ref, ppo = _setup(task, n, hidden, act, override=override)
     assert env.spec.obs_dim == (6 if override else env.spec.obs_dim)
     nobs, nu = env.spec.obs_dim, env.spec.nu
@@ -80,6 +82,27 @@ def test_fused_rollout_equals_step_by_step(task, hidden, act, override):
     assert not torch.equal(a1, actb)
     env.close(); ref.close()
 
+
+
+def test_rollout_does_not_depend_on_the_launch_geometry(monkeypatch):
+    """Stochastic rollouts with 64 and with 32 envs per wave are the same rollouts: the noise is a per-env Philox stream, the
+    actor's arithmetic per env is the same MFMA sequence."""
+    outs = []
+    for epw in ('64', '32'):
+        monkeypatch.setenv('SCG_ROLLOUT_EPW', epw)
+        env, ref, ppo = _setup('quadrotor_2D_track', 1000, 128, 'tanh')
+        n, K, nobs, nu = 1000, 40, 12, 2
+        f = dict(device=env.device, dtype=torch.float32)
+        obs, actb, logp, rew = torch.zeros(K + 1, n, nobs, **f), torch.zeros(K, n, nu, **f), torch.zeros(K, n, **f), torch.zeros(K, n, **f)
+        done, flags = torch.zeros(K, n, dtype=torch.uint8, device=env.device), torch.zeros(K, n, dtype=torch.uint8, device=env.device)
+        env.seed(5); env.reset_tensors()
+        env.rollout_policy(ppo._policy_struct(False), K, obs, actb, logp, rew, done, flags)
+        torch.cuda.synchronize()
+        outs.append((obs.clone(), actb.clone(), logp.clone(), rew.clone(), done.clone(), env.get_raw_state() if hasattr(env, 'get_raw_state') else None))
+        env.close(); ref.close()
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
+    assert int(outs[0][4].sum()) > 0                # episodes ended and were reset inside the launch
 
 
 def test_ppo_iteration_and_evaluation_on_the_fused_rollout():
