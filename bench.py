@@ -38,7 +38,7 @@ ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'qua
 KERNEL_NAME = {'quadrotor_2D_track': 'step_kernel<QUAD_2D,float>', 'cartpole_stab': 'step_kernel<CARTPOLE,float>',
                'quadrotor_3D_track': 'step_kernel<QUAD_3D,float>', 'quadrotor_3D_track_disturbed': 'step_kernel<QUAD_3D,float,DIST>'}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILES = ('r02_hbm_traffic.json', 'r01_hbm_traffic.json')
+TRAFFIC_FILES = ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json')
 
 
 def parse():
@@ -255,15 +255,15 @@ def gae_leg(torch):
         rew, v = torch.rand(T, N, device='cuda'), torch.rand(T, N, device='cuda')
         mask = (torch.rand(T, N, device='cuda') > 0.01).float()
         tv, last = torch.rand(T, N, device='cuda'), torch.rand(N, device='cuda')
-        out = (torch.empty_like(rew), torch.empty_like(rew))       # caller-owned outputs: the kernel's own time
+        bufs = (torch.empty_like(rew), torch.empty_like(rew))      # caller-owned outputs: the kernel's own time
         for _ in range(3):
-            gae_returns(rew, v, mask, tv, last, out=out)
+            gae_returns(rew, v, mask, tv, last, out=bufs)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         reps = 50
         ev0.record()
         for _ in range(reps):
-            gae_returns(rew, v, mask, tv, last, out=out)
+            gae_returns(rew, v, mask, tv, last, out=bufs)
         ev1.record()
         torch.cuda.synchronize()
         us = 1e3 * ev0.elapsed_time(ev1) / reps
@@ -466,7 +466,7 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=325
                     'deterministic rollout on a second stream'}
 
 
-def sac_leg(torch, seeds, budget_s, envs=4096, batch=4096, updates_per_step=8, lr=1e-3, warm_up_steps=65536, eval_every=50,
+def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, lr=1e-3, warm_up_steps=65536, eval_every=50,
             buffer=4_000_000):
     """SAC wall-clock-to-reward on BASELINE config #5's env (Quadrotor3D figure-8 tracking, white-noise dynamics disturbance,
     constraint evaluation; `randomized_inertial_prop` OFF — upstream's additive draw doubles the mass and nothing can fly it,

@@ -134,6 +134,7 @@ def source_hash():
         with open(os.path.normpath(os.path.join(CSRC_DIR, name)), 'rb') as f:
             h.update(name.encode() + b'\0' + f.read())
     h.update(CODEGEN_FLAGS.encode())
+    h.update(b'sched:q2=max-ilp,q3dist=iterative-ilp')              # (sched_flags below: part of what a library was built with)
     return int.from_bytes(h.digest()[:8], 'little')
 
 
@@ -260,6 +261,22 @@ def policy_supported(obs_dim, hidden, act_dim, activation):
     return 1 <= obs_dim <= 32 and hidden in (32, 64, 96, 128) and 1 <= act_dim <= 4 and activation in POLICY_ACTS
 
 
+def sched_flags(cfg):
+    """Machine-scheduler strategy per kernel family, measured on MI355X at 65 536 envs (one wave per SIMD: the step is an
+    in-order issue chain, so instruction ORDER is time; same-box A/B in tools/sessions/s39.sh / s40.sh, profiles/r03_summary.md):
+    Quadrotor2D float kernels gain 3 % from LLVM's max-ILP strategy (5.38 -> 5.22 us), the disturbed Quadrotor3D kernels 2.4 % from
+    the iterative-ILP one (11.12 -> 10.86 us; it crashes the compiler on the 2-D kernels, hence the fallback in build_spec);
+    CartPole (-2.6 %) and the plain Quadrotor3D kernels (+-0.5 %) keep the default.  A list of alternatives, first that compiles."""
+    has_dist = any(int(n) > 0 for n in cfg.n_dist) or int(cfg.adversary_channel) >= 0       # (= SCG_SPEC_DIST, scg_kernels.hip)
+    if int(cfg.dtype) != F32:
+        return [[]]
+    if int(cfg.system) == QUAD_2D:
+        return [['-mllvm', '-amdgpu-sched-strategy=max-ilp'], []]
+    if int(cfg.system) == QUAD_3D and has_dist:
+        return [['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'], []]
+    return [[]]
+
+
 def build_spec(cfg, force=False, verbose=False, policy=None):
     """Compile libscg_spec_<hash>.so: the same sources with this task config as compile-time constants
     (policy=(hidden, activation): + the fused policy rollout kernel for that actor shape)."""
@@ -276,13 +293,16 @@ def build_spec(cfg, force=False, verbose=False, policy=None):
            f'-DSCG_SRC_HASH=0x{source_hash():016x}ULL', '-o', so] + os.environ.get('SCG_SPEC_FLAGS', '').split()
     if policy:
         cmd += [f'-DSCG_POLICY_H={int(policy[0])}', f'-DSCG_POLICY_ACT={POLICY_ACTS[policy[1]]}']
-    cmd += srcs
-    if verbose:
-        print(' '.join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise ScgError('hipcc failed (specialised build):\n' + res.stdout + res.stderr)
-    return so
+    alts = [[]] if os.environ.get('SCG_SPEC_FLAGS') else sched_flags(cfg)       # (explicit development flags: nothing added)
+    res = None
+    for extra in alts:
+        full = cmd + extra + srcs
+        if verbose:
+            print(' '.join(full))
+        res = subprocess.run(full, capture_output=True, text=True)
+        if res.returncode == 0:
+            return so
+    raise ScgError('hipcc failed (specialised build):\n' + res.stdout + res.stderr)
 
 
 def lib_for(cfg, specialize='auto', policy=None):

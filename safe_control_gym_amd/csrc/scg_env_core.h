@@ -368,6 +368,64 @@ struct Env {
     int32_t step;      // ctrl_step_counter
     uint32_t episode;
     uint32_t gid;      // global env id (Philox counter word 0)
+    // Initial-state draws of the NEXT episode, computed speculatively inside the integrator of the current control step
+    // (PreDraw below): valid when pre_n > 0, consumed by reset().
+    U4 pre[3];
+    int pre_n;
+};
+
+// Speculative reset draws (specialised float builds, compact initial-state layout, no per-env parameter draws).
+// The auto-reset path of a wave that holds a finished episode is its Philox4x32-10 blocks (~20 quarter-rate 32 x 32
+// multiplies each); the integrator of the same control step is a DEPENDENT chain of packed fp32 instructions that issues
+// every ~7-9 clocks with one wave per SIMD.  The Philox rounds depend on nothing the integrator computes, so they are
+// spread over the unrolled substeps — round r between substeps — where they fill issue slots the chain leaves empty, and
+// the reset path finds its words ready.  Same blocks, same counters (env, episode + 1, 0, tag), same ten rounds: results
+// are bit-identical to rng_words() (tests compare the kernels with the oracle's Philox streams).
+template <int NB>
+struct PreDraw {
+    U4 c[NB];
+    uint32_t k0, k1;
+    int round;                                              // rounds done on every block (0..10)
+    __device__ __forceinline__ void begin(RngKey key, uint32_t gid, uint32_t next_episode) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) c[b] = U4{gid, next_episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b)};
+        k0 = key.k0; k1 = key.k1; round = 0;
+    }
+    __device__ __forceinline__ void one_round() {           // one Philox round on every block (philox4x32_10's loop body)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            uint32_t hi0, lo0, hi1, lo1;
+            mulhilo32(0xD2511F53u, c[b].x, hi0, lo0);
+            mulhilo32(0xCD9E8D57u, c[b].z, hi1, lo1);
+            U4 n;
+            n.x = hi1 ^ c[b].y ^ k0; n.y = lo1; n.z = hi0 ^ c[b].w ^ k1; n.w = lo0;
+            c[b] = n;
+        }
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        ++round;
+    }
+    // After substep k of n (n a multiple of 10, the shipped configs: 20 and 50): one round every n / 10 substeps.  The test
+    // `k % period == period - 1` is a compile-time constant in a loop unrolled by a multiple of the period, so no branch
+    // is emitted; any other n leaves all ten rounds to finish().
+    // `tie`: a live variable of the integrator chain.  It passes through the same (empty) asm statement as the round's words,
+    // which orders substep k -> round -> substep k + 1 for every compiler pass: without it the pure integrator arithmetic is
+    // free to move past the rounds (LLVM then emits all ten rounds in front of the loop, or sinks them into the reset branch).
+    // U: the loop's unroll factor (the in-group index k % U is then a compile-time constant: no branch is emitted).  Within
+    // every group of U substeps floor(10 U / n) rounds are issued, evenly spaced; what is left of the ten runs in finish().
+    template <int U>
+    __device__ __forceinline__ void tick(int k, int n, float& tie) {
+        const int j = k % U, R = 10 * U / n;
+        if (R > 0 && ((j + 1) * R) / U > (j * R) / U) {
+            one_round();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { asm volatile("" : "+v"(tie) : "v"(c[b].x), "v"(c[b].y), "v"(c[b].z), "v"(c[b].w)); }
+        }
+    }
+    __device__ __forceinline__ void finish() {
+#pragma unroll
+        for (int r = 0; r < 10; ++r)
+            if (round < 10) one_round();
+    }
 };
 
 // cos(2 pi u) for u in (0, 1): the Box-Muller angle.  Double: the library cosine of the product, as the oracle
@@ -538,6 +596,21 @@ template <int SYS, typename T, bool DIST>
 struct EnvOps {
     using D = Dims<SYS>;
     using E = Env<SYS, T>;
+    // speculative reset draws inside the integrator (PreDraw): specialised float builds whose reset is exactly the compact
+    // initial-state draw (-DSCG_NO_PREDRAW switches it off: A/B measurements)
+#if defined(SCG_SPEC) && !defined(SCG_NO_PREDRAW)
+    static constexpr bool PRE = sizeof(T) == 4 && !DIST && (SYS == SCG_CARTPOLE || SYS == SCG_QUAD_2D || SYS == SCG_QUAD_3D) && scg_make_spec_cfg<T>().randomized_init != 0 &&
+                                scg_make_spec_cfg<T>().init_compact != 0 && scg_make_spec_cfg<T>().per_env_params == 0 &&
+                                scg_make_spec_cfg<T>().auto_reset != 0 && scg_make_spec_cfg<T>().substeps % 10 == 0;
+#else
+    static constexpr bool PRE = false;
+#endif
+    static constexpr int PRE_NB = (Dims<SYS>::NX + 3) / 4;
+#ifdef SCG_SPEC
+    static constexpr int PRE_U2 = scg_make_spec_cfg<T>().substeps > 0 ? scg_make_spec_cfg<T>().substeps : 1;   // the 2-D loop is fully unrolled
+#else
+    static constexpr int PRE_U2 = 1;
+#endif
     static constexpr bool IS_QUAD = (SYS != SCG_CARTPOLE);
 
     // Split load: the raw state / counters are requested before the LDS staging barrier (P = global block),
@@ -551,6 +624,7 @@ struct EnvOps {
         e.step = slot_in<int32_t>(ws, P.i.step_off, i).load();
         e.episode = slot_in<uint32_t>(ws, P.i.episode_off, i).load();
         e.gid = (uint32_t)(P.i.env_id_offset + i);
+        e.pre_n = 0;
     }
     __device__ static __forceinline__ void load_params(const PV<T>& P, int i, E& e) {
         const size_t N = (size_t)P.i.num_envs;
@@ -610,6 +684,9 @@ struct EnvOps {
     __device__ static __forceinline__ void reset(const PV<T>& P, int i, E& e, RngKey key, T* st_out = nullptr) {
         e.episode += 1u;
         e.step = 0;
+        const int pre_n_in = e.pre_n;
+        e.pre_n = 0;                                        // (the words belong to THIS reset only; callers that reset without a step see 0)
+
         if constexpr (DIST) {
             // disturbance offsets (ImpulseDisturbance.reset / StepDisturbance.reset), variable index 4*ch + k
 #ifdef SCG_SPEC
@@ -658,7 +735,8 @@ SCG_DIST_UNROLL
         if (P.c.randomized_init && P.c.init_compact) {
 #pragma unroll
             for (int b = 0; b < (D::NX + 3) / 4; ++b) {
-                U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));
+                U4 w = b < pre_n_in ? e.pre[b < 3 ? b : 0]           // drawn inside the integrator of this control step (PreDraw)
+                                   : rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (4 * b + k < D::NX)
@@ -1051,10 +1129,13 @@ SCG_BOX_UNROLL
                     const f2 diag = {a22, a11};
                     const f2 c1 = {(float)(1.0 / 120), (float)(-1.0 / 720)}, c0 = {(float)(-1.0 / 6), (float)(1.0 / 24)};
                     const f2 cone = {1.0f, -0.5f};
+                    PreDraw<PRE_NB> pd;
+                    if constexpr (PRE) pd.begin(key, e.gid, e.episode + 1u);
 #ifdef SCG_SPEC
 #pragma unroll 10
 #endif
                     for (; k0 < P.c.substeps; ++k0) {
+                        if constexpr (PRE) { float tie = sc.x; pd.template tick<10>(k0, P.c.substeps, tie); sc.x = tie; }
                         const float a12 = ml * sc.y;
                         const float b1 = force + ml * vel.y * vel.y * sc.x;
                         const float b2 = mgl * sc.x;
@@ -1076,6 +1157,12 @@ SCG_BOX_UNROLL
                         sc = __builtin_elementwise_fma(sc, (f2)cd, rot);
                     }
                     sn = sc.x; cs = sc.y; xd = vel.x; thd = vel.y; x = pos.x; th = pos.y;
+                    if constexpr (PRE) {
+                        pd.finish();
+#pragma unroll
+                        for (int b = 0; b < PRE_NB; ++b) e.pre[b] = pd.c[b];
+                        e.pre_n = PRE_NB;
+                    }
                 }
             }
             for (int k = k0; k < P.c.substeps; ++k) {
@@ -1159,10 +1246,13 @@ SCG_BOX_UNROLL
                         const f2 fm = {fxm, fzm};
                         const f2 c1 = {(float)(1.0 / 120), (float)(-1.0 / 720)}, c0 = {(float)(-1.0 / 6), (float)(1.0 / 24)};
                         const f2 cone = {1.0f, -0.5f};
+                        PreDraw<PRE_NB> pd;
+                        if constexpr (PRE) pd.begin(key, e.gid, e.episode + 1u);
 #ifdef SCG_SPEC
 #pragma unroll          // constant trip count: straight-line code, no loop branches (a taken branch costs ~25 clocks)
 #endif
                         for (; k0 < P.c.substeps; ++k0) {
+                            if constexpr (PRE) { float tie = sc.x; pd.template tick<PRE_U2>(k0, P.c.substeps, tie); sc.x = tie; }
                             w = m_clamp(w + dwk, -vmax, vmax);
                             const float d = h * w, d2 = d * d;
                             f2 pq = __builtin_elementwise_fma((f2)d2, c1, c0);
@@ -1179,6 +1269,12 @@ SCG_BOX_UNROLL
                             sc = __builtin_elementwise_fma(sc, (f2)cd, rot);
                         }
                         sn = sc.x; cs = sc.y; vx = v2.x; vz = v2.y; x = p2.x; z = p2.y;
+                        if constexpr (PRE) {
+                            pd.finish();
+#pragma unroll
+                            for (int b = 0; b < PRE_NB; ++b) e.pre[b] = pd.c[b];
+                            e.pre_n = PRE_NB;
+                        }
                     }
                 }
                 for (int k = k0; k < P.c.substeps; ++k) {
@@ -1255,10 +1351,13 @@ SCG_BOX_UNROLL
                         const f2 c1 = {(float)(1.0 / 120), (float)(-1.0 / 720)}, c0 = {(float)(-1.0 / 6), (float)(1.0 / 24)};
                         const f2 cone = {1.0f, -0.5f};
                         const float hh2 = hh * hh;
+                        PreDraw<PRE_NB> pd;
+                        if constexpr (PRE) pd.begin(key, e.gid, e.episode + 1u);
 #ifdef SCG_SPEC
 #pragma unroll SCG_Q3_UNROLL
 #endif
                         for (; k0 < P.c.substeps; ++k0) {
+                            if constexpr (PRE) { float tie = A.x; pd.template tick<SCG_Q3_UNROLL>(k0, P.c.substeps, tie); A.x = tie; }
                             const f2 A2 = A + A, B2 = B + B;
                             const f2 P1 = A2 * A;                       // (2xx, 2yy)
                             const f2 P2 = A2 * B.xx;                    // (2xz, 2yz)
@@ -1348,6 +1447,12 @@ SCG_BOX_UNROLL
                             const float inv = __builtin_amdgcn_rsqf(S.x + S.y);
                             A = An * (f2)inv;
                             B = Bn * (f2)inv;
+                        }
+                        if constexpr (PRE) {
+                            pd.finish();
+#pragma unroll
+                            for (int b = 0; b < PRE_NB; ++b) e.pre[b] = pd.c[b];
+                            e.pre_n = PRE_NB;
                         }
                         q[0] = A.x; q[1] = A.y; q[2] = B.x; q[3] = B.y;
                         w[0] = W.x; w[1] = W.y; w[2] = w2;

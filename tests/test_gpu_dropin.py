@@ -68,7 +68,7 @@ def test_make_vec_envs_dropin_and_the_train_step_protocol():
                 assert 'terminal_info' in info['n'][k]
                 n_trunc_short += int(k % 3 == 1 and bool(info['n'][k]['terminal_info'].get('TimeLimit.truncated', False)))
     assert n_trunc_short >= 4                                  # the 0.1 s (5-step) episodes of group 1 hit THEIR time limit, the others not
-    assert het.get_attr('CTRL_STEPS') == [250, 5, 250] * 4
+    assert het.get_attr('CTRL_STEPS') == [10, 5, 10] * 4                # (env_func's own episode_len_sec is 0.2 s)
     st = het.get_env_random_state(); het.set_env_random_state(st)
     het.close()
     for s_env in singles:

@@ -6,7 +6,7 @@ SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
 DST = os.path.join(ROOT, 'profiles')
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 traffic = {}
-for extra in ('ppo_iteration', 'sequence'):
+for extra in ('ppo_iteration', 'ppo_iteration_65536', 'sac_iteration', 'sequence'):
     stats = glob.glob(f'{SRC}/{extra}/**/*kernel_stats.csv', recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
