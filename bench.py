@@ -386,7 +386,7 @@ def shipped_ppo_score(torch, eval_env, tag='quadrotor_2D_track', hidden=128, act
             'episodes': evals * eval_env.num_envs}
 
 
-def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=32512, lr=2e-3, target_kl=0.03, epochs=4, rollout_steps=32,
+def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=None, lr=2e-3, target_kl=0.03, epochs=None, rollout_steps=32,
             target=None):
     """PPO wall-clock until the deterministic-policy evaluation reaches the reference reward on BASELINE config #3's batch
     (65 536 envs per GPU): fused rollout, fused MFMA update; every iteration's weights are evaluated on a second stream
@@ -398,6 +398,12 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=325
     from safe_control_gym_amd.ppo import PPO, AsyncEvaluator, PPOConfig
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
+    # re-tuned for the batch (probes: tools/sessions/s43.sh, profiles/r03_ppo_probes_65536.txt): at 65 536 envs
+    # 2 epochs x 32 minibatches of 127 x 512 rows reach the target in 1.4 s median where 4 x 64 of 127 x 256 need 2.2-2.3 s
+    if minibatch is None:
+        minibatch = 65024 if envs >= 65536 else 32512
+    if epochs is None:
+        epochs = 2 if envs >= 65536 else 4
     env_id, cfg = load_task('quadrotor_2D_track')
     pol = (128, 'tanh')
     ev_cfg = eval_task_config(cfg, EVAL_INIT_RAND_Q2)

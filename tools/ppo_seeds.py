@@ -15,12 +15,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--envs', type=int, default=16384)
-    ap.add_argument('--minibatch', type=int, default=32512)
+    ap.add_argument('--minibatch', type=int, default=None)
     ap.add_argument('--seeds', type=int, default=6)
     ap.add_argument('--budget', type=float, default=10.0)
     ap.add_argument('--lr', type=float, default=2e-3)
     ap.add_argument('--target-kl', type=float, default=0.03)
-    ap.add_argument('--epochs', type=int, default=4)
+    ap.add_argument('--epochs', type=int, default=None)
     ap.add_argument('--rollout-steps', type=int, default=32)
     a = ap.parse_args()
     import torch
