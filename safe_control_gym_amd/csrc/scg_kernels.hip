@@ -878,7 +878,13 @@ static int launch_gae(void* rew, const void* v, const void* mask, const void* te
                       int Tn, int N, double gamma, double lam, int use_gae, hipStream_t st) {
     // >= 16 waves' worth of envs: the per-env walk already fills the chip with coalesced traffic;
     // below that, parallelise over time with the wave-level segmented scan.
-    if (N >= 1024 || Tn < 64) {
+    constexpr int CH = 8;
+    const int S = (Tn + CH - 1) / CH;
+    if (N >= 1024 && S >= 2 && S <= 16) {
+        // many envs, a collector's horizon: CH time steps per thread, one memory round trip, S x the waves (scg_gae_kernels.h (a'))
+        gae_seg_kernel<T, CH><<<dim3((N + 63) / 64), dim3(64, S), (size_t)S * 4 * 64 * sizeof(T), st>>>(
+            (T*)rew, (const T*)v, (const T*)mask, (const T*)term, (const T*)last, (T*)ret, (T*)adv, Tn, N, (T)gamma, (T)lam, use_gae);
+    } else if (N >= 1024 || Tn < 64) {
         const int grid = (N + GAE_BLOCK - 1) / GAE_BLOCK;
         gae_env_kernel<T><<<dim3(grid), dim3(GAE_BLOCK), 0, st>>>((T*)rew, (const T*)v, (const T*)mask, (const T*)term,
                                                              (const T*)last, (T*)ret, (T*)adv, Tn, N, (T)gamma, (T)lam, use_gae);
