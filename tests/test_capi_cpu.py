@@ -175,3 +175,25 @@ def test_rk4_mode_of_the_oracle_is_the_analytic_prior_model():
         spec = EnvSpec(env_id, cfg)
         c, _ = spec.to_c_config(4, 1, 0)
         assert c.integrator == 1 and c.substeps == 1 and abs(c.pyb_dt - spec.CTRL_TIMESTEP) < 1e-15
+
+
+def test_staged_reference_python_stays_out_of_history_and_out_of_the_product():
+    """tools/stage_reference.py copies the reference's Python to oracle/_ref/reference so that the GPU box can run the reference's
+    own PPO / SAC classes on HipVecEnv: untracked scratch (git-ignored like the built oracle library, not gpurun-ignored), read
+    only by the checker side."""
+    import subprocess
+    ignore = open(os.path.join(ROOT, '.gitignore')).read().split()
+    assert 'oracle/_ref/' in ignore
+    gpurunignore = os.path.join(ROOT, '.gpurunignore')
+    if os.path.exists(gpurunignore):
+        assert 'oracle/_ref' not in open(gpurunignore).read()
+    if os.path.isdir(os.path.join(ROOT, '.git')):
+        tracked = subprocess.run(['git', 'ls-files', 'oracle/_ref'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        assert tracked == '', tracked
+    for d, _, files in os.walk(os.path.join(ROOT, 'safe_control_gym_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(d, f)).read()
+                assert 'oracle/_ref' not in src and 'reference_root' not in src and 'ref_stubs' not in src, os.path.join(d, f)
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'ref_stubs' not in bench and 'reference_root' not in bench and '/root/reference' not in bench
