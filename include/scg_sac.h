@@ -68,7 +68,14 @@ typedef struct {
     void* d_workspace;              /* scg_sac_workspace_bytes(batch) bytes */
     float* d_stats;                 /* [4] policy_loss, critic_loss, entropy_loss, mean log pi of this step */
     float* d_stats_acc;             /* [4] nullable: running sums over calls */
+    /* ---- data-parallel use: which part of the step this call enqueues (0 = all).  The two gradient exchanges of a
+     * data-parallel step sit between the parts: SCG_SAC_ACTOR_GRAD leaves d(policy_loss)/d(actor) in d_grad[0, n_actor) and the
+     * temperature's gradient in d_grad[n_params]; SCG_SAC_CRITIC_GRAD applies the actor / temperature step from d_grad and leaves
+     * d(critic_loss)/d(q1, q2) in d_grad[n_actor, n_params); SCG_SAC_FINISH applies the critic step, the Polyak update and advances
+     * the counters.  All-reduce (mean) d_grad between the calls; every rank samples its own minibatch (seed per rank). */
+    int32_t phases;
 } scg_sac_args;
+enum { SCG_SAC_ACTOR_GRAD = 1, SCG_SAC_CRITIC_GRAD = 2, SCG_SAC_FINISH = 4, SCG_SAC_ALL = 7 };
 
 void scg_sac_shape(int32_t* obs_dim, int32_t* hidden, int32_t* act_dim, int32_t* activation);
 size_t scg_sac_workspace_bytes(int batch);

@@ -22,7 +22,10 @@ class SacArgs(C.Structure):
                 ('actor_lr', C.c_float), ('critic_lr', C.c_float), ('entropy_lr', C.c_float), ('use_entropy_tuning', C.c_int32),
                 ('target_entropy', C.c_float), ('act_low', C.c_float * 4), ('act_high', C.c_float * 4), ('seed', C.c_uint64),
                 ('d_counter', C.c_void_p), ('d_idx_in', C.c_void_p), ('d_eps_in', C.c_void_p), ('d_eps_next_in', C.c_void_p),
-                ('d_workspace', C.c_void_p), ('d_stats', C.c_void_p), ('d_stats_acc', C.c_void_p)]
+                ('d_workspace', C.c_void_p), ('d_stats', C.c_void_p), ('d_stats_acc', C.c_void_p), ('phases', C.c_int32)]
+
+
+ACTOR_GRAD, CRITIC_GRAD, FINISH, ALL = 1, 2, 4, 7
 
 
 def supported(obs_dim, hidden, act_dim, activation):

@@ -501,6 +501,8 @@ __device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay) {
 struct ReduceArgs {
     const float* partials; int n_part; scg_mlp_layout lay[2]; float* grad;
     float* stat_out;            // [2 * gridDim.y]: STAT + 0, STAT + 1 of each network
+    int alpha_slot;             // >= 0 (actor reduce): grad[alpha_slot] = d entropy_loss / d log_alpha = -(mean log pi + target_entropy)
+    float target_entropy;
 };
 template <int NIN, int NOUT>
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
@@ -521,7 +523,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     const int d = dest_of<NIN, NOUT>(k, R.lay[net]);
     if (d >= 0) R.grad[d] = s;
     else if (d == -2) R.stat_out[2 * net] = s;
-    else if (d == -3) R.stat_out[2 * net + 1] = s;
+    else if (d == -3) {
+        R.stat_out[2 * net + 1] = s;
+        // entropy_loss = -mean(log_alpha (log pi + target_entropy)) (sac_utils.py:124-126); in the gradient vector so that a
+        // data-parallel all-reduce of d_grad carries it
+        if (R.alpha_slot >= 0) R.grad[R.alpha_slot] = -(s + R.target_entropy);
+    }
 }
 
 // torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8) on elements [lo, hi) of the flat vectors; optionally the temperature
@@ -542,9 +549,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs A) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;            // one element per thread: Adam (if in [lo, hi)), then its soft update
     if (i >= A.lo && i < A.hi) adam_one(A.p[i], A.g[i], A.m[i], A.v[i], A.lr, A.steps[A.step_slot] + 1.0f);
     if (A.alpha_on && i == 0) {
-        // entropy_loss = -mean(log_alpha (log pi + target_entropy)) (sac_utils.py:124-126): d/d log_alpha = -(mean log pi + H*)
-        const int k = A.n_params;
-        adam_one(A.p[k], -(A.actor_stat[1] + A.target_entropy), A.m[k], A.v[k], A.lr_alpha, A.steps[2] + 1.0f);
+        const int k = A.n_params;                           // (gradient written by the actor's reduce_kernel)
+        adam_one(A.p[k], A.g[k], A.m[k], A.v[k], A.lr_alpha, A.steps[2] + 1.0f);
     }
     if (A.target && i < A.n_polyak) A.target[i] = (1.0f - A.tau) * A.target[i] + A.tau * A.p[i];
 }
@@ -627,6 +633,8 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     for (int j = 0; j < 4; ++j) { Cm.low[j] = a->act_low[j]; Cm.high[j] = a->act_high[j]; }
     Cm.k0 = (uint32_t)a->seed; Cm.k1 = (uint32_t)(a->seed >> 32); Cm.counter = a->d_counter;
     float* stat = W + w.stat;
+    const int phases = a->phases == 0 ? SCG_SAC_ALL : a->phases;
+    if (phases & SCG_SAC_ACTOR_GRAD) {
     // 0. minibatch rows; remember log_alpha as the policy loss sees it (entropy_loss is reported with that value)
     sample_kernel<<<dim3((B + 255) / 256), dim3(256), 0, st>>>(idx, a->d_ring_size, B, a->d_idx_in, Cm.k0, Cm.k1, a->d_counter);
     HIP_TRY(hipMemcpyAsync(W + w.la_before, a->d_params + a->n_params, sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -638,8 +646,11 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     actor_grad_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, W + w.eps, W + w.qpi, W + w.dqda, W + w.partials);
     {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->actor; R.lay[1] = a->actor; R.grad = a->d_grad; R.stat_out = stat;
+        R.alpha_slot = a->n_params; R.target_entropy = a->target_entropy;
         reduce_kernel<NOBS, NA><<<dim3((Part<NOBS, NA>::END + 63) / 64, 1), dim3(256), 0, st>>>(R);
     }
+    }
+    if (phases & SCG_SAC_CRITIC_GRAD) {
     // 4. actor (+ temperature) step
     {
         AdamArgs A{a->d_params, a->d_grad, a->d_m, a->d_v, 0, a->n_actor, a->actor_lr, a->d_steps, 0,
@@ -654,8 +665,11 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     q_kernel<2><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_params, a->q1, a->q2, Cm, nullptr, W + w.qt, W + w.logp_next, nullptr, nullptr, W + w.partials);
     {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->q1; R.lay[1] = a->q2; R.grad = a->d_grad; R.stat_out = stat + 2;
+        R.alpha_slot = -1; R.target_entropy = 0.0f;
         reduce_kernel<NQ, 1><<<dim3((Part<NQ, 1>::END + 63) / 64, 2), dim3(256), 0, st>>>(R);
     }
+    }
+    if (phases & SCG_SAC_FINISH) {
     // 8. critic step + Polyak averaging of every actor-critic parameter
     {
         AdamArgs A{a->d_params, a->d_grad, a->d_m, a->d_v, a->n_actor, a->n_params, a->critic_lr, a->d_steps, 1,
@@ -665,6 +679,7 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     {
         FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
         finish_kernel<<<dim3(1), dim3(64), 0, st>>>(F);
+    }
     }
     HIP_TRY(hipGetLastError());
     return 0;

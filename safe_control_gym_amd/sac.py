@@ -181,7 +181,8 @@ class SACAgent:
         # of ~100 PyTorch kernels.  Chosen here, visibly: single-rank GPU runs of shapes the library serves.
         from safe_control_gym_amd import _sac
         self.obs_dim, self.act_dim = obs_dim, act_dim
-        self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
+        self.use_fused = (torch.device(device).type == 'cuda' and bool(cfg.extra.get('cuda_graphs', True))
+                          and bool(cfg.extra.get('fused_update', True))
                           and _sac.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._flat = self._flatten(low, high) if self.use_fused else None
         self._fused = None
@@ -258,11 +259,26 @@ class SACAgent:
             a.act_low[j], a.act_high[j] = fl['low'][j], fl['high'][j]
         return {'D': D, 'args': a, 'ws': ws, 'stats': stats, 'acc': acc, 'C': C, 'keep': (idx, eps, eps_next, buffer)}
 
-    def _fused_step(self, F):
-        """Enqueue ONE gradient step on the current stream."""
+    def _fused_step(self, F, phases=0):
+        """Enqueue ONE gradient step (or the given part of it, scg_sac.h: SCG_SAC_*) on the current stream."""
         from safe_control_gym_amd import _sac
         st = F['C'].c_void_p(torch.cuda.current_stream(self._flat['p'].device).cuda_stream)
+        F['args'].phases = int(phases)
         _sac.check(F['D'], F['D'].scg_sac_update(F['C'].byref(F['args']), st))
+
+    def _fused_step_dp(self, F):
+        """One data-parallel gradient step: every rank samples its own minibatch; the actor's (+ temperature's) gradient and
+        the critics' gradient are averaged over the ranks where sac_utils.py's update would call backward() — two all-reduces of
+        the flat gradient vector per step (RCCL; latency-bound at 246 KB), everything else stays the fused kernels."""
+        from safe_control_gym_amd import _sac
+        g, world = self._flat['g'], parallel.world_size()
+        self._fused_step(F, _sac.ACTOR_GRAD)
+        parallel.all_reduce_sum_(g)
+        g.div_(world)
+        self._fused_step(F, _sac.CRITIC_GRAD)
+        parallel.all_reduce_sum_(g)
+        g.div_(world)
+        self._fused_step(F, _sac.FINISH)
 
     def _update_fused(self, buffer, batch_size, n_updates):
         if batch_size % 32:
@@ -273,6 +289,12 @@ class SACAgent:
         F = self._fused
         F['acc'].zero_()
         dev = self._flat['p'].device
+        if parallel.world_size() > 1:               # collectives between the parts of a step: launched eagerly, not captured
+            with torch.cuda.device(dev):
+                for _ in range(n_updates):
+                    self._fused_step_dp(F)
+            st = (F['acc'] / n_updates).tolist()
+            return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
         g = F['graphs'].get(n_updates)
         if g is None:                               # n_updates steps as one HIP graph (13 launches each: host-launch bound otherwise)
             with torch.cuda.device(dev):

@@ -100,3 +100,70 @@ def test_train_ppo_two_ranks_stay_in_lock_step(tmp_path):
     # and the weights moved: a rank that skipped the optimiser would also be "in lock-step"
     torch.testing.assert_close(a['init_params'], b['init_params'], rtol=0, atol=0)
     assert (a['params'] - a['init_params']).abs().max() > 1e-4
+
+
+def _sac_dp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    low, high = -torch.ones(4, device=dev), torch.ones(4, device=dev)
+    torch.manual_seed(100 + rank)                       # different local init: rank 0's weights are broadcast at construction
+    ag = SACAgent(24, 4, low, high, SACConfig(hidden_dim=128, activation='relu', use_entropy_tuning=True), dev)
+    assert ag.use_fused and not ag.use_graphs
+    init = {k: v.clone().cpu() for k, v in ag.ac.state_dict().items()}
+    cap, B = 4096, 1024
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)         # noqa: E731
+    data = dict(obs=r(cap, 24), act=torch.tanh(r(cap, 4)), rew=r(cap), next_obs=r(cap, 24), mask=(torch.rand(cap, device=dev, generator=g) > 0.05).float())
+    buf = DeviceReplay(cap, 24, 4, dev)
+    buf.push(data['obs'], data['act'], data['rew'], data['next_obs'], data['mask'])
+    steps = []
+    for _ in range(2):
+        idx = torch.randint(0, cap, (B,), device=dev, generator=g).to(torch.int32)
+        eps, eps2 = r(B, 4), r(B, 4)
+        F = ag._fused_args(buf, B, idx=idx, eps=eps, eps_next=eps2)
+        ag._fused_step_dp(F)
+        torch.cuda.synchronize()
+        steps.append({'idx': idx.cpu(), 'eps': eps.cpu(), 'eps2': eps2.cpu()})
+    torch.save({'init': init, 'params': ag._flat['p'].cpu(), 'targ': ag._flat['targ'].cpu(), 'data': {k: v.cpu() for k, v in data.items()},
+                'steps': steps, 'adam_steps': ag._flat['steps'].cpu()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_sac_step_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
+    """scg_sac_update split at its two gradient exchanges (SCG_SAC_ACTOR_GRAD / CRITIC_GRAD / FINISH, sac.py::_fused_step_dp):
+    two ranks on one GPU, each with its own replay shard, minibatch and noise, the flat gradient all-reduced (gloo here, RCCL
+    on a node) — both ranks end with the same parameters, and those are the parameters ONE process reaches on the joint
+    minibatch (mean over 2 B = mean of the per-rank means)."""
+    import torch.multiprocessing as mp
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    mp.spawn(_sac_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(str(tmp_path / f'rank{r}.pt')) for r in range(2))
+    assert torch.equal(a['params'], b['params']) and torch.equal(a['targ'], b['targ'])              # lock-step
+    assert a['adam_steps'].tolist() == [2.0, 2.0, 2.0]
+    dev = torch.device('cuda', 0)
+    low, high = -torch.ones(4, device=dev), torch.ones(4, device=dev)
+    one = SACAgent(24, 4, low, high, SACConfig(hidden_dim=128, activation='relu', use_entropy_tuning=True), dev)
+    one.ac.load_state_dict(a['init']); one.ac_targ.load_state_dict(a['init'])
+    cap = a['data']['obs'].shape[0]
+    buf = DeviceReplay(2 * cap, 24, 4, dev)
+    for d in (a, b):
+        t = {k: v.to(dev) for k, v in d['data'].items()}
+        buf.push(t['obs'], t['act'], t['rew'], t['next_obs'], t['mask'])
+    for k in range(2):
+        idx = torch.cat([a['steps'][k]['idx'], b['steps'][k]['idx'] + cap]).to(dev)
+        eps = torch.cat([a['steps'][k]['eps'], b['steps'][k]['eps']]).to(dev).contiguous()
+        eps2 = torch.cat([a['steps'][k]['eps2'], b['steps'][k]['eps2']]).to(dev).contiguous()
+        F = one._fused_args(buf, idx.numel(), idx=idx, eps=eps, eps_next=eps2)
+        one._fused_step(F)
+    torch.cuda.synchronize()
+    p1, p2 = one._flat['p'].cpu(), a['params']
+    assert (p1 - p2).abs().max() <= 2.1e-3 and (p1 - p2).abs().mean() <= 2e-5, ((p1 - p2).abs().max(), (p1 - p2).abs().mean())
+    assert (one._flat['targ'].cpu() - a['targ']).abs().max() <= 1e-4
+    init_flat_moved = (p2[:-1] - one._flat['p'].cpu()[:-1]).abs().max() < 1.0 and (a['params'] - b['params']).abs().max() == 0
+    assert init_flat_moved
