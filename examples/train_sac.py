@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--max-env-steps', type=float, default=1e8)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--quiet', action='store_true')
+    ap.add_argument('--save-final', default=None, help='write <path>.rank<r>.pt: final flat parameters of this rank (tests: ranks stay in lock-step)')
     args = ap.parse_args()
     rank, world = parallel.init_distributed()
     env_id, cfg = load_task(args.task)
@@ -40,11 +41,19 @@ def main():
                      warm_up_steps=args.warm_up_steps, train_interval=args.envs * world, max_buffer_size=args.buffer,
                      extra={'updates_per_step': args.updates_per_step})
     sac = SAC(env, scfg, seed=args.seed)
+    flat = lambda: torch.cat([p.detach().reshape(-1) for p in sac.agent.ac.parameters()]).cpu()      # noqa: E731
+    init_params = flat()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     it, ep_n, ep_ret = 0, 0.0, 0.0
     last_log = t0
-    while sac.total_steps < args.max_env_steps and time.perf_counter() - t0 < args.max_seconds:
+    while True:
+        # the gradient exchange sits inside train_step: every rank must leave the loop on the same iteration — rank 0 decides
+        stop = torch.tensor([1.0 if (sac.total_steps >= args.max_env_steps or time.perf_counter() - t0 >= args.max_seconds) else 0.0],
+                            device=env.device)
+        parallel.broadcast_(stop, 0)
+        if stop.item() > 0:
+            break
         res = sac.train_step()
         it += 1
         d = env.out.done.to(torch.float32)
@@ -57,6 +66,9 @@ def main():
             ep_n, ep_ret = 0.0, 0.0
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if args.save_final:
+        torch.save({'params': flat(), 'init_params': init_params, 'env_id_offset': env.env_id_offset, 'vector_steps': it,
+                    'fused_update': bool(sac.agent.use_fused), 'first_obs': sac.obs[:8].cpu()}, f'{args.save_final}.rank{rank}.pt')
     if rank == 0:
         print(json.dumps({'summary': True, 'task': args.task, 'n_gpus': world, 'envs_per_gpu': args.envs, 'vector_steps': it,
                           'env_steps': sac.total_steps, 'wall_clock_s': wall, 'env_steps_per_s_incl_learning': sac.total_steps / wall,

@@ -102,6 +102,21 @@ def test_train_ppo_two_ranks_stay_in_lock_step(tmp_path):
     assert (a['params'] - a['init_params']).abs().max() > 1e-4
 
 
+def test_train_sac_two_ranks_stay_in_lock_step(tmp_path):
+    """examples/train_sac.py (BASELINE config #5's shape: SAC, env shards, gradient all-reduce) launched like the driver launches
+    bench.py, two ranks on one GPU: the fused data-parallel step keeps the ranks' weights bit-identical while their env shards
+    and replay shards differ; the loop ends on the same iteration on both ranks (rank 0's stop flag)."""
+    base = str(tmp_path / 'sac')
+    _torchrun(['examples/train_sac.py', '--envs', '512', '--batch', '1024', '--updates-per-step', '2', '--warm-up-steps', '2048', '--buffer',
+               '100000', '--max-env-steps', str(24 * 2 * 512), '--max-seconds', '1e9', '--quiet', '--save-final', base], {'SCG_DIST_BACKEND': 'gloo'})
+    a, b = (torch.load(f'{base}.rank{r}.pt') for r in range(2))
+    assert a['fused_update'] and b['fused_update'] and a['vector_steps'] == b['vector_steps'] == 24
+    assert (a['env_id_offset'], b['env_id_offset']) == (0, 512) and not torch.equal(a['first_obs'], b['first_obs'])
+    torch.testing.assert_close(a['params'], b['params'], rtol=0, atol=0)
+    torch.testing.assert_close(a['init_params'], b['init_params'], rtol=0, atol=0)
+    assert (a['params'] - a['init_params']).abs().max() > 1e-4
+
+
 def _sac_dp_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
