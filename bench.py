@@ -473,14 +473,18 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
 
 
 def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, lr=1e-3, warm_up_steps=65536, eval_every=50,
-            buffer=4_000_000):
+            buffer=4_000_000, world=1, rank=0):
     """SAC wall-clock-to-reward on BASELINE config #5's env (Quadrotor3D figure-8 tracking, white-noise dynamics disturbance,
     constraint evaluation; `randomized_inertial_prop` OFF — upstream's additive draw doubles the mass and nothing can fly it,
     DESIGN §7), sac.py:162-335 semantics on the HIP engine.  Target = the score of the reference's SHIPPED SAC model
     (examples/rl/models/sac/sac_model_quadrotor_3D_track.pt, actor committed as tests/golden/sac_actor_quadrotor_3D_track.npz)
     under the same evaluation protocol as the PPO leg (EVAL_ENVS distinct randomised-init episodes per evaluation).  The
-    evaluations run inside the clock on the training stream, every `eval_every` vector steps."""
+    evaluations run inside the clock on the training stream, every `eval_every` vector steps.
+    With several ranks (BASELINE config #5 is SAC on 8 GPUs): `envs` envs and one replay shard per rank, the fused step's two
+    gradient all-reduces per gradient step (sac.py::_fused_step_dp); every rank evaluates the same weights on the same eval
+    seeds, rank 0's clock decides when the loop ends."""
     import numpy as np
+    from safe_control_gym_amd import parallel
     from safe_control_gym_amd.ppo import evaluate
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.sac import SAC, MLPActorCritic, SACConfig
@@ -507,15 +511,21 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
     target = sum(e['ep_return'] for e in evs) / len(evs)
     first, both, best_all, steps_all, grads_all, rate = [], [], [], [], [], []
     for seed in range(1, seeds + 1):
-        env = HipVecEnv(env_id, envs, seed=seed, return_numpy=False, **cfg)
-        scfg = SACConfig(hidden_dim=128, activation='relu', train_batch_size=batch, actor_lr=lr, critic_lr=lr, warm_up_steps=warm_up_steps,
-                         train_interval=envs, max_buffer_size=buffer, extra={'updates_per_step': updates_per_step})
+        env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, **cfg)
+        scfg = SACConfig(hidden_dim=128, activation='relu', train_batch_size=batch, actor_lr=lr, critic_lr=lr, warm_up_steps=warm_up_steps * world,
+                         train_interval=envs * world, max_buffer_size=buffer, extra={'updates_per_step': updates_per_step})
         sac = SAC(env, scfg, seed=seed)
         det = Det(sac.agent.ac)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         t_first, t_both, best, it, streak, n_grad = None, None, -1e30, 0, 0, 0
-        while time.perf_counter() - t0 < budget_s:
+        finished = False
+        while True:
+            go = torch.tensor([1.0 if (time.perf_counter() - t0 < budget_s and not finished) else 0.0], device=env.device)
+            if world > 1:                               # rank 0's clock: every rank leaves on the same iteration
+                parallel.broadcast_(go, 0)
+            if go.item() == 0:
+                break
             res = sac.train_step()
             n_grad += int(res.get('updates', 0))
             it += 1
@@ -529,7 +539,7 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
                     t_first = el
                 if streak >= 2:
                     t_both = el
-                    break
+                    finished = True                     # (leaves at the top of the next iteration, together with the other ranks)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         first.append(t_first); both.append(t_both); best_all.append(best); steps_all.append(sac.total_steps); grads_all.append(n_grad)
@@ -543,7 +553,7 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
             'shipped_model_eval': {'returns': [e['ep_return'] for e in evs], 'mean_length': sum(e['ep_length'] for e in evs) / len(evs)},
             'eval_protocol': f'{EVAL_ENVS} distinct randomised-init episodes per evaluation (x, y, z +-0.5, angles +-0.1, rates +-0.01), '
                              f'deterministic policy, every {eval_every} vector steps inside the clock',
-            'envs': envs, 'seeds': list(range(1, seeds + 1)), 'wall_clock_to_first_hit_s': first, 'wall_clock_to_two_consecutive_s': both,
+            'envs_per_gpu': envs, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)), 'wall_clock_to_first_hit_s': first, 'wall_clock_to_two_consecutive_s': both,
             'best_eval_return': best_all, 'env_steps': steps_all, 'gradient_steps': grads_all, 'env_steps_per_s_incl_learning': rate,
             'reached': len(ok1), 'reached_two_consecutive': len(ok2), 'median_first_hit_s': statistics.median(ok1) if ok1 else None,
             'median_two_consecutive_s': statistics.median(ok2) if ok2 else None, 'median_s': statistics.median(ok2) if ok2 else None,
@@ -655,6 +665,21 @@ def main():
             'roofline': roofline_of(args.task, args.dtype, N, period_us),
         }
     full = not args.no_secondary and args.task == 'quadrotor_2D_track' and args.dtype == 'f32'
+    # The learning legs run collectives (N > 1: RCCL).  A rank that dies or hangs inside one must not cost the run its line:
+    # after a generous limit every rank gives up, rank 0 prints what it has (the headline is complete at this point).
+    import threading
+    limit = 120.0 + 3.0 * (max(args.ppo_seeds, 0) * args.ppo_seconds * 2 + max(args.sac_seeds, 0) * args.sac_seconds)
+
+    def bail():
+        if rank == 0 and out is not None:
+            out.setdefault('ppo', {'error': 'watchdog: the learning legs did not finish'})
+            out['watchdog'] = f'learning legs exceeded {limit:.0f} s: line printed without them'
+            print(json.dumps(out), flush=True)
+        os._exit(0 if rank == 0 else 3)
+    watchdog = threading.Timer(limit, bail)
+    watchdog.daemon = True
+    if world > 1:
+        watchdog.start()
     if rank == 0 and world == 1 and full:
         try:
             fb = StepBench(torch, args.task, N, torch.float64, graph_len=500)
@@ -691,12 +716,15 @@ def main():
             res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
         if rank == 0:
             out['ppo'] = res
-    if rank == 0 and world == 1 and full and args.sac_seeds > 0:
+    if full and args.sac_seeds > 0 and (world == 1 or backend == 'nccl' or os.environ.get('SCG_BENCH_SAC_GLOO')):
         try:
-            out['sac'] = sac_leg(torch, args.sac_seeds, args.sac_seconds)
+            res = sac_leg(torch, args.sac_seeds, args.sac_seconds, world=world, rank=rank)
         except Exception as exc:                                    # noqa: BLE001
             import traceback
-            out['sac'] = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
+            res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
+        if rank == 0:
+            out['sac'] = res
+    watchdog.cancel()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.task, hb.cfg, hb.env_id, args.cpu_seconds, N)

@@ -102,6 +102,21 @@ def test_train_ppo_two_ranks_stay_in_lock_step(tmp_path):
     assert (a['params'] - a['init_params']).abs().max() > 1e-4
 
 
+def test_bench_sac_leg_two_ranks_on_one_gpu():
+    """bench.py's SAC leg with two ranks (BASELINE config #5 is SAC on 8 GPUs; the driver's N > 1 runs execute it over RCCL): env
+    shards, replay shards, the data-parallel fused step, rank 0's clock."""
+    out = _torchrun(['bench.py', '--gpus', '2', '--steps', '200', '--warmup', '50', '--ppo-seeds', '0', '--sac-seeds', '1', '--sac-seconds', '6'],
+                    {'SCG_BENCH_BACKEND': 'gloo', 'SCG_BENCH_SAC_GLOO': '1'})
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and 'watchdog' not in r
+    s = r['sac']
+    assert 'error' not in s, s
+    assert s['n_gpus'] == 2 and s['fused_update'] is True and s['env_steps'][0] > 0 and s['gradient_steps'][0] > 0
+    assert 150.0 < s['target_return'] < 250.0
+
+
 def test_train_sac_two_ranks_stay_in_lock_step(tmp_path):
     """examples/train_sac.py (BASELINE config #5's shape: SAC, env shards, gradient all-reduce) launched like the driver launches
     bench.py, two ranks on one GPU: the fused data-parallel step keeps the ranks' weights bit-identical while their env shards
