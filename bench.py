@@ -400,10 +400,11 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
     from safe_control_gym_amd.vec_env import HipVecEnv
     # re-tuned for the batch (probes: tools/sessions/s43.sh, profiles/r03_ppo_probes_65536.txt): at 65 536 envs
     # 2 epochs x 32 minibatches of 127 x 512 rows reach the target in 1.4 s median where 4 x 64 of 127 x 256 need 2.2-2.3 s
+    # (16 384 envs, tools/sessions/s54.sh: 2 epochs x 32 minibatches of 127 x 128 rows 0.62 s median of 4 seeds, 4 x 16 of 127 x 256 0.75 s)
     if minibatch is None:
-        minibatch = 65024 if envs >= 65536 else 32512
+        minibatch = 65024 if envs >= 65536 else 16256
     if epochs is None:
-        epochs = 2 if envs >= 65536 else 4
+        epochs = 2
     env_id, cfg = load_task('quadrotor_2D_track')
     pol = (128, 'tanh')
     ev_cfg = eval_task_config(cfg, EVAL_INIT_RAND_Q2)
