@@ -237,7 +237,7 @@ class SAC(HipController):
     def _act_module(self):
         return self._det
 
-    def save(self, path, save_buffer=True):
+    def save(self, path, save_buffer=False):
         """sac.py:119-141: agent + (training) total_steps, obs, RNG state, env random state and, with save_buffer, the replay ring."""
         self.impl.save(path, training=self.training, save_buffer=save_buffer)
 

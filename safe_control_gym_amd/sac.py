@@ -484,7 +484,7 @@ class SAC:
         return results
 
     # ---- checkpoint / resume (sac.py:119-160: same keys)
-    def save(self, path, training=True, save_buffer=True):
+    def save(self, path, training=True, save_buffer=False):
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         state = {'agent': self.agent.state_dict()}
@@ -493,7 +493,7 @@ class SAC:
                           'random_state': {'torch': torch.get_rng_state(),
                                            'torch_cuda': torch.cuda.get_rng_state(self.device) if self.device.type == 'cuda' else None},
                           'env_random_state': self.env.get_env_random_state()})
-            if save_buffer:                     # (upstream: on for model_latest, off for the intermediate checkpoints)
+            if save_buffer:                     # (upstream's default is off, sac.py:119: the ring is large; on for an exact experiment restore)
                 state['buffer'] = self.buffer.state_dict()
         torch.save(state, path)
 

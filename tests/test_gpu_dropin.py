@@ -162,7 +162,7 @@ def test_controller_ids_drive_training_like_train_rl_controller():
                    train_interval=256, train_batch_size=256, max_env_steps=256 * 8, max_buffer_size=10000)
         sac.reset(); sac.learn()
         assert sac.total_steps == 256 * 8 and sac.run(n_episodes=8)['ep_returns'].shape == (8,)
-        sac.save(os.path.join(out, 'sac.pt')); sac.load(os.path.join(out, 'sac.pt'))
+        sac.save(os.path.join(out, 'sac.pt'), save_buffer=True); sac.load(os.path.join(out, 'sac.pt'))
         # the training checkpoint carries what sac.py:119-160 saves: replay ring, current obs, env random state, step counter
         again = make('sac', env_func, training=True, output_dir=out, seed=1, hidden_dim=64, rollout_batch_size=256, warm_up_steps=512,
                      train_interval=256, train_batch_size=256, max_env_steps=256 * 10, max_buffer_size=10000)
