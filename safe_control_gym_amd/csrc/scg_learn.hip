@@ -36,7 +36,7 @@ using namespace scg;
 
 constexpr int NIN = SCG_L_NIN, HID = SCG_L_H, NU = SCG_L_NU, ACT = SCG_L_ACT;
 constexpr int NT = HID / 32;
-constexpr int NINP = (NIN + 3) / 4 * 4;                 // padded input row in the LDS sample cache
+constexpr int XS_WORDS = (NIN + 2) * 32;                // a wave's sample cache: [input | ones | zeros][32 samples]
 constexpr int WAVES = 4;                                // waves per workgroup of the gradient kernel
 
 static thread_local std::string g_err;
@@ -138,7 +138,7 @@ constexpr int W1R = GradLds<(NU > 1 ? NU : 1)>::END;                    // words
 constexpr size_t grad_lds_base_words() {
     size_t a = MlpLds<NIN, HID, NU>::END + GradLds<NU>::END;
     size_t c = MlpLds<NIN, HID, 1>::END + GradLds<1>::END;
-    return (a > c ? a : c) + WAVES * 32 * NINP + WAVES * 4 * 32 + WAVES * 32 * 33;
+    return (a > c ? a : c) + WAVES * XS_WORDS + WAVES * 4 * 32 + WAVES * TR_WORDS;
 }
 // Per-wave private copies of the whole small-gradient vector (dW1, db1, db2, dW3, db3, dlogstd, statistics): every
 // accumulation is then a plain read-add-write by the owning wave, the copies are summed in wave order at the end, and the
@@ -154,13 +154,16 @@ struct GradArgs {
     float* partials;                                    // [gridDim.x][2][PARTIAL_STRIDE]
 };
 
-// -DSCG_L_TIMING: the first wave of workgroup (0, actor) stamps s_memtime at its phase boundaries into the 8 words behind
-// the partial vectors (tools/learn_cost.py --timeline prints them); the workspace is 64 bytes longer in that build.
+// -DSCG_L_TIMING: the first wave of workgroup (0, actor) stamps the shader clock at its phase boundaries into the 32 words
+// behind the partial vectors (slots 0..5: kernel phases; 8..: phase boundaries inside the LAST tile of that wave, i.e. one warm
+// tile; tools/learn_cost.py --timeline prints them); the workspace is 256 bytes longer in that build.
 #ifdef SCG_L_TIMING
-#define SCG_L_STAMP(k) do { if (ACTOR && blockIdx.x == 0 && threadIdx.x == 0) \
-    reinterpret_cast<unsigned long long*>(A.partials + (size_t)gridDim.x * 2 * PARTIAL_STRIDE)[k] = __builtin_readcyclecounter(); } while (0)
+#define SCG_L_SLOTS reinterpret_cast<unsigned long long*>(A.partials + (size_t)gridDim.x * 2 * PARTIAL_STRIDE)
+#define SCG_L_STAMP(k) do { if (ACTOR && blockIdx.x == 0 && threadIdx.x == 0) SCG_L_SLOTS[k] = __builtin_readcyclecounter(); } while (0)
+#define SCG_L_TSTAMP(k) do { tst[k] = __builtin_readcyclecounter(); } while (0)     // kept in registers, stored after the tile
 #else
 #define SCG_L_STAMP(k) do {} while (0)
+#define SCG_L_TSTAMP(k) do {} while (0)
 #endif
 
 // += into the wave's small-gradient vector: its own copy (plain) or the shared one (LDS atomic)
@@ -175,10 +178,10 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     using G = GradLds<NOUT>;
     constexpr int L1Q = L::L1Q;
     float* const gl = lds + L::END;                                     // small gradients
-    float* const xs_all = gl + G::END;                                  // [WAVES][32][NINP]
-    float* const dout_all = xs_all + WAVES * 32 * NINP;                 // [WAVES][NOUT][32]
-    float* const scr_all = dout_all + WAVES * 4 * 32;                   // [WAVES][32 * 33]
-    float* const w1_all = scr_all + WAVES * 32 * 33;                    // [WAVES - 1][W1R] (private_dw1() only)
+    float* const xs_all = gl + G::END;                                  // [WAVES][NIN + 2][32]
+    float* const dout_all = xs_all + WAVES * XS_WORDS;                    // [WAVES][NOUT][32]
+    float* const scr_all = dout_all + WAVES * 4 * 32;                   // [WAVES][TR_WORDS]
+    float* const w1_all = scr_all + WAVES * TR_WORDS;                   // [WAVES - 1][W1R] (private_dw1() only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const MlpWeights w = weights_of(A.params, ACTOR ? A.actor : A.critic);
@@ -188,11 +191,13 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     if constexpr (private_dw1()) {
         for (int k = tid; k < (WAVES - 1) * W1R; k += blockDim.x) w1_all[k] = 0.0f;
     }
+    // rows NIN (ones: the bias column of the dW1 product) and NIN + 1 (zeros: what the lanes beyond it read) of every sample cache
+    for (int k = tid; k < WAVES * 64; k += blockDim.x) xs_all[(k >> 6) * XS_WORDS + NIN * 32 + (k & 63)] = (k & 63) < 32 ? 1.0f : 0.0f;
     __syncthreads();
     SCG_L_STAMP(1);
-    float* const xs = xs_all + wave * 32 * NINP;
+    float* const xs = xs_all + wave * XS_WORDS;
     float* const dout_l = dout_all + wave * 4 * 32;
-    float* const scr = scr_all + wave * 32 * 33;
+    float* const scr = scr_all + wave * TR_WORDS;
     // this wave's small-gradient vector; wave 0 (and every wave, when the private copies do not fit the LDS) uses the shared one
     float* const glw = (private_dw1() && wave > 0) ? w1_all + (wave - 1) * W1R : gl;
     float* const w1 = glw + G::DW1;                                     // dW1 | db1: [input c <= NIN][feature]
@@ -215,28 +220,50 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 
     const int n_tiles = A.batch / 32;
     for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+#ifdef SCG_L_TIMING
+        unsigned long long tst[10];
+#endif
+        SCG_L_TSTAMP(0);
         const int s = A.idx[tile * 32 + c];
         float x[L1Q];
         load_x<L1Q>(A.obs, s, h, x);
-        // sample cache for dW1: xs[c][feature]
+        // the per-sample scalars of the loss are requested here, a forward pass ahead of their use (asked for where they are
+        // used, their round trip to memory was 2.3 us of a 37 us tile)
+        float s_act[NOUT], s_a = 0.0f, s_b = 0.0f;
+        if constexpr (ACTOR) {
 #pragma unroll
-        for (int g = 0; g < L1Q / 4; ++g) {
-            const int r0 = 8 * g + 4 * h;
-            if (r0 < NINP) *reinterpret_cast<f32x4*>(xs + c * NINP + r0) = (f32x4){x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+            for (int a = 0; a < NOUT; ++a) s_act[a] = A.act[(size_t)s * NOUT + a];
+            s_a = A.logp_old[s]; s_b = A.adv[s];
+        } else {
+            s_a = A.ret[s];
+            if (A.use_clipped_value) s_b = A.v_old[s];
         }
+        // sample cache for dW1: xs[input column][sample c]
+#pragma unroll
+        for (int q = 0; q < L1Q; ++q) {
+            const int f = d_row(q, 0);                                  // this lane holds column f + 4 h
+            if (f + 4 < NIN) xs[(f + 4 * h) * 32 + c] = x[q];
+            else if (f < NIN) { if (h == 0) xs[f * 32 + c] = x[q]; }
+        }
+        SCG_L_TSTAMP(1);
         f32x16 h1[NT], h2[NT];
         float out[NOUT], dout[NOUT];
+#ifdef SCG_L_TIMING
+        mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, out, lane, tst + 8);
+#else
         mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, out, lane);
+#endif
+        SCG_L_TSTAMP(2);
         // ---- loss derivatives w.r.t. the network outputs (both lane halves compute the same numbers)
         if constexpr (ACTOR) {
             // compute_policy_loss (ppo_utils.py:82-96): Normal(mean, exp(logstd)).log_prob(act).sum(-1), clipped surrogate
             float logp = 0.0f, z[NOUT];
 #pragma unroll
             for (int a = 0; a < NOUT; ++a) {
-                z[a] = (A.act[(size_t)s * NOUT + a] - out[a]) * inv_std[a];
+                z[a] = (s_act[a] - out[a]) * inv_std[a];
                 logp += -0.5f * z[a] * z[a] - logstd[a] - 0.91893853320467274f;
             }
-            const float lp_old = A.logp_old[s], adv = A.adv[s];
+            const float lp_old = s_a, adv = s_b;
             const float ratio = __expf(logp - lp_old);
             const float lo = 1.0f - A.clip_param, hi = 1.0f + A.clip_param;
             const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -254,10 +281,10 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
             if (h == 0) { st_loss += -fminf(s1, s2) * inv_b; st_kl += (lp_old - logp) * inv_b; }
         } else {
             // compute_value_loss (ppo_utils.py:98-111)
-            const float v = out[0], ret = A.ret[s];
+            const float v = out[0], ret = s_a;
             float dv = v - ret, l = dv * dv;
             if (A.use_clipped_value) {
-                const float vo = A.v_old[s];
+                const float vo = s_b;
                 const float d = v - vo;
                 const float vc = vo + fminf(fmaxf(d, -A.clip_param), A.clip_param);
                 const float e2 = vc - ret, l2 = e2 * e2;
@@ -282,22 +309,28 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SCG_L_TSTAMP(3);
 #ifndef DBG_NO_DW3
         // ---- output layer backward: dW3 from the transposed h2 tiles, then dz2 = (W3^T dout) * act'(h2) in place
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             float t[16];
-            tile_transpose(scr, h2[tau], t, lane);                      // t[s'] = h2[feature 32 tau + c][sample 2 s' + h]
+            tile_transpose(scr, h2[tau], t, lane);                      // t[q] = h2[feature 32 tau + c][sample row(q, h)]
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + 2 * sp + h], acc);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dout_l + o * 32 + 8 * g + 4 * h);
+                    acc = __builtin_fmaf(t[4 * g], dv.x, acc); acc = __builtin_fmaf(t[4 * g + 1], dv.y, acc);
+                    acc = __builtin_fmaf(t[4 * g + 2], dv.z, acc); acc = __builtin_fmaf(t[4 * g + 3], dv.w, acc);
+                }
                 acc += __shfl_xor(acc, 32, 64);
                 if (h == 0) gl_add(glw + G::DW3 + o * HID + 32 * tau + c, acc);
             }
         }
 #endif
+        SCG_L_TSTAMP(4);
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
 #pragma unroll
@@ -313,14 +346,23 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
                 for (int r = 0; r < 4; ++r) h2[tau][4 * g + r] = dh[r] * mlp_dact<ACT>(h2[tau][4 * g + r]);
             }
         }
-        // (h2 now holds dz2)
+        // (h2 now holds dz2, still in the accumulator layout: lane = sample)
+        // h1 is needed from here on only with the FEATURE on the lane (the activation derivative of the transposed data
+        // gradient below, the A operand of dW2): one in-place transpose per tile
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) tile_transpose_inplace(scr, h1[tau], lane);
+        SCG_L_TSTAMP(5);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- data gradient through layer 2, one input tile at a time:
-        //      dh1[tau'] = sum over (rho', q') of W2[32 rho' + row(q', h)][32 tau' + i'] dz2[rho'][q'],  dz1 = dh1 * act'(h1);
-        //      each dz1 tile is consumed at once (transposed: dW1 and db1 with the cached inputs) and never stored
+        // ---- data gradient through layer 2, one input tile at a time, computed TRANSPOSED: with dz2 as the A operand and the
+        //      weights as B the product comes out as
+        //        dh1^T[sample row(q', h)][feature 32 tau' + i'] = sum over (rho', q) of dz2[rho'][q] W2[32 rho' + row(q, h)][32 tau' + i'],
+        //      i.e. with the feature on the lane — already the A operand of the dW1 product (no transpose of the result; the
+        //      first form computed dh1 with the sample on the lane and sent every tile through the scratch).
+        //      dz1 = dh1 * act'(h1); each dz1 tile is consumed at once (dW1 and db1 with the cached inputs) and never stored
         {
             const int ip = lane & 31;
             const int qi = 4 * (ip >> 3) + (ip & 3), hi2 = (ip >> 2) & 1;
+            const float* const xrow = xs + (c < NIN + 1 ? c : NIN + 1) * 32 + 4 * h;   // [x | 1 | 0][column c][sample row(., h)]
 #pragma unroll
             for (int tp = 0; tp < NT; ++tp) {
                 f32x16 acc;
@@ -333,38 +375,44 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) a[q] = base[d_row(q, h) * L::S];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc = mfma32(a[q], h2[rp][q], acc);
+                    for (int q = 0; q < 16; ++q) acc = mfma32(h2[rp][q], a[q], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[tp][q]);
 #ifndef DBG_NO_DW1
                 // dW1 and db1 on the matrix cores as well: [dz1 tile (32 features x 32 samples)] x [x | 1] (32 samples x
-                // (NIN + 1) columns).  A = the transposed tile (lane = feature, register = sample pair), B = the cached
-                // inputs with a column of ones appended, D[feature][c]: c < NIN -> dW1[feature][c], c == NIN -> db1[feature].
+                // (NIN + 1) columns).  A = the dz1 tile as it stands, B = the cached inputs with a column of ones appended,
+                // D[feature][c]: c < NIN -> dW1[feature][c], c == NIN -> db1[feature].  The wave's running sums are the C input of
+                // the first product and the result is stored back: no read-add-write.
                 // (The vector-unit form — 16 sample pairs x NIN FMAs per lane + 13 LDS atomics per input tile — was the most
                 //  expensive section of the kernel: 18 of 49 us per tile for the smallest of the three weight matrices.)
                 {
-                    float t[16], xb[16];
-                    tile_transpose(scr, acc, t, lane);
-                    // B operand: xb[s'] = [x | 1][sample 2 s' + h][column c] from the sample cache (re-read per input tile:
-                    // sixteen more registers held across the data-gradient loop spilled)
-#pragma unroll
-                    for (int sp = 0; sp < 16; ++sp) xb[sp] = c < NIN ? xs[(2 * sp + h) * NINP + c] : (c == NIN ? 1.0f : 0.0f);
+                    float* const dst = w1 + (c <= NIN ? c : NIN) * HID + 32 * tp + 4 * h;
                     f32x16 g1;
+                    if constexpr (private_dw1()) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(dst + 8 * g);
+                            g1[4 * g] = v.x; g1[4 * g + 1] = v.y; g1[4 * g + 2] = v.z; g1[4 * g + 3] = v.w;
+                        }
+                    } else {
 #pragma unroll
-                    for (int sp = 0; sp < 16; ++sp) g1 = mfma32(t[sp], xb[sp], g1);
+                        for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
+                    }
+                    float xb[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + 8 * g);
+                        xb[4 * g] = v.x; xb[4 * g + 1] = v.y; xb[4 * g + 2] = v.z; xb[4 * g + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) g1 = mfma32(acc[q], xb[q], g1);
                     if (c <= NIN) {
-                        float* const dst = w1 + c * HID + 32 * tp + 4 * h;
-                        if constexpr (private_dw1()) {                  // this wave's own words: plain read-add-write
+                        if constexpr (private_dw1()) {                  // this wave's own words
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                f32x4 v = *reinterpret_cast<const f32x4*>(dst + 8 * g);
-                                v += (f32x4){g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
-                                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
-                            }
+                            for (int g = 0; g < 4; ++g)
+                                *reinterpret_cast<f32x4*>(dst + 8 * g) = (f32x4){g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
                         } else {
 #pragma unroll
                             for (int q = 0; q < 16; ++q) atomicAdd(dst + d_row(q, 0), g1[q]);
@@ -375,25 +423,35 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SCG_L_TSTAMP(6);
 #ifndef DBG_NO_DW2
-        // ---- dW2 += h1 dz2^T over this tile's 32 samples (MFMA over sample pairs), db2
+        // ---- dW2 += h1 dz2^T over this tile's 32 samples (MFMA over sample pairs), db2: dz2 goes through the scratch as h1 did
+        //      (8 in-place transposes for this product; transposing h1[tau] inside the rho loop made it 20)
 #pragma unroll
         for (int rho = 0; rho < NT; ++rho) {
-            float b[16];
-            tile_transpose(scr, h2[rho], b, lane);                      // dz2[out 32 rho + c][sample 2 s' + h]
+            tile_transpose_inplace(scr, h2[rho], lane);                 // dz2[out 32 rho + c][sample row(q, h)]
             float sb = 0.0f;
 #pragma unroll
-            for (int sp = 0; sp < 16; ++sp) sb += b[sp];
+            for (int q = 0; q < 16; ++q) sb += h2[rho][q];
             sb += __shfl_xor(sb, 32, 64);
             if (h == 0) gl_add(glw + G::DB2 + 32 * rho + c, sb);
+        }
 #pragma unroll
-            for (int tau = 0; tau < NT; ++tau) {
-                float a[16];
-                tile_transpose(scr, h1[tau], a, lane);                  // h1[in 32 tau + c][sample 2 s' + h]
+        for (int tau = 0; tau < NT; ++tau) {
 #pragma unroll
-                for (int sp = 0; sp < 16; ++sp) dW2[tau][rho] = mfma32(a[sp], b[sp], dW2[tau][rho]);
+            for (int rho = 0; rho < NT; ++rho) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dW2[tau][rho] = mfma32(h1[tau][q], h2[rho][q], dW2[tau][rho]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+#endif
+        SCG_L_TSTAMP(7);
+#ifdef SCG_L_TIMING
+        if (ACTOR && blockIdx.x == 0 && threadIdx.x == 0 && tile + (int)gridDim.x * WAVES >= n_tiles) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) SCG_L_SLOTS[8 + k] = tst[k];
+            SCG_L_SLOTS[24] = tst[8]; SCG_L_SLOTS[25] = tst[9];
         }
 #endif
     }
@@ -424,24 +482,28 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         }
     }
     SCG_L_STAMP(3);
-    // The four waves' dW2 accumulators are summed IN WAVE ORDER through the (now free) weight image: wave 0 writes, waves
-    // 1..3 read-add-write, 16-byte LDS accesses.  (256 ds_add_f32 per lane from four waves onto the same words took 86 us
-    // — 27 % of the kernel at four tiles per wave — and summed in arrival order.)  Word order: [tile][lane][q].
+    // The waves' dW2 accumulators are summed through the (now free) weight image in a FIXED order with every wave busy in every
+    // round: in round r wave w owns the tile rows tau = (w + r) mod WAVES — round 0 writes, the later rounds read-add-write,
+    // 16-byte LDS accesses — so row tau is summed in the order wave tau, tau - 1, ...  (One wave at a time, wave 0 to 3, made four
+    // passes over the 64 KB instead of one: 9.3 us; 256 ds_add_f32 per lane from four waves onto the same words took 86 us and
+    // summed in arrival order.)  Word order: [tile][lane][q].
     float* const stg = lds + L::W2F;                                    // H * H words
-    for (int wv = 0; wv < WAVES; ++wv) {
-        if (wave == wv) {
+    static_assert(NT <= WAVES, "round 0 must write every tile row");
 #pragma unroll
-            for (int tau = 0; tau < NT; ++tau)
+    for (int r = 0; r < WAVES; ++r) {
 #pragma unroll
-                for (int rho = 0; rho < NT; ++rho) {
-                    float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+        for (int tau = 0; tau < NT; ++tau) {
+            if (tau != ((wave + r) % WAVES)) continue;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {dW2[tau][rho][4 * g], dW2[tau][rho][4 * g + 1], dW2[tau][rho][4 * g + 2], dW2[tau][rho][4 * g + 3]};
-                        if (wv > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
-                        *reinterpret_cast<f32x4*>(p + 4 * g) = v;
-                    }
+            for (int rho = 0; rho < NT; ++rho) {
+                float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {dW2[tau][rho][4 * g], dW2[tau][rho][4 * g + 1], dW2[tau][rho][4 * g + 2], dW2[tau][rho][4 * g + 3]};
+                    if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
+                    *reinterpret_cast<f32x4*>(p + 4 * g) = v;
                 }
+            }
         }
         __syncthreads();
     }
@@ -631,7 +693,7 @@ extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layo
 extern "C" size_t scg_ppo_grad_workspace_bytes(int n_workgroups) {
     size_t b = (size_t)n_workgroups * 2 * PARTIAL_STRIDE * sizeof(float);
 #ifdef SCG_L_TIMING
-    b += 64;
+    b += 256;
 #endif
     return b;
 }

@@ -153,7 +153,8 @@ __device__ __forceinline__ float mlp_dact<MLP_ACT_NONE>(float) { return 1.0f; }
 // Leaves h1, h2 (activations, D layout: [tile][q]) and out[NOUT] (identical in both lane halves).  ACT2: activation of
 // the second hidden layer when it differs from the first's.
 template <int NIN, int H, int NOUT, int ACT, int SS = 20, int ACT2 = ACT>
-__device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* x, f32x16* h1, f32x16* h2, float* out, int lane) {
+__device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* x, f32x16* h1, f32x16* h2, float* out, int lane,
+                                                 unsigned long long* ts = nullptr) {
     using L = MlpLds<NIN, H, NOUT, SS>;
     constexpr int NT = L::NT;
     const int h = lane >> 5;
@@ -173,6 +174,7 @@ __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* 
         for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT>(acc[q]);
         h1[rho] = acc;
     }
+    if (ts) ts[0] = __builtin_readcyclecounter();
     // ---- layer 2
 #pragma unroll
     for (int rho = 0; rho < NT; ++rho) {
@@ -194,6 +196,7 @@ __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* 
         for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT2>(acc[q]);
         h2[rho] = acc;
     }
+    if (ts) ts[1] = __builtin_readcyclecounter();
     // ---- output layer on the vector unit: each lane holds half of its sample's features
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
@@ -212,20 +215,36 @@ __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* 
     }
 }
 
-// D-layout tile -> "lane = feature, registers = samples" through the wave-private scratch (32 x 33 words):
-// t[s] = tile[feature i = lane & 31][sample 2 s + (lane >> 5)].
+// D-layout tile -> "lane = feature, registers = samples" through the wave-private scratch (TR_WORDS words, 16-byte aligned):
+// t[q] = tile[feature i = lane & 31][sample d_row(q, lane >> 5)] — the samples in the accumulator's own row order, so that a
+// transposed tile is again a valid MFMA operand over sample pairs (contraction index <-> (q, lane half), as in the forward
+// pass) and the read side is four 16-byte loads per lane (row i of the scratch = the 32 samples of feature i; the row stride
+// of 36 words puts the sixteen lanes of one LDS pass on sixty-four different banks).
+constexpr int TR_STRIDE = 36, TR_WORDS = 32 * TR_STRIDE;
 __device__ __forceinline__ void tile_transpose(float* scr, const f32x16& tile, float* t, int lane) {
     const int c = lane & 31, h = lane >> 5;
+    float* const wr = scr + 4 * h * TR_STRIDE + c;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) scr[d_row(q, h) * 33 + c] = tile[q];
+    for (int q = 0; q < 16; ++q) wr[d_row(q, 0) * TR_STRIDE] = tile[q];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float* const rd = scr + c * TR_STRIDE + 4 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) t[s] = scr[c * 33 + 2 * s + h];
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rd + 8 * g);
+        t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// The same, in place: the tile's registers become t[0..15].
+__device__ __forceinline__ void tile_transpose_inplace(float* scr, f32x16& tile, int lane) {
+    float t[16];
+    tile_transpose(scr, tile, t, lane);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[q] = t[q];
 }
 
 }  // namespace scg

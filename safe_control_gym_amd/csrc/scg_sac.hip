@@ -126,7 +126,7 @@ __device__ __forceinline__ void backward_tile(const float* lds, float* xs, float
             for (int o = 0; o < NOUT; ++o) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + 2 * sp + h], acc);
+                for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + d_row(sp, h)], acc);
                 acc += __shfl_xor(acc, 32, 64);
                 if (h == 0) padd(P + G::DW3 + o * HID + 32 * tau + c, acc, first);
             }
@@ -189,7 +189,10 @@ __device__ __forceinline__ void backward_tile(const float* lds, float* xs, float
                 float t[16], xb[16];
                 tile_transpose(scr, acc, t, lane);
 #pragma unroll
-                for (int sp = 0; sp < 16; ++sp) xb[sp] = c < NIN ? xs[(2 * sp + h) * NINP + (c < NIN ? c : 0)] : (c == NIN ? 1.0f : 0.0f);
+                for (int sp = 0; sp < 16; ++sp) {                           // unconditional read + select (a conditional read compiles to a branch each)
+                    const float v = xs[d_row(sp, h) * NINP + (c < NIN ? c : 0)];
+                    xb[sp] = c < NIN ? v : (c == NIN ? 1.0f : 0.0f);
+                }
                 f32x16 g1;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
@@ -213,19 +216,21 @@ __device__ __forceinline__ void backward_tile(const float* lds, float* xs, float
         for (int j = 0; j < NU; ++j) din[j] += __shfl_xor(din[j], 32, 64);
     }
     if constexpr (WGRAD) {
+        // neither h1 nor dz2 is needed in the accumulator layout any more: one in-place transpose per tile
 #pragma unroll
         for (int rho = 0; rho < NT; ++rho) {
-            float b[16];
-            tile_transpose(scr, h2[rho], b, lane);                      // dz2[out 32 rho + c][sample 2 s' + h]
+            tile_transpose_inplace(scr, h2[rho], lane);                 // dz2[out 32 rho + c][sample row(q, h)]
             float sb = 0.0f;
 #pragma unroll
-            for (int sp = 0; sp < 16; ++sp) sb += b[sp];
+            for (int sp = 0; sp < 16; ++sp) sb += h2[rho][sp];
             sb += __shfl_xor(sb, 32, 64);
             if (h == 0) padd(P + G::DB2 + 32 * rho + c, sb, first);
+        }
 #pragma unroll
-            for (int tau = 0; tau < NT; ++tau) {
-                float a[16];
-                tile_transpose(scr, h1[tau], a, lane);
+        for (int tau = 0; tau < NT; ++tau) {
+            tile_transpose_inplace(scr, h1[tau], lane);
+#pragma unroll
+            for (int rho = 0; rho < NT; ++rho) {
                 // dW2 tile (in 32 tau.., out 32 rho..) of THIS sample tile straight into the wave's partial vector, in the
                 // accumulator's own [tile][lane][q] order (a wave usually owns one sample tile; keeping 16 H^2 / 1024 accumulator
                 // registers across tiles as scg_learn.hip does spilled here: the actor head is 8 outputs wide)
@@ -233,7 +238,7 @@ __device__ __forceinline__ void backward_tile(const float* lds, float* xs, float
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 #pragma unroll
-                for (int sp = 0; sp < 16; ++sp) acc = mfma32(a[sp], b[sp], acc);
+                for (int sp = 0; sp < 16; ++sp) acc = mfma32(h1[tau][sp], h2[rho][sp], acc);
                 float* const p = P + G::DW2 + ((tau * NT + rho) * 64 + lane) * 16;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void q_kernel(const float* __restric
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32, B = Cm.batch;
-    float* const wl = lds + L::END + wave * (32 * NINP + 32 + 32 * 33);
+    float* const wl = lds + L::END + wave * (32 * NINP + 32 + TR_WORDS);
     float* const xs = wl; float* const dout_l = xs + 32 * NINP; float* const scr = dout_l + 32;
     float* const P = partials ? partials + ((size_t)y * Cm.n_part + wid) * PSTRIDE : nullptr;
     const float alpha = MODE == 2 ? expf(*Cm.log_alpha) : 0.0f;
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void actor_grad_kernel(const float* 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32, B = Cm.batch;
-    float* const wl = lds + L::END + wave * (32 * NINP + NA * 32 + 32 * 33);
+    float* const wl = lds + L::END + wave * (32 * NINP + NA * 32 + TR_WORDS);
     float* const xs = wl; float* const dout_l = xs + 32 * NINP; float* const scr = dout_l + NA * 32;
     if (wid >= Cm.n_part) return;
     float* const P = partials + (size_t)wid * PSTRIDE;
@@ -599,8 +604,8 @@ static int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
-static size_t lds_actor_bytes() { return (MlpLds<NOBS, HID, NA>::END + WAVES * (32 * ((NOBS + 3) / 4 * 4) + NA * 32 + 32 * 33)) * sizeof(float); }
-static size_t lds_q_bytes() { return (MlpLds<NQ, HID, 1>::END + WAVES * (32 * ((NQ + 3) / 4 * 4) + 32 + 32 * 33)) * sizeof(float); }
+static size_t lds_actor_bytes() { return (MlpLds<NOBS, HID, NA>::END + WAVES * (32 * ((NOBS + 3) / 4 * 4) + NA * 32 + TR_WORDS)) * sizeof(float); }
+static size_t lds_q_bytes() { return (MlpLds<NQ, HID, 1>::END + WAVES * (32 * ((NQ + 3) / 4 * 4) + 32 + TR_WORDS)) * sizeof(float); }
 
 // One-time kernel attributes (dynamic LDS above 64 KB).  Call once before capturing scg_sac_update into a HIP graph: the
 // attribute calls are not stream operations.  scg_sac_update calls it itself otherwise.

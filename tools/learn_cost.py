@@ -47,7 +47,15 @@ if '--timeline' in sys.argv:            # needs a library built with SCG_LEARN_F
     for _ in range(3):
         ag._fused_grad(F)
     torch.cuda.synchronize()
-    t = F['ws'][-64:].view(torch.int64)[:6].cpu().tolist()
-    names = ['fill + barrier', 'tile loop (4 tiles)', 'small-gradient atomics + barrier', 'dW2 staging (zero, ds_add, barrier)', 'partial vector write']
+    T = F['ws'][-256:].view(torch.int64).cpu().tolist()
+    t = T[:6]
+    names = ['fill + barrier', 'tile loop (4 tiles)', 'small-gradient sums + barrier', 'dW2 staging', 'partial vector write']
     for n, a, b in zip(names, t, t[1:]):
-        print(f'  {n:40s} {(b - a) / 100.0:8.2f} us   (100 MHz counter)')
+        print(f'  {n:40s} {(b - a) / 2400.0:8.2f} us')
+    # one warm tile (the wave's last), phase boundaries; the two forward-pass stamps sit between 'inputs' and 'loss derivatives'
+    tt = [T[8], T[9], T[24], T[25]] + T[10:16]
+    names = ['index -> observation gather, sample cache', 'forward layer 1 (+ activations)', 'forward layer 2 (+ activations)', 'output layer',
+             'loss derivatives, db3', 'dW3 (4 transposes + vector unit)', 'dz2, h1 transposes', 'data gradient + dW1 | db1', 'dW2 + db2 (4 transposes)']
+    for n, a, b in zip(names, tt, tt[1:]):
+        print(f'    tile: {n:44s} {(b - a) / 2400.0:8.2f} us')
+    print(f'    tile total {(tt[-1] - tt[0]) / 2400.0:8.2f} us   (shader clock taken as 2.4 GHz)')
