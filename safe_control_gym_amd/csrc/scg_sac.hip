@@ -3,26 +3,32 @@
 //     hipcc -DSCG_S_NOBS=<obs_dim> -DSCG_S_H=<hidden> -DSCG_S_NU=<act_dim> -DSCG_S_ACT=<0 tanh|1 relu|2 leaky>
 //     -> libscg_sac_<nobs>_<h>_<nu>_<act>.so       (C ABI: include/scg_sac.h)
 //
-// Why a sequence and not one kernel: the step touches five networks (actor, q1, q2, q1', q2') whose MFMA operand images
-// are ~100 KB of LDS each — one per workgroup at a time — and the phases depend on each other through tiny per-sample
-// vectors (action, log-prob, q, dq/da: a few floats per row), which cross global memory between launches.  Every kernel
-// follows scg_learn.hip's scheme: the workgroup packs ONE network into LDS (scg_mlp.h), each wave walks 32-sample column
-// tiles with the activations in registers, all matrix products on v_mfma_f32_32x32x2_f32 (exact float32).
-//   sample_kernel        batch rows ~ U[0, ring size)                                     SACBuffer.sample  (:399-413)
-//   actor_fwd_kernel     a, log pi (tanh-Gaussian, reparameterised)                       MLPActor.forward  (:185-222)
+// Why a sequence and not one kernel: the step touches five networks (actor, q1, q2, q1', q2') and its phases depend on each
+// other through tiny per-sample vectors (action, log-prob, q, dq/da: a few floats per row), which cross global memory between
+// launches.  Every MFMA kernel works on 32-sample column tiles, one tile per WORKGROUP, with the hidden layers split by feature
+// over the workgroup's waves (see "wide tiles" below); all matrix products on v_mfma_f32_32x32x2_f32 (exact float32).
+//   actor_fwd_kernel     batch rows ~ U[0, ring size) (SACBuffer.sample :399-413), then
+//                        a, log pi (tanh-Gaussian, reparameterised)                       MLPActor.forward  (:185-222)
 //   q_kernel<1>          q_y(obs, a) and dq_y/da for y = 1, 2 (forward + data gradient)   compute_policy_loss (:110-127)
 //   actor_grad_kernel    d mean(alpha log pi - min q)/d(actor), forward recomputed, weight gradients
-//   adam_kernel          actor (+ log_alpha)
+//   reduce_kernel        sum of the partials + Adam: actor (+ log_alpha), soft update of the actor's target copy
 //   actor_fwd_kernel     a', log pi' at next_obs with the UPDATED actor                   compute_q_loss    (:129-141)
 //   q_kernel<0>          target networks at (next_obs, a')
 //   q_kernel<2>          d[mean (q_y - target)^2]/d(q_y), y = 1, 2
-//   adam_kernel          critics + Polyak of every parameter into the target copy         (:163-168)
-// Gradient reduction: every WAVE owns one partial gradient vector in global memory (a wave usually owns one tile: plain
+//   reduce_kernel        sum of the partials + Adam: critics, soft update of their target copies        (:163-168)
+//   finish_kernel        step counters, loss statistics
+// (Data-parallel callers run the phases separately — include/scg_sac.h — with reduce_kernel writing the gradient only and
+//  adam_kernel stepping after the all-reduce.)
+// Gradient reduction: every WORKGROUP owns one partial gradient vector in global memory (a workgroup usually owns one tile: plain
 // stores), reduce_kernel sums the partials in a fixed order — no atomics, bitwise reproducible.
+// History: until late in round 3 a tile belonged to ONE wave behind a 100 KB LDS weight image (scg_learn.hip's scheme, right for
+// PPO's 2000-tile minibatches): 0.211 ms per step at batch 4096, where 128 tiles left 7/8 of the SIMDs idle behind 288-864
+// dependent MFMAs each; the wide tiles run the same step in 0.114 ms (profiles/r03_sac_update_cost.json).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/scg_sac.h"
@@ -93,175 +99,6 @@ __device__ __forceinline__ void load_x2(const float* __restrict__ a, const float
     }
 }
 
-// Backward pass of one 32-sample tile of an  NIN -> H (ACT) -> H (ACT2) -> NOUT  network whose forward left h1, h2 in
-// registers.  dout[o] = d loss / d out[o] of this lane's sample (identical in both lane halves).
-//   WGRAD: weight / bias gradients into the wave's partial vector P (first: plain stores, else read-add-write);  DIN: din[j] = d loss / d input[NIN - NU + j] (the action columns of a Q network).
-// Scheme and layouts as scg_learn.hip::grad_net (dW3 from transposed h2 tiles on the vector unit, dz2 in place, the layer-2
-// data gradient gathered from the forward weight image, dW1 | db1 and dW2 as MFMA products over sample pairs).
-template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN>
-__device__ __forceinline__ void backward_tile(const float* lds, float* xs, float* dout_l, float* scr, f32x16* h1, f32x16* h2,
-                                              const float* dout, int lane, float* P, bool first, float* din) {
-    using L = MlpLds<NIN, HID, NOUT>;
-    using G = Part<NIN, NOUT>;
-    constexpr int NINP = (NIN + 3) / 4 * 4;
-    const int c = lane & 31, h = lane >> 5;
-    if constexpr (WGRAD) {
-        if (h == 0) {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) dout_l[o * 32 + c] = dout[o];
-        }
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {                                // db3: sum over the tile's 32 samples
-            float v = dout[o];
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0) padd(P + G::DB3 + o, v, first);
-        }
-        wave_sync();
-#pragma unroll
-        for (int tau = 0; tau < NT; ++tau) {                            // dW3[o][f] = sum_s h2[f][s] dout[o][s]
-            float t[16];
-            tile_transpose(scr, h2[tau], t, lane);
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int sp = 0; sp < 16; ++sp) acc = __builtin_fmaf(t[sp], dout_l[o * 32 + d_row(sp, h)], acc);
-                acc += __shfl_xor(acc, 32, 64);
-                if (h == 0) padd(P + G::DW3 + o * HID + 32 * tau + c, acc, first);
-            }
-        }
-    }
-    // dz2 = (W3^T dout) * act2'(h2), in place
-#pragma unroll
-    for (int tau = 0; tau < NT; ++tau) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + L::W3 + o * HID + 32 * tau + 8 * g + 4 * h);
-                dh[0] = __builtin_fmaf(wv.x, dout[o], dh[0]); dh[1] = __builtin_fmaf(wv.y, dout[o], dh[1]);
-                dh[2] = __builtin_fmaf(wv.z, dout[o], dh[2]); dh[3] = __builtin_fmaf(wv.w, dout[o], dh[3]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h2[tau][4 * g + r] = dh[r] * mlp_dact<ACT2>(h2[tau][4 * g + r]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DIN) {
-#pragma unroll
-        for (int j = 0; j < NU; ++j) din[j] = 0.0f;
-    }
-    {
-        const int ip = lane & 31;
-        const int qi = 4 * (ip >> 3) + (ip & 3), hi2 = (ip >> 2) & 1;
-#pragma unroll
-        for (int tp = 0; tp < NT; ++tp) {
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-#pragma unroll
-            for (int rp = 0; rp < NT; ++rp) {
-                const float* base = lds + L::W2F + (rp * NT + tp) * L::TILE2 + 32 * hi2 * L::S + qi;
-                float a[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = base[d_row(q, h) * L::S];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc = mfma32(a[q], h2[rp][q], acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[tp][q]);        // dz1 tile
-            if constexpr (DIN) {
-                // d loss / d input column rr = sum_f W1[f][rr] dz1[f]; this lane holds features 32 tp + row(q, h)
-#pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    const int rr = NIN - NU + j;
-                    const int qj = 4 * (rr >> 3) + (rr & 3), hj = (rr >> 2) & 1;
-                    float s = din[j];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) s = __builtin_fmaf(lds[L::W1F + (tp * L::L1Q + qj) * 64 + d_row(q, h) + 32 * hj], acc[q], s);
-                    din[j] = s;
-                }
-            }
-            if constexpr (WGRAD) {
-                float t[16], xb[16];
-                tile_transpose(scr, acc, t, lane);
-#pragma unroll
-                for (int sp = 0; sp < 16; ++sp) {                           // unconditional read + select (a conditional read compiles to a branch each)
-                    const float v = xs[d_row(sp, h) * NINP + (c < NIN ? c : 0)];
-                    xb[sp] = c < NIN ? v : (c == NIN ? 1.0f : 0.0f);
-                }
-                f32x16 g1;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
-#pragma unroll
-                for (int sp = 0; sp < 16; ++sp) g1 = mfma32(t[sp], xb[sp], g1);
-                if (c <= NIN) {
-                    float* const dst = P + G::DW1 + c * HID + 32 * tp + 4 * h;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
-                        if (!first) v += *reinterpret_cast<const f32x4*>(dst + 8 * g);
-                        *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if constexpr (DIN) {
-#pragma unroll
-        for (int j = 0; j < NU; ++j) din[j] += __shfl_xor(din[j], 32, 64);
-    }
-    if constexpr (WGRAD) {
-        // neither h1 nor dz2 is needed in the accumulator layout any more: one in-place transpose per tile
-#pragma unroll
-        for (int rho = 0; rho < NT; ++rho) {
-            tile_transpose_inplace(scr, h2[rho], lane);                 // dz2[out 32 rho + c][sample row(q, h)]
-            float sb = 0.0f;
-#pragma unroll
-            for (int sp = 0; sp < 16; ++sp) sb += h2[rho][sp];
-            sb += __shfl_xor(sb, 32, 64);
-            if (h == 0) padd(P + G::DB2 + 32 * rho + c, sb, first);
-        }
-#pragma unroll
-        for (int tau = 0; tau < NT; ++tau) {
-            tile_transpose_inplace(scr, h1[tau], lane);
-#pragma unroll
-            for (int rho = 0; rho < NT; ++rho) {
-                // dW2 tile (in 32 tau.., out 32 rho..) of THIS sample tile straight into the wave's partial vector, in the
-                // accumulator's own [tile][lane][q] order (a wave usually owns one sample tile; keeping 16 H^2 / 1024 accumulator
-                // registers across tiles as scg_learn.hip does spilled here: the actor head is 8 outputs wide)
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-#pragma unroll
-                for (int sp = 0; sp < 16; ++sp) acc = mfma32(h1[tau][sp], h2[rho][sp], acc);
-                float* const p = P + G::DW2 + ((tau * NT + rho) * 64 + lane) * 16;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    if (!first) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
-                    *reinterpret_cast<f32x4*>(p + 4 * g) = v;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-}
-
-// sample cache for the dW1 product: xs[c][feature] of this wave's tile
-template <int L1Q, int NINP>
-__device__ __forceinline__ void cache_x(float* xs, const float* x, int c, int h) {
-#pragma unroll
-    for (int g = 0; g < L1Q / 4; ++g) {
-        const int r0 = 8 * g + 4 * h;
-        if (r0 < NINP) *reinterpret_cast<f32x4*>(xs + c * NINP + r0) = (f32x4){x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
-    }
-}
-
 // ------------------------------------------------------------------ kernels
 struct Common {
     const int32_t* idx; int batch; int n_part;
@@ -272,15 +109,13 @@ struct Common {
     uint32_t k0, k1; const uint32_t* counter;
 };
 
-__global__ __launch_bounds__(256) void sample_kernel(int32_t* __restrict__ idx, const int32_t* __restrict__ ring_size, int batch,
-                                                      const int32_t* __restrict__ idx_in, uint32_t k0, uint32_t k1,
-                                                      const uint32_t* __restrict__ counter) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= batch) return;
-    if (idx_in) { idx[i] = idx_in[i]; return; }
+// batch row r of this update: a replay-ring slot ~ U[0, ring size) (or the caller's, for tests)
+__device__ __forceinline__ int sample_row(int r, const int32_t* __restrict__ ring_size, const int32_t* __restrict__ idx_in, uint32_t cnt,
+                                          uint32_t k0, uint32_t k1) {
+    if (idx_in) return idx_in[r];
     const uint32_t n = (uint32_t)max(*ring_size, 1);
-    const U4 w = philox4x32_10(U4{*counter, (uint32_t)i, 0u, 0x5ac0u}, k0, k1);
-    idx[i] = (int32_t)int_below(w.x, n);
+    const U4 w = philox4x32_10(U4{cnt, (uint32_t)r, 0u, 0x5ac0u}, k0, k1);
+    return (int32_t)int_below(w.x, n);
 }
 
 // N(0,1) draws for one batch row: Box-Muller on a Philox block (stream: 1 policy-loss action, 2 target action)
@@ -307,42 +142,6 @@ __device__ __forceinline__ void squash(const float* out, const float* eps, const
         th[j] = tanhf(u[j]);
         a[j] = low[j] + 0.5f * (th[j] + 1.0f) * (high[j] - low[j]);
         logp += -0.5f * eps[j] * eps[j] - ls - LOG_SQRT_2PI - 2.0f * (LOG2F - u[j] - softplusf(-2.0f * u[j]));
-    }
-}
-
-// actor forward on obs rows idx (use_next = 0) or next_obs rows (1): eps, action, log pi per batch row
-__global__ __launch_bounds__(64 * WAVES, 1) void actor_fwd_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
-                                                                   int use_next, const float* __restrict__ eps_in, uint32_t stream,
-                                                                   float* __restrict__ eps_out, float* __restrict__ a_out,
-                                                                   float* __restrict__ logp_out) {
-    using L = MlpLds<NOBS, HID, NA>;
-    extern __shared__ __align__(16) float lds[];
-    mlp_fill_lds<NOBS, HID, NA>(lds, weights_of(params, lay), threadIdx.x);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32;
-    const float* src = use_next ? Cm.next_obs : Cm.obs;
-    const uint32_t cnt = *Cm.counter;
-    if (wid >= Cm.n_part) return;
-    for (int tile = wid; tile < n_tiles; tile += Cm.n_part) {
-        const int r = tile * 32 + c, s = Cm.idx[r];
-        float x[L::L1Q];
-        load_x2<L::L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
-        f32x16 h1[NT], h2[NT];
-        float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp;
-        mlp_forward_tile<NOBS, HID, NA, ACT, 20, MLP_ACT_NONE>(lds, x, h1, h2, out, lane);
-        if (eps_in) {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r * NU + j];
-        } else {
-            normal4(cnt, (uint32_t)r, stream, Cm.k0, Cm.k1, eps);
-        }
-        squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
-        if (h == 0) {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) { eps_out[(size_t)r * NU + j] = eps[j]; a_out[(size_t)r * NU + j] = a[j]; }
-            logp_out[r] = logp;
-        }
     }
 }
 
@@ -373,97 +172,478 @@ __global__ __launch_bounds__(64 * WAVES, 1) void actor_act_kernel(const float* _
     }
 }
 
+// ================================================================== wide tiles
+// A batch of 4096 is only 128 tiles.  The NT waves of a workgroup SHARE one tile: wave w owns the hidden features
+// [32 w, 32 w + 32) of both layers, the activations cross an LDS exchange between the layers, and every wave's dependent MFMA
+// chain is 1 / NT of the network's.  Each weight is then used by exactly one wave, once per tile: the MFMA operands are read from
+// the parameter vector straight into registers (no LDS image, no fill) — only W3 and the biases sit in the LDS.
+//   forward :  L1 (own 32 features) -> h1 tile to H1X -> barrier -> L2 (A = own rows of W2, B = all h1 tiles) -> own partial of the
+//              output layer to RED -> barrier -> every wave sums the NT partials (fixed order)
+//   backward:  dW3 / db2 / dz2 on the own tile; dz2 tile to DZX, own h1 tile transposed to H1T -> barrier ->
+//              data gradient of the OWN input-feature tile (all dz2 tiles x own columns of W2; computed transposed when it feeds
+//              dW1 — scg_learn.hip's trick — plain when it feeds dq/da), dW1 | db1 slice, the dW2 tiles [all tau][rho = w]
+//              (A = H1T tiles, B = own dz2^T)
+// Partial gradient vectors: one per workgroup, word order of Part<> (dW2 in the accumulator's [tile][lane][q] order).
+namespace wide {
+constexpr int XW = 20, XT = 64 * XW;                    // an exchanged tile: 16 words per lane, padded to 20 (conflict-free 16-byte access)
+template <int NOUT>
+struct Lds {
+    static constexpr int W3 = 0;                                        // [NOUT][H]
+    static constexpr int B1 = W3 + NOUT * HID, B2 = B1 + HID, B3 = B2 + HID;   // b3: [8]
+    static constexpr int W1A = B3 + 8;                                  // [4][H]    W1's action columns (Q networks, dq/da)
+    static constexpr int H1X = W1A + 4 * HID;                           // [NT][XT]  h1 tiles, accumulator layout (lane = sample)
+    static constexpr int RED = H1X + NT * XT;                           // [NT][8][32] per-wave partial outputs
+    static constexpr int FWD_END = RED + NT * 8 * 32;
+    static constexpr int DZX = FWD_END;                                 // [NT][XT]  dz2 tiles, accumulator layout
+    static constexpr int H1T = DZX + NT * XT;                           // [NT][XT]  h1 tiles transposed (lane = feature)
+    static constexpr int DIN = H1T + NT * XT;                           // [NT][4][32] per-wave partial input gradients
+    static constexpr int WAVE = DIN + NT * 4 * 32;                      // per wave: scr | xs | dout_l
+    static constexpr int WAVE_WORDS = TR_WORDS + 34 * 32 + 8 * 32;
+    static constexpr int END = WAVE + NT * WAVE_WORDS;
+    static_assert(NOUT <= 8 && (H1X % 4) == 0, "layout");
+};
+
+// W3 and the biases of one network -> LDS (all threads; caller barriers)
+template <int NOUT>
+__device__ __forceinline__ void fill_small(float* lds, const MlpWeights& w, int tid) {
+    using S = Lds<NOUT>;
+    for (int k = tid; k < NOUT * HID; k += 64 * NT) lds[S::W3 + k] = w.W3[k];
+    for (int k = tid; k < HID; k += 64 * NT) { lds[S::B1 + k] = w.b1[k]; lds[S::B2 + k] = w.b2[k]; }
+    if (tid < 8) lds[S::B3 + tid] = tid < NOUT ? w.b3[tid] : 0.0f;
+}
+
+// MFMA operands of wave `wave` from the torch-layout parameters:
+//   a1[q]      = W1[32 wave + i][row(q, h)]                  A operand of layer 1            (i = lane & 31, h = lane >> 5)
+//   a2[tau][q] = W2[32 wave + i][32 tau + row(q, h)]         A operand of layer 2
+//   bt[rho][q] = W2[32 rho + row(q, h)][32 wave + i]         operand of the data gradient of the own input tile
+template <int NIN, int L1Q>
+__device__ __forceinline__ void load_a1(const float* __restrict__ W1, int wave, int lane, float* a1) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < L1Q; ++q) {
+        const int f = d_row(q, 0) + 4 * h;
+        a1[q] = f < NIN ? W1[(size_t)(32 * wave + i) * NIN + (f < NIN ? f : 0)] : 0.0f;
+    }
+}
+__device__ __forceinline__ void load_a2(const float* __restrict__ W2, int wave, int lane, float (&a2)[NT][16]) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* row = W2 + (size_t)(32 * wave + i) * HID + 4 * h;
+    if ((reinterpret_cast<uintptr_t>(W2) & 15) == 0) {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * tau + 8 * g);
+                a2[tau][4 * g] = v.x; a2[tau][4 * g + 1] = v.y; a2[tau][4 * g + 2] = v.z; a2[tau][4 * g + 3] = v.w;
+            }
+    } else {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a2[tau][q] = row[32 * tau + d_row(q, 0)];
+    }
+}
+__device__ __forceinline__ void load_bt(const float* __restrict__ W2, int wave, int lane, float (&bt)[NT][16]) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int rho = 0; rho < NT; ++rho)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bt[rho][q] = W2[(size_t)(32 * rho + d_row(q, h)) * HID + 32 * wave + i];
+}
+
+__device__ __forceinline__ void put_tile(float* slot, const f32x16& t) {          // slot = base + lane * XW
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(slot + 4 * g) = (f32x4){t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+}
+__device__ __forceinline__ void get_tile(const float* slot, float* t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slot + 4 * g);
+        t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+    }
+}
+
+// Forward pass of the workgroup's tile: h1, h2 = this wave's feature tile of each hidden layer (accumulator layout), out = the
+// network outputs of this lane's sample (every wave, both lane halves).  Two workgroup barriers.
+template <int NIN, int NOUT, int ACT2>
+__device__ __forceinline__ void forward(float* lds, const float* a1, const float (&a2)[NT][16], const float* x, int wave, int lane,
+                                        f32x16& h1, f32x16& h2, float* out) {
+    using S = Lds<NOUT>;
+    constexpr int L1Q = 4 * ((NIN + 7) / 8);
+    const int c = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + S::B1 + 32 * wave + 8 * g + 4 * h);
+        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+    }
+#pragma unroll
+    for (int q = 0; q < L1Q; ++q) acc = mfma32(a1[q], x[q], acc);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT>(acc[q]);
+    h1 = acc;
+    put_tile(lds + S::H1X + wave * XT + lane * XW, h1);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + S::B2 + 32 * wave + 8 * g + 4 * h);
+        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+    }
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        float hb[16];
+        get_tile(lds + S::H1X + tau * XT + lane * XW, hb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = mfma32(a2[tau][q], hb[q], acc);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT2>(acc[q]);
+    h2 = acc;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float s = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + S::W3 + o * HID + 32 * wave + 8 * g + 4 * h);
+            s = __builtin_fmaf(w.x, h2[4 * g], s); s = __builtin_fmaf(w.y, h2[4 * g + 1], s);
+            s = __builtin_fmaf(w.z, h2[4 * g + 2], s); s = __builtin_fmaf(w.w, h2[4 * g + 3], s);
+        }
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) lds[S::RED + (wave * 8 + o) * 32 + c] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float s = lds[S::B3 + o];
+#pragma unroll
+        for (int w = 0; w < NT; ++w) s += lds[S::RED + (w * 8 + o) * 32 + c];
+        out[o] = s;
+    }
+}
+
+// Backward pass of the workgroup's tile (see the scheme above).  h1, h2: this wave's tiles from forward(); dout: d loss / d out of
+// this lane's sample (identical in every wave).  WGRAD: this wave's slices of the weight / bias gradients into the workgroup's
+// partial vector P;  DIN: din[j] = d loss / d input[NIN - NU + j] of this lane's sample (every wave).  One workgroup barrier
+// (two with DIN); the caller barriers before the next tile's forward().
+template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN>
+__device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], f32x16& h1, f32x16& h2,
+                                         const float* dout, int wave, int lane, float* P, bool first, float* din) {
+    using S = Lds<NOUT>;
+    using G = Part<NIN, NOUT>;
+    const int c = lane & 31, h = lane >> 5;
+    float* const wl = lds + S::WAVE + wave * S::WAVE_WORDS;
+    float* const scr = wl; float* const xs = wl + TR_WORDS; float* const dout_l = xs + 34 * 32;
+    float zt[16];                                                       // dz2^T of the own tile (WGRAD)
+    if constexpr (WGRAD) {
+        if (h == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dout_l[o * 32 + c] = dout[o];
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {                            // db3: sum over the tile's 32 samples
+                float v = dout[o];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                if (lane == 0) padd(P + G::DB3 + o, v, first);
+            }
+        }
+        wave_sync();
+        float t[16];
+        tile_transpose(scr, h2, t, lane);                               // t[q] = h2[feature 32 wave + c][sample row(q, h)]
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {                                // dW3[o][f] = sum_s h2[f][s] dout[o][s]
+            float acc = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(dout_l + o * 32 + 8 * g + 4 * h);
+                acc = __builtin_fmaf(t[4 * g], dv.x, acc); acc = __builtin_fmaf(t[4 * g + 1], dv.y, acc);
+                acc = __builtin_fmaf(t[4 * g + 2], dv.z, acc); acc = __builtin_fmaf(t[4 * g + 3], dv.w, acc);
+            }
+            acc += __shfl_xor(acc, 32, 64);
+            if (h == 0) padd(P + G::DW3 + o * HID + 32 * wave + c, acc, first);
+        }
+    }
+    // dz2 = (W3^T dout) * act2'(h2), in place
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + S::W3 + o * HID + 32 * wave + 8 * g + 4 * h);
+            dh[0] = __builtin_fmaf(wv.x, dout[o], dh[0]); dh[1] = __builtin_fmaf(wv.y, dout[o], dh[1]);
+            dh[2] = __builtin_fmaf(wv.z, dout[o], dh[2]); dh[3] = __builtin_fmaf(wv.w, dout[o], dh[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[4 * g + r] = dh[r] * mlp_dact<ACT2>(h2[4 * g + r]);
+    }
+    put_tile(lds + S::DZX + wave * XT + lane * XW, h2);
+    if constexpr (WGRAD) {
+        tile_transpose(scr, h2, zt, lane);                              // dz2[out 32 wave + c][sample row(q, h)]
+        float sb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sb += zt[q];
+        sb += __shfl_xor(sb, 32, 64);
+        if (h == 0) padd(P + G::DB2 + 32 * wave + c, sb, first);
+        tile_transpose_inplace(scr, h1, lane);                          // h1[in 32 wave + c][sample row(q, h)]
+        put_tile(lds + S::H1T + wave * XT + lane * XW, h1);
+    }
+    __syncthreads();
+    // data gradient of the own input tile: dh1[32 wave + .] = sum over rho of W2[32 rho + ., 32 wave + .]^T dz2[rho]
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+    for (int rho = 0; rho < NT; ++rho) {
+        float za[16];
+        get_tile(lds + S::DZX + rho * XT + lane * XW, za);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if constexpr (WGRAD) acc = mfma32(za[q], bt[rho][q], acc);  // transposed: [sample row(q', h)][feature 32 wave + c]
+            else acc = mfma32(bt[rho][q], za[q], acc);                  // plain:      [feature row(q', h)][sample c]
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[q]);       // h1 is transposed exactly when acc is
+    if constexpr (DIN) {
+        // d loss / d (action inputs): this wave's 32 features, then the waves' partials through the LDS
+        static_assert(!WGRAD, "the input gradient is taken from the plain data gradient");
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + S::W1A + j * HID + 32 * wave + 8 * g + 4 * h);
+                s = __builtin_fmaf(wv.x, acc[4 * g], s); s = __builtin_fmaf(wv.y, acc[4 * g + 1], s);
+                s = __builtin_fmaf(wv.z, acc[4 * g + 2], s); s = __builtin_fmaf(wv.w, acc[4 * g + 3], s);
+            }
+            s += __shfl_xor(s, 32, 64);
+            if (h == 0) lds[S::DIN + (wave * 4 + j) * 32 + c] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) s += lds[S::DIN + (w * 4 + j) * 32 + c];
+            din[j] = s;
+        }
+    }
+    if constexpr (WGRAD) {
+        // dW1 | db1 slice: [dz1 tile (own 32 features x 32 samples)] x [x | 1]; D[feature row(q', h)][column c]
+        {
+            const float* const xrow = xs + (c < NIN + 1 ? c : NIN + 1) * 32 + 4 * h;
+            float xb[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + 8 * g);
+                xb[4 * g] = v.x; xb[4 * g + 1] = v.y; xb[4 * g + 2] = v.z; xb[4 * g + 3] = v.w;
+            }
+            f32x16 g1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g1[q] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g1 = mfma32(acc[q], xb[q], g1);
+            if (c <= NIN) {
+                float* const dst = P + G::DW1 + c * HID + 32 * wave + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
+                    if (!first) v += *reinterpret_cast<const f32x4*>(dst + 8 * g);
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                }
+            }
+        }
+        // dW2 tiles (in 32 tau.., out 32 wave..) = h1^T[tau] x dz2^T[own] over this tile's samples
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            float ta[16];
+            get_tile(lds + S::H1T + tau * XT + lane * XW, ta);
+            f32x16 d2;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d2[q] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d2 = mfma32(ta[q], zt[q], d2);
+            float* const p = P + G::DW2 + ((tau * NT + wave) * 64 + lane) * 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {d2[4 * g], d2[4 * g + 1], d2[4 * g + 2], d2[4 * g + 3]};
+                if (!first) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
+                *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+            }
+        }
+    }
+}
+
+// the wave's own sample cache for the dW1 product: xs[column][sample], a ones row and a zeros row behind the inputs
+template <int NIN, int L1Q>
+__device__ __forceinline__ void cache_x(float* xs, const float* x, int c, int h) {
+#pragma unroll
+    for (int q = 0; q < L1Q; ++q) {
+        const int f = d_row(q, 0);
+        if (f + 4 < NIN) xs[(f + 4 * h) * 32 + c] = x[q];
+        else if (f < NIN) { if (h == 0) xs[f * 32 + c] = x[q]; }
+    }
+    if (h == 0) { xs[NIN * 32 + c] = 1.0f; xs[(NIN + 1) * 32 + c] = 0.0f; }
+}
+
+// ---- kernels: gridDim.x workgroups of NT waves walk the 32-row tiles
+// actor forward on obs rows idx (use_next = 0) or next_obs rows (1): eps, action, log pi per batch row.
+// idx_out != nullptr (first launch of an update): the launch also DRAWS the minibatch rows and leaves them in idx_out for the later
+// launches, and snapshots log_alpha (la_out) as the policy loss sees it — a sampling launch and a 4-byte copy less
+__global__ __launch_bounds__(64 * NT, 1) void actor_fwd_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
+                                                                int use_next, const float* __restrict__ eps_in, uint32_t stream,
+                                                                float* __restrict__ eps_out, float* __restrict__ a_out,
+                                                                float* __restrict__ logp_out, int32_t* __restrict__ idx_out,
+                                                                const int32_t* __restrict__ ring_size, const int32_t* __restrict__ idx_in,
+                                                                float* __restrict__ la_out) {
+    constexpr int L1Q = 4 * ((NOBS + 7) / 8);
+    extern __shared__ __align__(16) float lds[];
+    const MlpWeights w = weights_of(params, lay);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    float a1[L1Q], a2[NT][16];
+    load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
+    load_a2(w.W2, wave, lane, a2);
+    fill_small<NA>(lds, w, threadIdx.x);
+    if (la_out && blockIdx.x == 0 && threadIdx.x == 0) *la_out = *Cm.log_alpha;
+    __syncthreads();
+    const int n_tiles = Cm.batch / 32;
+    const float* src = use_next ? Cm.next_obs : Cm.obs;
+    const uint32_t cnt = *Cm.counter;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int r = tile * 32 + c;
+        int s;
+        if (idx_out) {
+            s = sample_row(r, ring_size, idx_in, cnt, Cm.k0, Cm.k1);
+            if (wave == 0 && h == 0) idx_out[r] = s;
+        } else {
+            s = Cm.idx[r];
+        }
+        float x[L1Q];
+        load_x2<L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
+        f32x16 h1, h2;
+        float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp;
+        forward<NOBS, NA, MLP_ACT_NONE>(lds, a1, a2, x, wave, lane, h1, h2, out);
+        if (wave == 0) {
+            if (eps_in) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r * NU + j];
+            } else {
+                normal4(cnt, (uint32_t)r, stream, Cm.k0, Cm.k1, eps);
+            }
+            squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
+            if (h == 0) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { eps_out[(size_t)r * NU + j] = eps[j]; a_out[(size_t)r * NU + j] = a[j]; }
+                logp_out[r] = logp;
+            }
+        }
+    }
+}
+
 // Q networks, blockIdx.y = which (q1 / q2).
 //   MODE 0: target networks at (next_obs[idx], a_in[row])                 -> q_out[y][row]
 //   MODE 1: online networks at (obs[idx], a_in[row]), data gradient       -> q_out[y][row], dqda[y][row][NU]
-//   MODE 2: online networks at (obs[idx], act[idx]): d mean (q - y)^2 / d(theta_y) into the waves' partials,
+//   MODE 2: online networks at (obs[idx], act[idx]): d mean (q - y)^2 / d(theta_y) into the workgroups' partials,
 //           y = rew + gamma mask (min(qt1, qt2) - alpha logp_next)
 template <int MODE>
-__global__ __launch_bounds__(64 * WAVES, 1) void q_kernel(const float* __restrict__ params, const scg_mlp_layout lay1, const scg_mlp_layout lay2,
-                                                           const Common Cm, const float* __restrict__ a_in, const float* __restrict__ qt,
-                                                           const float* __restrict__ logp_next, float* __restrict__ q_out,
-                                                           float* __restrict__ dqda, float* __restrict__ partials) {
-    using L = MlpLds<NQ, HID, 1>;
+__global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__ params, const scg_mlp_layout lay1, const scg_mlp_layout lay2,
+                                                        const Common Cm, const float* __restrict__ a_in, const float* __restrict__ qt,
+                                                        const float* __restrict__ logp_next, float* __restrict__ q_out,
+                                                        float* __restrict__ dqda, float* __restrict__ partials) {
+    using S = Lds<1>;
     using G = Part<NQ, 1>;
-    constexpr int NINP = (NQ + 3) / 4 * 4;
+    constexpr int L1Q = 4 * ((NQ + 7) / 8);
     extern __shared__ __align__(16) float lds[];
     const int y = blockIdx.y;
-    mlp_fill_lds<NQ, HID, 1>(lds, weights_of(params, y ? lay2 : lay1), threadIdx.x);
-    __syncthreads();
+    const MlpWeights w = weights_of(params, y ? lay2 : lay1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32, B = Cm.batch;
-    float* const wl = lds + L::END + wave * (32 * NINP + 32 + TR_WORDS);
-    float* const xs = wl; float* const dout_l = xs + 32 * NINP; float* const scr = dout_l + 32;
-    float* const P = partials ? partials + ((size_t)y * Cm.n_part + wid) * PSTRIDE : nullptr;
+    float a1[L1Q], a2[NT][16], bt[NT][16];
+    load_a1<NQ, L1Q>(w.W1, wave, lane, a1);
+    load_a2(w.W2, wave, lane, a2);
+    if constexpr (MODE != 0) load_bt(w.W2, wave, lane, bt);
+    fill_small<1>(lds, w, threadIdx.x);
+    if constexpr (MODE == 1) {                                          // W1A[j][f] = W1[f][NOBS + j]
+        for (int k = threadIdx.x; k < NU * HID; k += 64 * NT) lds[S::W1A + k] = w.W1[(size_t)(k % HID) * NQ + NOBS + k / HID];
+    }
+    __syncthreads();
+    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    float* const xs = lds + S::WAVE + wave * S::WAVE_WORDS + TR_WORDS;
+    float* const P = partials ? partials + ((size_t)y * Cm.n_part + blockIdx.x) * PSTRIDE : nullptr;
     const float alpha = MODE == 2 ? expf(*Cm.log_alpha) : 0.0f;
     const float inv_b = 1.0f / (float)B;
     float st = 0.0f;
     bool first = true;
-    if (wid >= Cm.n_part) return;
-    for (int tile = wid; tile < n_tiles; tile += Cm.n_part) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int r = tile * 32 + c, s = Cm.idx[r];
-        float x[L::L1Q];
-        if constexpr (MODE == 0) load_x2<L::L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
-        else if constexpr (MODE == 1) load_x2<L::L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
-        else load_x2<L::L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
-        f32x16 h1[NT], h2[NT];
+        float x[L1Q];
+        if constexpr (MODE == 0) load_x2<L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+        else if constexpr (MODE == 1) load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+        else load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
+        f32x16 h1, h2;
         float out[1];
-        mlp_forward_tile<NQ, HID, 1, ACT>(lds, x, h1, h2, out, lane);
+        forward<NQ, 1, ACT>(lds, a1, a2, x, wave, lane, h1, h2, out);
         if constexpr (MODE == 0) {
-            if (h == 0) q_out[(size_t)y * B + r] = out[0];
+            if (wave == 0 && h == 0) q_out[(size_t)y * B + r] = out[0];
         } else if constexpr (MODE == 1) {
             const float dout[1] = {1.0f};
             float din[NU];
-            backward_tile<NQ, 1, ACT, false, true>(lds, xs, dout_l, scr, h1, h2, dout, lane, nullptr, true, din);
-            if (h == 0) {
+            backward<NQ, 1, ACT, false, true>(lds, bt, h1, h2, dout, wave, lane, nullptr, true, din);
+            if (wave == 0 && h == 0) {
                 q_out[(size_t)y * B + r] = out[0];
 #pragma unroll
                 for (int j = 0; j < NU; ++j) dqda[((size_t)y * B + r) * NU + j] = din[j];
             }
         } else {
-            cache_x<L::L1Q, NINP>(xs, x, c, h);
+            cache_x<NQ, L1Q>(xs, x, c, h);
             const float target = Cm.rew[s] + Cm.gamma * Cm.mask[s] * (fminf(qt[r], qt[B + r]) - alpha * logp_next[r]);
             const float e = out[0] - target;
             const float dout[1] = {2.0f * e * inv_b};
-            if (h == 0) st += e * e * inv_b;
-            backward_tile<NQ, 1, ACT, true, false>(lds, xs, dout_l, scr, h1, h2, dout, lane, P, first, nullptr);
+            if (wave == 0 && h == 0) st += e * e * inv_b;
+            backward<NQ, 1, ACT, true, false>(lds, bt, h1, h2, dout, wave, lane, P, first, nullptr);
             first = false;
         }
+        __syncthreads();                                                // the exchange buffers are free for the next tile
     }
     if constexpr (MODE == 2) {
+        if (wave == 0) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) st += __shfl_xor(st, m, 64);
-        if (lane == 0) { P[G::STAT] = st; P[G::STAT + 1] = 0.0f; }
+            for (int m = 32; m >= 1; m >>= 1) st += __shfl_xor(st, m, 64);
+            if (lane == 0) { P[G::STAT] = st; P[G::STAT + 1] = 0.0f; }
+        }
     }
 }
 
 // actor gradient of policy_loss = mean(alpha log pi - min(q1, q2)(obs, a)): forward recomputed with the stored noise
-__global__ __launch_bounds__(64 * WAVES, 1) void actor_grad_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
-                                                                    const float* __restrict__ eps_all, const float* __restrict__ qpi,
-                                                                    const float* __restrict__ dqda, float* __restrict__ partials) {
-    using L = MlpLds<NOBS, HID, NA>;
+__global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
+                                                                 const float* __restrict__ eps_all, const float* __restrict__ qpi,
+                                                                 const float* __restrict__ dqda, float* __restrict__ partials) {
+    using S = Lds<NA>;
     using G = Part<NOBS, NA>;
-    constexpr int NINP = (NOBS + 3) / 4 * 4;
+    constexpr int L1Q = 4 * ((NOBS + 7) / 8);
     extern __shared__ __align__(16) float lds[];
-    mlp_fill_lds<NOBS, HID, NA>(lds, weights_of(params, lay), threadIdx.x);
-    __syncthreads();
+    const MlpWeights w = weights_of(params, lay);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    const int wid = blockIdx.x * WAVES + wave, n_tiles = Cm.batch / 32, B = Cm.batch;
-    float* const wl = lds + L::END + wave * (32 * NINP + NA * 32 + TR_WORDS);
-    float* const xs = wl; float* const dout_l = xs + 32 * NINP; float* const scr = dout_l + NA * 32;
-    if (wid >= Cm.n_part) return;
-    float* const P = partials + (size_t)wid * PSTRIDE;
+    float a1[L1Q], a2[NT][16], bt[NT][16];
+    load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
+    load_a2(w.W2, wave, lane, a2);
+    load_bt(w.W2, wave, lane, bt);
+    fill_small<NA>(lds, w, threadIdx.x);
+    __syncthreads();
+    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    float* const xs = lds + S::WAVE + wave * S::WAVE_WORDS + TR_WORDS;
+    float* const P = partials + (size_t)blockIdx.x * PSTRIDE;
     const float alpha = expf(*Cm.log_alpha), inv_b = 1.0f / (float)B;
     float st_loss = 0.0f, st_logp = 0.0f;
     bool first = true;
-    for (int tile = wid; tile < n_tiles; tile += Cm.n_part) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int r = tile * 32 + c, s = Cm.idx[r];
-        float x[L::L1Q];
-        load_x2<L::L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x);
-        cache_x<L::L1Q, NINP>(xs, x, c, h);
-        f32x16 h1[NT], h2[NT];
+        float x[L1Q];
+        load_x2<L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x);
+        cache_x<NOBS, L1Q>(xs, x, c, h);
+        f32x16 h1, h2;
         float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp, dout[NA];
-        mlp_forward_tile<NOBS, HID, NA, ACT, 20, MLP_ACT_NONE>(lds, x, h1, h2, out, lane);
+        forward<NOBS, NA, MLP_ACT_NONE>(lds, a1, a2, x, wave, lane, h1, h2, out);
 #pragma unroll
         for (int j = 0; j < NU; ++j) eps[j] = eps_all[(size_t)r * NU + j];
         squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
@@ -472,21 +652,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void actor_grad_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             const float dq = dqda[((size_t)ysel * B + r) * NU + j];
-            // d/du [alpha log pi - q]:  d log pi / du = 2 tanh(u);  da/du = 0.5 (high - low)(1 - tanh^2 u)
             const float du = inv_b * (alpha * 2.0f * th[j] - dq * 0.5f * (Cm.high[j] - Cm.low[j]) * (1.0f - th[j] * th[j]));
             const float raw = out[NU + j];
             const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;      // torch.clamp's gradient
-            dout[j] = du;                                                           // d/d mu
-            dout[NU + j] = pass * (du * sig[j] * eps[j] - inv_b * alpha);           // d/d log_std: u = mu + exp(ls) eps;  -ls in log pi
+            dout[j] = du;
+            dout[NU + j] = pass * (du * sig[j] * eps[j] - inv_b * alpha);
         }
-        if (h == 0) { st_loss += (alpha * logp - fminf(q1, q2)) * inv_b; st_logp += logp * inv_b; }
-        backward_tile<NOBS, NA, MLP_ACT_NONE, true, false>(lds, xs, dout_l, scr, h1, h2, dout, lane, P, first, nullptr);
+        if (wave == 0 && h == 0) { st_loss += (alpha * logp - fminf(q1, q2)) * inv_b; st_logp += logp * inv_b; }
+        backward<NOBS, NA, MLP_ACT_NONE, true, false>(lds, bt, h1, h2, dout, wave, lane, P, first, nullptr);
         first = false;
+        __syncthreads();
     }
+    if (wave == 0) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { st_loss += __shfl_xor(st_loss, m, 64); st_logp += __shfl_xor(st_logp, m, 64); }
-    if (lane == 0) { P[G::STAT] = st_loss; P[G::STAT + 1] = st_logp; }
+        for (int m = 32; m >= 1; m >>= 1) { st_loss += __shfl_xor(st_loss, m, 64); st_logp += __shfl_xor(st_logp, m, 64); }
+        if (lane == 0) { P[G::STAT] = st_loss; P[G::STAT + 1] = st_logp; }
+    }
 }
+}  // namespace wide
 
 // Sum of the waves' partials -> flat gradient (torch parameter order); blockIdx.y = network of the launch.
 template <int NIN, int NOUT>
@@ -508,7 +691,13 @@ struct ReduceArgs {
     float* stat_out;            // [2 * gridDim.y]: STAT + 0, STAT + 1 of each network
     int alpha_slot;             // >= 0 (actor reduce): grad[alpha_slot] = d entropy_loss / d log_alpha = -(mean log pi + target_entropy)
     float target_entropy;
+    // p != nullptr (single-GPU path): the element's torch.optim.Adam step and its soft update follow its sum at once — each
+    // parameter is written by exactly one thread of one launch, so the separate adam_kernel launch and the trip of the
+    // gradient through memory go away.  Data-parallel callers leave p null, all-reduce grad and run adam_kernel.
+    float* p; float* m; float* v; float lr; const float* steps; int step_slot; float* target; float tau;
+    int alpha_on; float lr_alpha;
 };
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float t);
 template <int NIN, int NOUT>
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     __shared__ float part[4][64];
@@ -526,13 +715,24 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     if (grp != 0 || k >= words) return;
     s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
     const int d = dest_of<NIN, NOUT>(k, R.lay[net]);
-    if (d >= 0) R.grad[d] = s;
-    else if (d == -2) R.stat_out[2 * net] = s;
-    else if (d == -3) {
+    if (d >= 0) {
+        R.grad[d] = s;
+        if (R.p) {
+            adam_one(R.p[d], s, R.m[d], R.v[d], R.lr, R.steps[R.step_slot] + 1.0f);
+            if (R.target) R.target[d] = (1.0f - R.tau) * R.target[d] + R.tau * R.p[d];
+        }
+    } else if (d == -2) {
+        R.stat_out[2 * net] = s;
+    } else if (d == -3) {
         R.stat_out[2 * net + 1] = s;
         // entropy_loss = -mean(log_alpha (log pi + target_entropy)) (sac_utils.py:124-126); in the gradient vector so that a
         // data-parallel all-reduce of d_grad carries it
-        if (R.alpha_slot >= 0) R.grad[R.alpha_slot] = -(s + R.target_entropy);
+        if (R.alpha_slot >= 0) {
+            const float g = -(s + R.target_entropy);
+            const int a = R.alpha_slot;
+            R.grad[a] = g;
+            if (R.p && R.alpha_on) adam_one(R.p[a], g, R.m[a], R.v[a], R.lr_alpha, R.steps[2] + 1.0f);
+        }
     }
 }
 
@@ -605,17 +805,20 @@ static int set_lds(K kernel, size_t bytes) {
 }
 
 static size_t lds_actor_bytes() { return (MlpLds<NOBS, HID, NA>::END + WAVES * (32 * ((NOBS + 3) / 4 * 4) + NA * 32 + TR_WORDS)) * sizeof(float); }
-static size_t lds_q_bytes() { return (MlpLds<NQ, HID, 1>::END + WAVES * (32 * ((NQ + 3) / 4 * 4) + 32 + TR_WORDS)) * sizeof(float); }
+static size_t wide_lds_actor() { return wide::Lds<NA>::END * sizeof(float); }
+static size_t wide_lds_q() { return wide::Lds<1>::END * sizeof(float); }
 
 // One-time kernel attributes (dynamic LDS above 64 KB).  Call once before capturing scg_sac_update into a HIP graph: the
 // attribute calls are not stream operations.  scg_sac_update calls it itself otherwise.
 extern "C" int scg_sac_prepare(void) {
     static bool done = false;
     if (done) return 0;
-    const size_t lds_a = lds_actor_bytes(), lds_q = lds_q_bytes();
-    if (lds_a > 160 * 1024 || lds_q > 160 * 1024) return fail(-1, "scg_sac: network image does not fit the LDS");
-    if (set_lds(actor_fwd_kernel, lds_a) || set_lds(actor_grad_kernel, lds_a) || set_lds(q_kernel<0>, lds_q) || set_lds(q_kernel<1>, lds_q) ||
-        set_lds(q_kernel<2>, lds_q) || set_lds(actor_act_kernel, lds_a)) return -2;
+    const size_t lds_a = lds_actor_bytes();
+    if (lds_a > 160 * 1024 || wide_lds_actor() > 160 * 1024 || wide_lds_q() > 160 * 1024)
+        return fail(-1, "scg_sac: network image does not fit the LDS");
+    if (set_lds(actor_act_kernel, lds_a)) return -2;
+    if (set_lds(wide::actor_fwd_kernel, wide_lds_actor()) || set_lds(wide::actor_grad_kernel, wide_lds_actor()) ||
+        set_lds(wide::q_kernel<0>, wide_lds_q()) || set_lds(wide::q_kernel<1>, wide_lds_q()) || set_lds(wide::q_kernel<2>, wide_lds_q())) return -2;
     done = true;
     return 0;
 }
@@ -626,11 +829,11 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
         return fail(-1, "scg_sac_update: NULL argument");
     if (a->batch <= 0 || a->batch % 32) return fail(-1, "scg_sac_update: the batch size must be a positive multiple of 32");
     hipStream_t st = (hipStream_t)stream;
-    const int B = a->batch, n_part = n_part_of(B), n_wg = (n_part + WAVES - 1) / WAVES;
+    const int B = a->batch, n_part = n_part_of(B);
     const Ws w = carve(B, n_part);
     float* W = (float*)a->d_workspace;
     int32_t* idx = (int32_t*)(W + w.idx);
-    const size_t lds_a = lds_actor_bytes(), lds_q = lds_q_bytes();
+    const size_t wlds_a = wide_lds_actor(), wlds_q = wide_lds_q();
     if (int rc = scg_sac_prepare()) return rc;
     Common Cm;
     Cm.idx = idx; Cm.batch = B; Cm.n_part = n_part; Cm.obs = a->d_obs; Cm.act = a->d_act; Cm.rew = a->d_rew; Cm.next_obs = a->d_next_obs;
@@ -639,48 +842,61 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     Cm.k0 = (uint32_t)a->seed; Cm.k1 = (uint32_t)(a->seed >> 32); Cm.counter = a->d_counter;
     float* stat = W + w.stat;
     const int phases = a->phases == 0 ? SCG_SAC_ALL : a->phases;
+    // the whole step on one GPU: the optimiser steps ride in the reduction launches; data-parallel callers (phases given one
+    // by one, an all-reduce of d_grad between them) get the gradient only and step in adam_kernel
+    const bool fuse = phases == SCG_SAC_ALL;
+    auto optimiser = [&](ReduceArgs& R, float lr, int step_slot) {
+        if (!fuse) { R.p = nullptr; R.m = R.v = R.target = nullptr; R.steps = nullptr; R.lr = R.tau = R.lr_alpha = 0.0f; R.step_slot = 0; R.alpha_on = 0; return; }
+        R.p = a->d_params; R.m = a->d_m; R.v = a->d_v; R.lr = lr; R.steps = a->d_steps; R.step_slot = step_slot;
+        R.target = a->d_target; R.tau = a->tau; R.alpha_on = a->use_entropy_tuning; R.lr_alpha = a->entropy_lr;
+    };
     if (phases & SCG_SAC_ACTOR_GRAD) {
-    // 0. minibatch rows; remember log_alpha as the policy loss sees it (entropy_loss is reported with that value)
-    sample_kernel<<<dim3((B + 255) / 256), dim3(256), 0, st>>>(idx, a->d_ring_size, B, a->d_idx_in, Cm.k0, Cm.k1, a->d_counter);
-    HIP_TRY(hipMemcpyAsync(W + w.la_before, a->d_params + a->n_params, sizeof(float), hipMemcpyDeviceToDevice, st));
-    // 1. a, log pi at obs
-    actor_fwd_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, 0, a->d_eps_in, 1u, W + w.eps, W + w.a_pi, W + w.logp);
+    // 1. minibatch rows (kept in idx), log_alpha as the policy loss sees it (entropy_loss is reported with that value);
+    //    a, log pi at obs
+    wide::actor_fwd_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, 0, a->d_eps_in, 1u, W + w.eps, W + w.a_pi, W + w.logp,
+                                                                        idx, a->d_ring_size, a->d_idx_in, W + w.la_before);
     // 2. q1, q2 and dq/da at (obs, a)
-    q_kernel<1><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_params, a->q1, a->q2, Cm, W + w.a_pi, nullptr, nullptr, W + w.qpi, W + w.dqda, nullptr);
+    wide::q_kernel<1><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_params, a->q1, a->q2, Cm, W + w.a_pi, nullptr, nullptr, W + w.qpi, W + w.dqda, nullptr);
     // 3. actor gradient
-    actor_grad_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, W + w.eps, W + w.qpi, W + w.dqda, W + w.partials);
+    wide::actor_grad_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, W + w.eps, W + w.qpi, W + w.dqda, W + w.partials);
+    // 4. its sum (+ the actor and temperature steps and the soft update of the actor's target copy when fused)
     {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->actor; R.lay[1] = a->actor; R.grad = a->d_grad; R.stat_out = stat;
         R.alpha_slot = a->n_params; R.target_entropy = a->target_entropy;
+        optimiser(R, a->actor_lr, 0);
         reduce_kernel<NOBS, NA><<<dim3((Part<NOBS, NA>::END + 63) / 64, 1), dim3(256), 0, st>>>(R);
     }
     }
     if (phases & SCG_SAC_CRITIC_GRAD) {
-    // 4. actor (+ temperature) step
-    {
+    // 4'. actor (+ temperature) step after the caller's all-reduce
+    if (!fuse) {
         AdamArgs A{a->d_params, a->d_grad, a->d_m, a->d_v, 0, a->n_actor, a->actor_lr, a->d_steps, 0,
                    a->use_entropy_tuning, a->n_params, a->entropy_lr, a->target_entropy, stat, nullptr, 0, 0.0f};
         adam_kernel<<<dim3((a->n_actor + 255) / 256), dim3(256), 0, st>>>(A);
     }
     // 5. a', log pi' at next_obs with the updated actor
-    actor_fwd_kernel<<<dim3(n_wg), dim3(64 * WAVES), lds_a, st>>>(a->d_params, a->actor, Cm, 1, a->d_eps_next_in, 2u, W + w.eps2, W + w.a_next, W + w.logp_next);
+    wide::actor_fwd_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, 1, a->d_eps_next_in, 2u, W + w.eps2, W + w.a_next, W + w.logp_next,
+                                                                        nullptr, nullptr, nullptr, nullptr);
     // 6. target networks
-    q_kernel<0><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_target, a->q1, a->q2, Cm, W + w.a_next, nullptr, nullptr, W + w.qt, nullptr, nullptr);
+    wide::q_kernel<0><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_target, a->q1, a->q2, Cm, W + w.a_next, nullptr, nullptr, W + w.qt, nullptr, nullptr);
     // 7. critic gradients
-    q_kernel<2><<<dim3(n_wg, 2), dim3(64 * WAVES), lds_q, st>>>(a->d_params, a->q1, a->q2, Cm, nullptr, W + w.qt, W + w.logp_next, nullptr, nullptr, W + w.partials);
+    wide::q_kernel<2><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_params, a->q1, a->q2, Cm, nullptr, W + w.qt, W + w.logp_next, nullptr, nullptr, W + w.partials);
+    // 8. their sums (+ the critic steps and the soft update of their target copies when fused)
     {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->q1; R.lay[1] = a->q2; R.grad = a->d_grad; R.stat_out = stat + 2;
         R.alpha_slot = -1; R.target_entropy = 0.0f;
+        optimiser(R, a->critic_lr, 1);
         reduce_kernel<NQ, 1><<<dim3((Part<NQ, 1>::END + 63) / 64, 2), dim3(256), 0, st>>>(R);
     }
     }
     if (phases & SCG_SAC_FINISH) {
-    // 8. critic step + Polyak averaging of every actor-critic parameter
-    {
+    // 8'. critic step + Polyak averaging of every actor-critic parameter after the caller's all-reduce
+    if (!fuse) {
         AdamArgs A{a->d_params, a->d_grad, a->d_m, a->d_v, a->n_actor, a->n_params, a->critic_lr, a->d_steps, 1,
                    0, a->n_params, 0.0f, 0.0f, stat, a->d_target, a->n_params, a->tau};
         adam_kernel<<<dim3((a->n_params + 255) / 256), dim3(256), 0, st>>>(A);
     }
+    // 9. step counters, loss statistics
     {
         FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
         finish_kernel<<<dim3(1), dim3(64), 0, st>>>(F);
