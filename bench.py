@@ -621,18 +621,9 @@ def main():
     G = max(1, min(args.graph_len, args.steps))
     hb = StepBench(torch, args.task, N, dtype, rank=rank, generic=args.generic, graph_len=G, use_graph=not args.no_graph)
 
-    # How the host waits for the device inside barrier(): torch.cuda.synchronize() alone (hipDeviceSynchronize: the runtime may
-    # park the thread on an interrupt, tens of microseconds to wake up — a visible share of a 20-step region of ~110 us), or
-    # polling an event recorded behind the work (hipEventQuery) before that same synchronize.  Both are tried on the UNTIMED
-    # warm-up regions and the quicker one brackets the timed ones; `config.host_wait` says which and what each measured.
-    wait_ev = torch.cuda.Event()
-    wait_mode = ['device']
-
     def device_sync():
-        if wait_mode[0] == 'poll':
-            wait_ev.record()
-            while not wait_ev.query():
-                pass
+        # (measured, tools/sessions/s70.sh: polling an event behind the work before this call is SLOWER — 127.5 vs 125.0 us per
+        #  20-step region — hipDeviceSynchronize already spins)
         torch.cuda.synchronize()
 
     def barrier():
@@ -642,35 +633,22 @@ def main():
             device_sync()
 
     def timed_region():
+        # barrier + synchronize, clock, K steps, synchronize, clock, barrier.  A rank's clock stops when ITS K steps are done; the
+        # closing barrier (N > 1: an RCCL all-reduce of tens of microseconds, comparable to a 20-step region) keeps the ranks
+        # together for the next region but is not part of the K steps — the job's time is the MAX over ranks taken below.
         barrier()
         t0 = time.perf_counter()
         n = hb.do(args.steps)
-        barrier()
-        return time.perf_counter() - t0, n
+        device_sync()
+        el_s = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        return el_s, n
 
     hb.do(args.warmup)
     # timed region: EXACTLY K steps between barrier + synchronize.  When K is small (one graph replay), the same K-step
     # region is repeated and the median repeat is reported (every repeat is bracketed the same way).
     repeats = 1 if args.steps >= 5000 else 31
-    host_wait = {'mode': 'device'}
-    if repeats > 1 and os.environ.get('SCG_BENCH_HOST_WAIT', 'auto') in ('auto', 'poll', 'device'):
-        forced = os.environ.get('SCG_BENCH_HOST_WAIT', 'auto')
-        if forced == 'auto':                            # untimed calibration: 9 regions per mode
-            cal = {}
-            for mode in ('device', 'poll'):
-                wait_mode[0] = mode
-                cal[mode] = statistics.median([timed_region()[0] for _ in range(9)])
-            best = min(cal, key=cal.get)
-            if world > 1:                               # one choice for every rank (rank 0's)
-                pick = torch.tensor([0 if best == 'device' else 1], device=dev if backend == 'nccl' else 'cpu')
-                dist.broadcast(pick, 0)
-                best = 'poll' if int(pick.item()) else 'device'
-            wait_mode[0] = best
-            host_wait = {'mode': best, 'calibration_region_ms': {k: round(1e3 * v, 4) for k, v in cal.items()},
-                         'note': 'chosen on untimed warm-up regions; poll = hipEventQuery loop on an event behind the work, then the same synchronize'}
-        else:
-            wait_mode[0] = forced
-            host_wait = {'mode': forced, 'note': 'SCG_BENCH_HOST_WAIT'}
     samples, done_steps = [], args.steps
     for _ in range(repeats):
         el_s, done_steps = timed_region()
@@ -698,9 +676,9 @@ def main():
                        'parallelism': f'env-shard x{world}', 'rccl_ranks': rccl_ranks, 'collective_backend': backend if world > 1 else None,
                        'finite_outputs': ok,
                        'kernel_build': 'config-specialised' if hb.env.specialized else 'generic',
-                       'timing': f'median of {repeats} timed repeats of the {done_steps}-step region' if repeats > 1 else 'one timed region',
-                       'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))],
-                       'host_wait': host_wait},
+                       'timing': (f'median of {repeats} timed repeats of the {done_steps}-step region' if repeats > 1 else 'one timed region')
+                                 + ('; per rank: barrier + synchronize, clock, K steps, synchronize, clock, barrier; MAX over ranks' if world > 1 else ''),
+                       'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))]},
             'roofline': roofline_of(args.task, args.dtype, N, period_us),
         }
     full = not args.no_secondary and args.task == 'quadrotor_2D_track' and args.dtype == 'f32'
