@@ -341,9 +341,12 @@ class EnvSpec:
         ti = self.TASK_INFO
         if self.TASK == 'stabilization':
             g = ti['stabilization_goal']
-            self.X_GOAL = np.asarray({1: [g[1], 0.0] if len(g) > 1 else None,
-                                      2: [g[0], 0.0, g[1], 0.0, 0.0, 0.0] if len(g) > 1 else None,
-                                      3: ([g[0], 0.0, g[1], 0.0, g[2], 0.0] + [0.0] * 6) if len(g) > 2 else None}[qt], dtype=float)
+            # (quadrotor.py:264-278 indexes the goal: [x, z] for 1-D — z is entry 1 — and 2-D, [x, y, z] for 3-D; a shorter list
+            #  raises IndexError there, and here — not a NaN reference)
+            if len(g) < (3 if qt == 3 else 2):
+                raise IndexError('list index out of range')
+            self.X_GOAL = np.asarray({1: [g[1], 0.0], 2: [g[0], 0.0, g[1], 0.0, 0.0, 0.0],
+                                      3: [g[0], 0.0, g[1], 0.0] + [g[2] if qt == 3 else 0.0, 0.0] + [0.0] * 6}[qt], dtype=float)
             self.goal_tolerance = float(ti['stabilization_goal_tolerance'])
         else:
             pos, vel = self._trajectory(ti, ti['trajectory_position_offset'])
@@ -530,6 +533,28 @@ class EnvSpec:
             self.adversary_channel = chan[adv]
             self.adversary_dim = dims[adv]
             self.adversary_action_space = Box(low=-1, high=1, shape=(self.adversary_dim,))
+        self._check_quad1d_lateral_drift()
+
+    def _check_quad1d_lateral_drift(self):
+        """Upstream's 1-D quadrotor is a free 3-D body that REPORTS (z, z_dot): its `init_x` / `init_x_dot` entries (and their
+        default randomisation, U(-0.5, 0.5) / U(-0.01, 0.01)) set the drone's X position and velocity (quadrotor.py:209-211,
+        :361-384), which the observation never shows.  Alone that drift is invisible.  With a force on the `dynamics` channel it
+        is not: base_aviary.py:271-279 applies the disturbance at the position cached at the start of the control step, so a
+        drone that has moved dx since then gets the torque -dx * F_z about y, pitches, and its thrust leaves the z axis (the
+        oracle restates this; found by tests/test_gpu_config_fuzz.py).  The 1-D kernel integrates (z, z_dot) only and would
+        silently return different trajectories — refuse the combination instead."""
+        if self.name != 'quadrotor' or self.system != L.QUAD_1D:
+            return
+        if not self.dist[L.CH_DYNAMICS] and self.adversary_channel != L.CH_DYNAMICS:
+            return
+        x_dot0 = self.init_values[self.init_labels.index('init_x_dot')]
+        drawn = bool(self.kw['randomized_init']) and 'init_x_dot' in self.init_rand_info
+        if x_dot0 != 0.0 or drawn:
+            raise NotImplementedError(
+                'quad_type 1 with a dynamics disturbance / adversary and a non-zero (or randomised) init_x_dot: upstream lets the '
+                'unobserved X drift turn the disturbance into a pitch torque (base_aviary.py:272); the 1-D kernel does not model '
+                "that.  Use init_x_dot = 0 with randomized_init off (or respect_randomization_info with a table that leaves "
+                "init_x_dot out), or quad_type 2.")
 
     @property
     def adversary_observation_space(self):

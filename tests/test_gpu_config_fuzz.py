@@ -1,0 +1,82 @@
+"""Differential test over RANDOM task configs (tests/config_fuzz.py): the float64 HIP kernels of the generic library (any
+config, parameters staged in LDS) free-running against the oracle — 70 envs (a full wave and a partial one), 60 control steps of
+random actions with auto-resets, random adversary actions where the config has the channel.  The 16 golden rollouts
+(test_gpu_env_parity.py) are hand-picked combinations; this walks the YAML surface: substep counts 4-50 (incl. the
+large-rotation path of the planar integrators at 200-250 Hz engines), both costs, goal horizons, every constraint form, every
+disturbance kind per channel, uniform / normal / choice randomisation tables, projected 3-D references.  Integer / bool outputs
+exactly, floating point to rtol 1e-7 / atol 2e-9 (free-running; test_gpu_env_parity.py holds the golden rollouts to 1e-9)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from tests.config_fuzz import SYSTEMS, fuzz_config                      # noqa: E402
+from tests.test_gpu_env_parity import _flags, _np, _params, _raw_state  # noqa: E402
+
+N_ENVS, N_STEPS = 70, 60
+
+
+@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_f64_generic_kernels_vs_oracle_on_a_random_config(system, seed):
+    from oracle.envs import make_oracle_env, make_rng
+    from oracle.vec import OracleVecEnv
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = fuzz_config(system, seed)
+    n = N_ENVS
+    oracle = make_oracle_env(env_id, n, make_rng('philox', n, 100 + seed), **cfg)
+    ovec = OracleVecEnv(oracle)
+    gpu = HipVecEnv(env_id, n, seed=100 + seed, dtype=torch.float64, return_numpy=False, specialize=False, **cfg)
+    # (free-running, up to 50 engine substeps per step with randomised rates and disturbances: rounding differences of the two
+    #  float64 programs grow to ~3e-9 within 30 steps of the 15 Hz / 750 Hz 3-D case; semantic differences show up at >= 1e-7)
+    tol = dict(rtol=1e-7, atol=2e-9)
+    obs_o, info_o = ovec.reset()
+    obs_g = gpu.reset_tensors()
+    np.testing.assert_allclose(_np(obs_g), obs_o, **tol)
+    np.testing.assert_allclose(gpu.get_raw_state(), _raw_state(oracle), **tol)
+    rng = np.random.default_rng(seed)
+    n_done = 0
+    for t in range(N_STEPS):
+        msg = f'{system} seed={seed} t={t}'
+        act = rng.uniform(-1.2, 1.2, (n, oracle.action_dim))           # (beyond the normalised range now and then: clipping)
+        if not oracle.NORMALIZED_RL_ACTION_SPACE:
+            lo, hi = oracle.physical_action_bounds
+            act = lo + (act + 1.2) / 2.4 * (hi - lo) * 1.1 - 0.05 * (hi - lo)
+        adv = None
+        if oracle.adversary_disturbance is not None:
+            a = rng.uniform(-1.3, 1.3, (n, oracle.adversary_dim))
+            oracle.set_adversary_control(a)
+            gpu.set_adversary_control(a)
+            adv = gpu._adv
+        obs_o, rew_o, done_o, info = ovec.step(act)
+        out = gpu.step_tensors(torch.as_tensor(act, dtype=torch.float64, device=gpu.device), adv)
+        gpu._adv = None
+        # every output of the step is compared before anything is asserted, so that a failure names ALL the fields that moved
+        mask = 0x0F if 'out_of_bounds' in info else 0x03
+        d = np.nonzero(done_o)[0]
+        n_done += len(d)
+        checks = [('state', _np(out.state).T, oracle.state), ('obs', _np(out.obs), obs_o), ('reward', _np(out.reward), rew_o),
+                  ('mse', _np(out.mse), info['mse'])]
+        if len(d):
+            checks.append(('terminal_obs', _np(out.terminal_obs)[d], info['terminal_observation'][d]))
+        bad = []
+        for name, got, want in checks:
+            err = np.abs(got - want) - (tol['atol'] + tol['rtol'] * np.abs(want))
+            if not np.all(np.isfinite(got)) or err.max() > 0:
+                bad.append(f'{name}: max |delta| {np.nanmax(np.abs(got - want)):.3e} (rel {np.nanmax(np.abs(got - want) / (np.abs(want) + 1e-300)):.2e})')
+        if 'constraint_values' in info:
+            cv = np.abs(_np(out.c_values).T - info['constraint_values']).max()
+            if not cv <= 3.1e-8:        # (values are rounded to 8 decimals, constraints.py:109: a state delta of 3e-9 can move a row by 1-3 units)
+                bad.append(f'constraint_values: max |delta| {cv:.3e}')
+        if not np.array_equal(_np(out.done).astype(bool), done_o):
+            bad.append(f'done: {int((_np(out.done).astype(bool) != done_o).sum())} envs differ')
+        if not np.array_equal(_np(out.flags).astype(np.uint8) & mask, _flags(info) & mask):
+            bad.append('flags differ')
+        assert not bad, msg + ' -> ' + '; '.join(bad)
+    step, ep = gpu.get_counters()
+    np.testing.assert_array_equal(step, oracle.ctrl_step_counter)
+    np.testing.assert_array_equal(ep.astype(np.int64), oracle.episode)
+    if oracle.RANDOMIZED_INERTIAL_PROP:
+        np.testing.assert_allclose(gpu.get_params(), _params(oracle), rtol=1e-12)
+    gpu.close()
