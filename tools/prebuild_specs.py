@@ -27,6 +27,13 @@ def configs():
     for task in ('quadrotor_2D_track', 'cartpole_stab', 'quadrotor_3D_track'):
         env_id, c = load_task(task)
         out.append((env_id, dict(c, randomized_init=True)))
+    # tests/test_gpu_config_fuzz.py: random configs whose specialised builds are tested (SPEC_SEEDS per system, both dtypes)
+    from tests.config_fuzz import SYSTEMS, fuzz_config
+    from tests.test_gpu_config_fuzz import SPEC_SEEDS
+    for system in SYSTEMS:
+        for seed in SPEC_SEEDS:
+            env_id, c = fuzz_config(system, seed)
+            out.append((env_id, dict(c, _no_rk4=True)))
     return out
 
 
@@ -37,8 +44,9 @@ def main():
     _lib.lib()
     todo = {}
     for task, cfg in configs():
+        no_rk4 = cfg.pop('_no_rk4', False)
         variants = [cfg]
-        if not cfg.get('disturbances') and not cfg.get('adversary_disturbance'):
+        if not no_rk4 and not cfg.get('disturbances') and not cfg.get('adversary_disturbance'):
             variants.append(dict(cfg, integrator='rk4'))
         for c in variants:
             for dt in (_lib.F32, _lib.F64):
