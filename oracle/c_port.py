@@ -58,7 +58,7 @@ class CPort:
         assert c.system in (0, 2, 3)
         c.n, c.nx, c.nu, c.nobs = e.num_envs, e.state_dim, e.action_dim, e.obs_dim
         c.ns = {0: 4, 2: 6, 3: 13}[c.system]
-        c.substeps, c.ctrl_steps = e.PYB_STEPS_PER_CTRL, int(e.CTRL_STEPS)
+        c.substeps, c.ctrl_steps = e.PYB_STEPS_PER_CTRL, int(np.ceil(e.CTRL_STEPS))      # counter >= float CTRL_STEPS (benchmark_env.py:499)
         c.tracking = int(e.TASK == 'traj_tracking')
         xg = np.ascontiguousarray(np.atleast_2d(e.X_GOAL), dtype=np.float64)
         self._xg = xg

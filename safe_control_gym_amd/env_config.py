@@ -127,6 +127,7 @@ class EnvSpec:
         self.CTRL_TIMESTEP, self.PYB_TIMESTEP = 1. / self.CTRL_FREQ, 1. / self.PYB_FREQ
         self.EPISODE_LEN_SEC = kw['episode_len_sec']
         self.CTRL_STEPS = self.EPISODE_LEN_SEC * self.CTRL_FREQ
+        self.max_episode_steps = int(math.ceil(self.CTRL_STEPS))      # first counter value with counter >= CTRL_STEPS
         self.NORMALIZED_RL_ACTION_SPACE = bool(kw['normalized_rl_action_space'])
         self.obs_goal_horizon = int(kw['obs_goal_horizon'])
         if self.obs_goal_horizon > L.MAX_GOAL_HORIZON:
@@ -668,7 +669,10 @@ class EnvSpec:
         c.abi_version, c.system, c.dtype = L.SCG_ABI_VERSION, self.system, dtype
         c.integrator = L.INT_RK4 if rk4 else L.INT_PYB_EULER
         c.num_envs, c.env_id_offset, c.seed = int(num_envs), int(env_id_offset), int(seed) & 0xFFFFFFFFFFFFFFFF
-        c.substeps, c.ctrl_steps = self.PYB_STEPS_PER_CTRL, int(self.CTRL_STEPS)
+        # benchmark_env.py:148,499: CTRL_STEPS = EPISODE_LEN_SEC * CTRL_FREQ stays a FLOAT upstream and the time limit is
+        # `ctrl_step_counter >= CTRL_STEPS` — for 3.5 s at 15 Hz (52.5) the episode ends at step 53: the integer the kernels
+        # compare with is the ceiling (truncating gave 52: one step early; found by tests/test_gpu_config_fuzz.py)
+        c.substeps, c.ctrl_steps = self.PYB_STEPS_PER_CTRL, self.max_episode_steps
         c.pyb_dt, c.ctrl_dt = self.PYB_TIMESTEP, self.CTRL_TIMESTEP
         if rk4:     # `rk4_substeps` RK4 steps of the prior model per control period (mpc_utils.py:42-64 uses one)
             c.substeps = int(self.kw['rk4_substeps'])

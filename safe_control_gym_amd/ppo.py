@@ -767,7 +767,7 @@ def _evaluate_fused_device(env, policy, episodes_per_env=1):
     totals accumulated in the kernel.  Returns (device tensor [episodes, mean return, length, violations, mse], per-env
     accumulator [N, 8]) without touching the host."""
     N, dev = env.num_envs, env.device
-    steps = int(env.spec.CTRL_STEPS) * episodes_per_env
+    steps = env.spec.max_episode_steps * episodes_per_env
     buf = getattr(env, '_eval_fused', None)
     if buf is None or buf['rew'].shape[0] != steps:
         f = dict(device=dev, dtype=torch.float32)
@@ -852,7 +852,7 @@ def evaluate(ac, env, episodes_per_env=1, use_graph=None, obs_normalizer=None, p
     policy: an _lib.Policy with deterministic = 1 (PPO._policy_struct(True)) for an env built with that policy shape —
     the whole evaluation is then ONE launch of the fused rollout kernel."""
     N = env.num_envs
-    steps = int(env.spec.CTRL_STEPS) * episodes_per_env
+    steps = env.spec.max_episode_steps * episodes_per_env
     dev = env.device
     if policy is not None and obs_normalizer is None and getattr(env, 'policy_shape', None) is not None:
         res, a = _evaluate_fused_device(env, policy, episodes_per_env)

@@ -19,7 +19,7 @@ def test_envspec_agrees_with_the_oracle_on_a_random_config(system, seed):
     spec = EnvSpec(env_id, dict(cfg))
     c, keep = spec.to_c_config(n, _lib.F64, 0)
     assert (spec.nx, spec.nu, spec.obs_dim) == (o.state_dim, o.action_dim, o.obs_dim)
-    assert int(c.substeps) == o.PYB_STEPS_PER_CTRL and int(c.ctrl_steps) == int(o.CTRL_STEPS)
+    assert int(c.substeps) == o.PYB_STEPS_PER_CTRL and int(c.ctrl_steps) == int(np.ceil(o.CTRL_STEPS))     # (counter >= float CTRL_STEPS)
     np.testing.assert_allclose(np.atleast_2d(spec.X_GOAL), np.atleast_2d(o.X_GOAL), rtol=0, atol=1e-12)
     np.testing.assert_allclose(spec.U_GOAL, o.U_GOAL, rtol=1e-12)
     np.testing.assert_allclose(spec.action_space.low, o.action_space_low, rtol=1e-6)
@@ -70,3 +70,20 @@ def test_quad1d_with_a_dynamics_force_and_lateral_drift_is_refused():
         EnvSpec(env_id, dict(cfg, randomized_init=True, init_state=None))
     EnvSpec(env_id, dict(cfg, init_state={'init_x': 0.3, 'init_x_dot': 0.0}))          # X at rest: nothing to refuse
     EnvSpec(env_id, dict(cfg, disturbances=None))                                      # no dynamics force: the drift is invisible
+
+
+def test_fractional_episode_length_ends_at_the_ceiling():
+    """benchmark_env.py:148,499: CTRL_STEPS = 3.5 s * 15 Hz = 52.5 stays a float upstream, `counter >= 52.5` first holds at
+    step 53.  The kernels' integer limit was int(52.5) = 52 — one step early — until the config fuzz compared done flags."""
+    from safe_control_gym_amd.registration import load_task
+    env_id, cfg = load_task('cartpole_stab')
+    cfg.update(ctrl_freq=15, pyb_freq=750, episode_len_sec=3.5, randomized_init=False, init_state=None, constraints=None,
+               done_on_out_of_bound=False)
+    o = make_oracle_env(env_id, 2, make_rng('philox', 2, 0), **cfg)
+    o.reset()
+    for t in range(53):
+        _, _, done, info = o.step(np.zeros((2, 1)))
+        assert bool(done[0]) == (t == 52), t
+    spec = EnvSpec(env_id, dict(cfg))
+    c, _ = spec.to_c_config(2, _lib.F64, 0)
+    assert int(c.ctrl_steps) == 53 == spec.max_episode_steps and spec.CTRL_STEPS == 52.5
