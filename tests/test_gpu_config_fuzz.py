@@ -206,3 +206,64 @@ def test_sequence_equals_repeated_steps_on_a_random_config_generic(system, seed,
 @pytest.mark.parametrize('system', SYSTEMS)
 def test_sequence_equals_repeated_steps_on_a_random_config_specialised(system, seed, dtype):
     _sequence_equals_steps(system, seed, dtype, specialize=True)
+
+
+@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_single_env_facade_vs_oracle_on_a_random_config(system, seed):
+    """BenchmarkEnv.reset() / step() of the reference (single env, the CALLER resets: benchmark_env.py:320-359, 400-502) through
+    the facade on a batch-of-1 handle (`auto_reset` off — another branch of the step kernel) against the oracle's un-vectorised
+    step: observations, rewards, done, and the info dict — the same KEYS (TimeLimit.truncated only once the time is up,
+    out_of_bounds / goal_reached only where upstream defines them) and values — and the action attributes controllers read."""
+    from oracle.envs import make_oracle_env, make_rng
+    from safe_control_gym_amd.registration import make
+    env_id, cfg = fuzz_config(system, seed)
+    env = make(env_id, seed=31 + seed, **cfg)
+    o = make_oracle_env(env_id, 1, make_rng('philox', 1, 31 + seed), **cfg)
+    tol = dict(rtol=1e-7, atol=2e-9)
+    rng = np.random.default_rng(seed)
+    obs_o, info_o = o.reset()
+    obs, info = env.reset()
+    np.testing.assert_allclose(obs, obs_o[0], **tol)
+    assert info['current_step'] == 0 and ('constraint_values' in info) == ('constraint_values' in info_o)
+    if 'constraint_values' in info_o:
+        np.testing.assert_allclose(info['constraint_values'], info_o['constraint_values'][0], rtol=0, atol=3e-8)
+    episodes = 0
+    for t in range(90):
+        msg = f'{system} seed={seed} t={t}'
+        act = rng.uniform(-1.1, 1.1, o.action_dim)
+        if not o.NORMALIZED_RL_ACTION_SPACE:
+            lo, hi = o.physical_action_bounds
+            act = lo + (act + 1.1) / 2.2 * (hi - lo)
+        if o.adversary_disturbance is not None:
+            a = rng.uniform(-1.2, 1.2, o.adversary_dim)
+            o.set_adversary_control(a[None])
+            env.set_adversary_control(a)
+        obs_o, rew_o, done_o, info_o = o.step(act[None])
+        obs, rew, done, info = env.step(act)
+        assert done == bool(done_o[0]), msg
+        np.testing.assert_allclose(obs, obs_o[0], err_msg=msg, **tol)
+        np.testing.assert_allclose(rew, rew_o[0], err_msg=msg, **tol)
+        np.testing.assert_allclose(env.state, o.state[0], err_msg=msg, **tol)
+        want = {'current_step', 'constraint_violation', 'mse'}
+        want |= {k for k in ('constraint_values', 'out_of_bounds', 'goal_reached') if k in info_o}
+        if info_o['time_limit_reached'][0]:
+            want.add('TimeLimit.truncated')
+        assert set(info) == want, (msg, sorted(info), sorted(want))
+        assert info['current_step'] == int(info_o['current_step'][0]) == env.ctrl_step_counter, msg
+        assert info['constraint_violation'] == int(info_o['constraint_violation'][0]), msg
+        np.testing.assert_allclose(info['mse'], info_o['mse'][0], err_msg=msg, **tol)
+        for k in ('out_of_bounds', 'goal_reached', 'TimeLimit.truncated'):
+            if k in want:
+                assert info[k] == bool(info_o[k][0]), (msg, k)
+        if 'constraint_values' in want:
+            np.testing.assert_allclose(info['constraint_values'], info_o['constraint_values'][0], rtol=0, atol=5e-8, err_msg=msg)
+        np.testing.assert_allclose(env.current_physical_action, o.current_physical_action[0], err_msg=msg, **tol)
+        np.testing.assert_allclose(env.current_noisy_physical_action, o.current_noisy_physical_action[0], err_msg=msg, **tol)
+        np.testing.assert_allclose(env.current_clipped_action, o.current_clipped_action[0], err_msg=msg, **tol)
+        if done:
+            episodes += 1
+            obs_o, _ = o.reset()
+            obs, _ = env.reset()
+            np.testing.assert_allclose(obs, obs_o[0], err_msg=msg + ' (reset)', **tol)
+    env.close()
