@@ -28,6 +28,7 @@ class OracleVecEnv:
         out = {
             'done': done.copy(),
             'truncated': (info['TimeLimit.truncated'] & info['time_limit_reached']),
+            'time_limit_reached': info['time_limit_reached'].copy(),     # where upstream's info HAS the TimeLimit.truncated key
             'constraint_violation': info['constraint_violation'].copy(),
             'mse': info['mse'].copy(),
             'terminal_observation': obs.copy(),     # meaningful where done

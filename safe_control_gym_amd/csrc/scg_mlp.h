@@ -84,6 +84,13 @@ struct MlpLds {
     static_assert(NIN <= 32 && H % 32 == 0 && NOUT <= 8, "unsupported MLP shape");
 };
 
+// loads in flight per thread and chunk of the W2 fill: the largest divisor of `it` that is <= 32
+constexpr int fill_chunk(int it) {
+    int c = it < 32 ? it : 32;
+    while (it % c) --c;
+    return c;
+}
+
 // Cooperative fill of the LDS image from torch-layout parameters (all NTHR threads of the workgroup; caller barriers after).
 // Global reads run along the rows of W (coalesced), the permutation is applied on the LDS side.  Each phase issues ALL its
 // global loads before its first LDS store: written element by element (load, permute, store, next) the fill exposed one
@@ -110,7 +117,7 @@ __device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, in
     }
     {                                                                   // source order: W2[o][in], in fastest
         static_assert((H * H) % NTHR == 0, "workgroup size must divide H * H");
-        constexpr int IT = H * H / NTHR, CH = IT < 32 ? IT : 32;
+        constexpr int IT = H * H / NTHR, CH = fill_chunk(IT);         // H = 96: 36 loads per thread in two chunks of 18
         static_assert(IT % CH == 0, "chunking");
         for (int base = 0; base < IT; base += CH) {
             float v[CH];

@@ -134,6 +134,7 @@ class LazyInfoList(Sequence):
             fin = o.fin_stats.cpu().numpy()
             h.update(fin_return=fin[:, 0], fin_length=fin[:, 1], fin_violation=fin[:, 2], fin_mse=fin[:, 3])
             h['c_values'] = o.c_values.t().cpu().numpy() if o.c_values is not None else None
+            h['step'] = self._venv.get_counters()[0]       # ctrl_step_counter of the running episodes (benchmark_env.py:466)
             self._host = h
         return self._host
 
@@ -164,12 +165,18 @@ class LazyInfoList(Sequence):
             if flags & L.FLAG_TRUNCATED or step['current_step'] >= spec.CTRL_STEPS:
                 step['TimeLimit.truncated'] = bool(flags & L.FLAG_TRUNCATED)
             info = v._reset_info(h, i)
+            if spec.n_state_con_rows and self._out.state is not None:
+                # after_reset of the NEW episode (benchmark_env.py:356-357: state constraints only).  The kernel's c_values row is
+                # the finished episode's (-> terminal_info): evaluate the rows on the post-reset state the step returned
+                if 'state' not in h:
+                    h['state'] = self._out.state.t().cpu()
+                info['constraint_values'] = spec.state_constraint_values(h['state'][i:i + 1])[0].numpy()
             info['terminal_observation'] = h['terminal_obs'][i].astype(np.float64)
             info['terminal_info'] = step
             info['episode'] = {'r': float(h['fin_return'][i]), 'l': float(h['fin_length'][i]),
                                'constraint_violation': float(h['fin_violation'][i]), 'mse': float(h['fin_mse'][i])}
             return info
-        step.pop('current_step')
+        step['current_step'] = int(h['step'][i])
         return step
 
 

@@ -47,3 +47,40 @@ def test_gae_matches_oracle(T, N, use_gae, dtype):
     tol = dict(rtol=1e-10, atol=1e-10) if dtype == 'float64' else dict(rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(ret, ret_o, **tol)
     np.testing.assert_allclose(adv, adv_o, **tol)
+
+
+# shapes around every dispatch boundary of launch_gae (scg_kernels.hip: gae_seg_kernel for N >= 1024 and 9 <= T <= 128,
+# gae_env_kernel for N >= 1024 or T < 64, gae_wave_kernel otherwise), ragged last waves / last time chunks included
+BOUNDARY_SHAPES = [(8, 1024), (9, 1024), (9, 1030), (15, 2049), (16, 1025), (17, 1087), (127, 1100), (128, 1024), (129, 1024), (63, 1023),
+                   (64, 1023), (65, 100), (64, 64), (63, 64), (1, 1), (1, 70000), (2, 1), (300, 63), (513, 2), (40, 5000)]
+
+
+@pytest.mark.parametrize('T,N', BOUNDARY_SHAPES)
+def test_gae_dispatch_boundaries_random_parameters(T, N):
+    """Random gamma / lambda (0 and 1 included), mask densities from all-terminal to none, with and without a terminal-value
+    buffer, both advantage estimators, float64 (1e-10) and float32."""
+    from oracle.vec import compute_returns_and_advantages
+    from safe_control_gym_amd.rollout import gae_returns
+    rng = np.random.default_rng(T * 7919 + N)
+    for trial in range(3):
+        gamma = float(rng.choice([0.0, 0.9, 0.99, 1.0]))
+        lam = float(rng.choice([0.0, 0.5, 0.95, 1.0]))
+        use_gae = bool(rng.integers(0, 2))
+        p_term = float(rng.choice([0.0, 0.02, 0.3, 1.0]))
+        rews = rng.standard_normal((T, N, 1))
+        vals = rng.standard_normal((T, N, 1))
+        masks = (rng.uniform(size=(T, N, 1)) >= p_term).astype(np.float64)
+        with_term = bool(rng.integers(0, 2))
+        term = rng.standard_normal((T, N, 1)) * (masks == 0) * (rng.uniform(size=(T, N, 1)) > 0.5) if with_term else np.zeros((T, N, 1))
+        last = rng.standard_normal((N, 1))
+        ret_o, adv_o = compute_returns_and_advantages(rews.copy(), vals, masks, term, last, gamma, use_gae, lam)
+        for dtype, tol in ((torch.float64, dict(rtol=1e-10, atol=1e-10)), (torch.float32, dict(rtol=3e-4, atol=3e-4))):
+            dev = torch.device('cuda:0')
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a[..., 0]), dtype=dtype, device=dev)   # noqa: E731
+            r = t(rews)
+            ret, adv = gae_returns(r, t(vals), t(masks), t(term) if with_term else None, t(last), gamma, lam, use_gae)
+            msg = f'T={T} N={N} gamma={gamma} lam={lam} use_gae={use_gae} p_term={p_term} term={with_term} {dtype}'
+            scale = max(1.0, float(np.abs(ret_o).max()))           # (gamma = 1: returns grow with T)
+            np.testing.assert_allclose(ret.cpu().numpy() / scale, ret_o[..., 0] / scale, err_msg=msg, **tol)
+            np.testing.assert_allclose(adv.cpu().numpy() / scale, adv_o[..., 0] / scale, err_msg=msg, **tol)
+            np.testing.assert_allclose(r.cpu().numpy(), (rews + gamma * term)[..., 0], rtol=1e-6, atol=1e-6, err_msg=msg)

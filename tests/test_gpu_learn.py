@@ -9,7 +9,10 @@ import pytest
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(12, 128, 2, 'tanh'), (4, 64, 1, 'leaky_relu'), (24, 128, 4, 'relu'), (12, 32, 2, 'tanh')]
+SHAPES = [(12, 128, 2, 'tanh'), (4, 64, 1, 'leaky_relu'), (24, 128, 4, 'relu'), (12, 32, 2, 'tanh'),
+          # shapes no shipped task has: three feature tiles (96: the W2 fill did not compile before round 3's fill_chunk), input
+          # widths that are not multiples of 4 / 8, the widest input, a one-float observation
+          (7, 96, 1, 'relu'), (17, 96, 2, 'tanh'), (31, 64, 4, 'leaky_relu'), (1, 32, 1, 'tanh'), (9, 64, 4, 'tanh')]
 
 
 def _agent(obs_dim, hidden, act_dim, act, **extra):

@@ -30,6 +30,7 @@ def _setup(task, n, hidden, act, seed=5, override=None):
 
 @pytest.mark.parametrize('task,hidden,act,override', [('quadrotor_2D_track', 128, 'tanh', None), ('cartpole_stab', 64, 'leaky_relu', None),
                                                       ('quadrotor_3D_track', 128, 'relu', None),
+                                                      ('quadrotor_2D_track', 96, 'tanh', None),       # three feature tiles per hidden layer
                                                       ('quadrotor_2D_track', 64, 'tanh', STAB6)])     # rows of 24 bytes: no LDS transpose
 @pytest.mark.parametrize('epw', ['64', '32'])         # envs per wave: lane = env / lane pair = env (shards <= 32 768 envs by default)
 def test_fused_rollout_equals_step_by_step(task, hidden, act, override, epw, monkeypatch):

@@ -90,23 +90,35 @@ def test_fused_update_reproduces_the_reference_sac_agent():
 
 @pytest.mark.parametrize('tuning', [False, True])
 def test_fused_update_equals_the_eager_update_at_the_production_shape(tuning):
+    _fused_vs_eager(24, 4, 128, 'relu', tuning, 4096)
+
+
+# shapes no shipped task has: three feature tiles (hidden 96), input widths that are not multiples of 4 / 8, obs + act = 31 (the
+# widest Q input the library serves), one-float observations, three actions; batches of 1 to 20 tiles
+@pytest.mark.parametrize('obs_dim,act_dim,hidden,act,B', [(7, 1, 96, 'relu', 256), (17, 2, 96, 'tanh', 640), (27, 4, 64, 'leaky_relu', 32),
+                                                         (1, 1, 32, 'tanh', 96), (29, 2, 128, 'relu', 512), (3, 3, 32, 'relu', 224)])
+def test_fused_update_equals_the_eager_update_on_other_shapes(obs_dim, act_dim, hidden, act, B):
+    _fused_vs_eager(obs_dim, act_dim, hidden, act, bool(obs_dim % 2), B)
+
+
+def _fused_vs_eager(nobs, nu, hidden, act, tuning, B):
     from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
     dev = torch.device('cuda', 0)
-    low, high = -torch.ones(4, device=dev), torch.ones(4, device=dev)
-    kw = dict(hidden_dim=128, activation='relu', use_entropy_tuning=tuning, actor_lr=1e-3, critic_lr=1e-3, entropy_lr=1e-3)
+    low, high = -torch.ones(nu, device=dev), torch.ones(nu, device=dev)
+    kw = dict(hidden_dim=hidden, activation=act, use_entropy_tuning=tuning, actor_lr=1e-3, critic_lr=1e-3, entropy_lr=1e-3)
     torch.manual_seed(3)
-    eager = SACAgent(24, 4, low, high, SACConfig(**kw, extra={'cuda_graphs': False}), dev)
-    fused = SACAgent(24, 4, low, high, SACConfig(**kw), dev)
+    eager = SACAgent(nobs, nu, low, high, SACConfig(**kw, extra={'cuda_graphs': False}), dev)
+    fused = SACAgent(nobs, nu, low, high, SACConfig(**kw), dev)
     assert fused.use_fused and not eager.use_fused
     fused.ac.load_state_dict(eager.ac.state_dict()); fused.ac_targ.load_state_dict(eager.ac_targ.state_dict())
-    cap, B = 20000, 4096
-    buf = DeviceReplay(cap, 24, 4, dev)
+    cap = 20000
+    buf = DeviceReplay(cap, nobs, nu, dev)
     g = torch.Generator(device=dev).manual_seed(5)
     r = lambda *s: torch.randn(*s, device=dev, generator=g)                     # noqa: E731
-    buf.push(r(cap, 24), torch.tanh(r(cap, 4)), r(cap), r(cap, 24), (torch.rand(cap, device=dev, generator=g) > 0.05).float())
+    buf.push(r(cap, nobs), torch.tanh(r(cap, nu)), r(cap), r(cap, nobs), (torch.rand(cap, device=dev, generator=g) > 0.05).float())
     for step in range(3):
         idx = torch.randint(0, cap, (B,), device=dev, generator=g)
-        eps, eps2 = r(B, 4), r(B, 4)
+        eps, eps2 = r(B, nu), r(B, nu)
         batch = {k: getattr(buf, k)[idx] for k in ('obs', 'act', 'rew', 'next_obs', 'mask')}
         # reference gradients of this step from autograd on the eager agent's CURRENT weights
         with RecordNoise(replay=[eps, eps2]):
