@@ -338,3 +338,55 @@ def test_reference_vec_api_info_dicts_on_a_random_config(system, seed):
             if 'constraint_values' in want:
                 np.testing.assert_allclose(st['constraint_values'], io['constraint_values'][i], rtol=0, atol=5e-8, err_msg=msg)
     env.close()
+
+
+@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_partial_reset_and_random_state_round_trip_on_a_random_config(system, seed):
+    """scg_reset with a mask (the envs a caller resets itself) against the oracle's reset(idx) — other envs untouched, the reset
+    ones on the next episode's draws — and get / set_env_random_state (dummy_vec_env.py:68-74): replaying the same actions from a
+    restored snapshot reproduces every output bit for bit (disturbance offsets, randomised parameters, episode counters)."""
+    oracle, ovec, gpu = _pair(system, seed, torch.float64, False)
+    n = oracle.num_envs
+    tol = dict(rtol=1e-7, atol=2e-9)
+    ovec.reset()
+    gpu.reset_tensors()
+    rng = np.random.default_rng(1000 + seed)
+    for t in range(6):
+        act, adv = _draw_actions(rng, oracle, gpu)
+        ovec.step(act)
+        gpu.step_tensors(torch.as_tensor(act, dtype=torch.float64, device=gpu.device), adv)
+    mask = rng.random(n) < 0.35
+    mask[0] = True
+    idx = np.nonzero(mask)[0]
+    obs_o, _ = oracle.reset(idx)
+    obs_g = _np(gpu.reset_tensors(mask.astype(np.uint8)))
+    np.testing.assert_allclose(obs_g[idx], obs_o, **tol)
+    raw_g, raw_o = gpu.get_raw_state(), _raw_state(oracle)
+    if system == 'quadrotor_2D':        # the kernel's pitch accumulates, the oracle's quaternion knows it modulo 4 pi (tumbling drones)
+        raw_g[:, 4] = raw_o[:, 4] + np.remainder(raw_g[:, 4] - raw_o[:, 4] + 2 * np.pi, 4 * np.pi) - 2 * np.pi
+    np.testing.assert_allclose(raw_g, raw_o, **tol)
+    step, ep = gpu.get_counters()
+    np.testing.assert_array_equal(step, oracle.ctrl_step_counter)
+    np.testing.assert_array_equal(ep.astype(np.int64), oracle.episode)
+    snap = gpu.get_env_random_state()
+    acts = [_draw_actions(rng, oracle, gpu) for _ in range(10)]
+    runs = []
+    for rep in range(2):
+        outs = []
+        for act, adv in acts:
+            out = gpu.step_tensors(torch.as_tensor(act, dtype=torch.float64, device=gpu.device), adv)
+            d = out.done.bool()                          # (fin_stats / terminal_obs rows are written where done only)
+            outs.append([getattr(out, k).clone() for k in ('obs', 'reward', 'done', 'flags', 'state', 'mse')] +
+                        [out.fin_stats[d].clone(), out.terminal_obs[d].clone()])
+        runs.append((outs, gpu.get_raw_state(), gpu.get_counters(), gpu.ep_stats.clone()))
+        if rep == 0:
+            gpu.set_env_random_state(snap)
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    for x, y in zip(runs[0][2], runs[1][2]):
+        np.testing.assert_array_equal(x, y)
+    assert torch.equal(runs[0][3], runs[1][3])
+    gpu.close()
