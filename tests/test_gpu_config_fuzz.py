@@ -390,3 +390,46 @@ def test_partial_reset_and_random_state_round_trip_on_a_random_config(system, se
         np.testing.assert_array_equal(x, y)
     assert torch.equal(runs[0][3], runs[1][3])
     gpu.close()
+
+
+@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('system', SYSTEMS)
+def test_rollout_random_on_a_random_config(system, seed):
+    """scg_rollout_random (BASELINE config #2's loop: K control steps per launch, actions ~ U(-1, 1) drawn in the kernel, state in
+    registers between steps) == K oracle steps fed the same Philox actions: reward sums, done / violation counts, last observation,
+    final simulator state and counters."""
+    from oracle.envs import make_oracle_env, make_rng
+    from oracle.rng import CH_RANDOM_ACTION, make_tag
+    from oracle.vec import OracleVecEnv
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = fuzz_config(system, seed)
+    cfg['adversary_disturbance'] = None                 # (the loop has no adversary input)
+    n, K = N_ENVS, 45
+    oracle = make_oracle_env(env_id, n, make_rng('philox', n, 300 + seed), **cfg)
+    ovec = OracleVecEnv(oracle)
+    gpu = HipVecEnv(env_id, n, seed=300 + seed, dtype=torch.float64, return_numpy=False, specialize=False, **cfg)
+    ovec.reset()
+    gpu.reset_tensors()
+    idx = np.arange(n)
+    rsum, dcount, vcount = np.zeros(n), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    tag = make_tag(CH_RANDOM_ACTION, 0, 0)
+    for _ in range(K):
+        w = oracle.rng.words(idx, oracle.episode, oracle.ctrl_step_counter, tag)
+        act = -1.0 + 2.0 * (((w[:, :oracle.action_dim] >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0)
+        obs, rew, done, info = ovec.step(act)
+        rsum += rew
+        dcount += done
+        vcount += info['constraint_violation']
+    r, d, v, last = gpu.rollout_random(K)
+    np.testing.assert_array_equal(_np(d), dcount)
+    np.testing.assert_array_equal(_np(v), vcount)
+    np.testing.assert_allclose(_np(r), rsum, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(_np(last), obs, rtol=1e-7, atol=2e-9)
+    raw_g, raw_o = gpu.get_raw_state(), _raw_state(oracle)
+    if system == 'quadrotor_2D':
+        raw_g[:, 4] = raw_o[:, 4] + np.remainder(raw_g[:, 4] - raw_o[:, 4] + 2 * np.pi, 4 * np.pi) - 2 * np.pi
+    np.testing.assert_allclose(raw_g, raw_o, rtol=1e-7, atol=2e-9)
+    step, ep = gpu.get_counters()
+    np.testing.assert_array_equal(step, oracle.ctrl_step_counter)
+    np.testing.assert_array_equal(ep.astype(np.int64), oracle.episode)
+    gpu.close()
