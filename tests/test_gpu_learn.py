@@ -200,3 +200,49 @@ def test_gradient_kernel_is_bitwise_reproducible():
     for g, st in outs[1:]:
         assert torch.equal(g, outs[0][0]) and torch.equal(st, outs[0][1])
     assert float(outs[0][0].abs().sum()) > 0
+
+
+# ---- directly against the REFERENCE's PPOAgent.update (tests/golden/learner.npz, learner_variants.npz)
+def _fixture_cases():
+    from tests.golden.learner_cases import PPO_CASES
+    cases = [('learner.npz', 'ppo', dict(obs=12, act=2, kw=dict(hidden_dim=32, activation='tanh', use_clipped_value=False, clip_param=0.2,
+                                                                 target_kl=0.02, entropy_coef=0.01, actor_lr=3e-3, critic_lr=1e-3, opt_epochs=3,
+                                                                 mini_batch_size=64)))]
+    for name, c in sorted(PPO_CASES.items()):
+        if c['kw']['mini_batch_size'] % 32 == 0:            # (40-row minibatches take the PyTorch update: PPOAgent.update routes them)
+            cases.append(('learner_variants.npz', f'ppo/{name}', c))
+    return cases
+
+
+@pytest.mark.parametrize('file,prefix,c', _fixture_cases(), ids=lambda v: v.split('/')[-1] if isinstance(v, str) and '/' in v else None)
+def test_fused_update_reproduces_the_reference_ppo_agent(file, prefix, c):
+    """scg_ppo_grad + scg_adam_gated, minibatch by minibatch on the index rows the reference's sampler drew, from the reference's
+    initial weights: the reference's final weights, Adam step counts (the approx-KL gate) and averaged loss statistics."""
+    import os
+    from safe_control_gym_amd.ppo import PPOAgent, PPOConfig
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', file))
+    sd = lambda pre: {k[len(pre) + 1:]: torch.as_tensor(G[k]) for k in G.files if k.startswith(pre + '/')}      # noqa: E731
+    cfg = PPOConfig(**c['kw'])
+    ag = PPOAgent(c['obs'], c['act'], cfg, 'cuda:0')
+    assert ag.use_fused
+    ag.ac.load_state_dict(sd(prefix + '/init'))
+    data = {k: torch.as_tensor(G[f'{prefix}/data/{k}'], dtype=torch.float32, device='cuda') for k in ('obs', 'act', 'logp', 'adv', 'ret', 'v')}
+    data = {k: (v.reshape(-1) if k in ('logp', 'adv', 'ret', 'v') else v).contiguous() for k, v in data.items()}
+    M = data['obs'].shape[0]
+    mb = min(cfg.mini_batch_size, M)
+    n_mb = M // mb
+    F = ag._build_fused(data, mb)
+    F['stats_acc'].zero_()
+    for perm in G[prefix + '/perms']:
+        for j in range(n_mb):
+            F['idx'].copy_(torch.as_tensor(perm[j * mb:(j + 1) * mb].astype(np.int32), device='cuda'))
+            ag._fused_grad(F)
+            ag._fused_adam(F)
+    torch.cuda.synchronize()
+    n_steps = cfg.opt_epochs * n_mb
+    st = (F['stats_acc'] / n_steps).tolist()
+    assert int(round(st[4] * n_steps)) == int(G[prefix + '/actor_adam_steps']) and n_steps == int(G[prefix + '/critic_adam_steps'])
+    np.testing.assert_allclose(st[:4], G[prefix + '/results'], rtol=2e-4, atol=2e-5)
+    final = sd(prefix + '/final')
+    for k, v in ag.ac.state_dict().items():
+        torch.testing.assert_close(v.cpu(), final[k], rtol=2e-4, atol=1e-5, msg=lambda m, k=k: f'{prefix} {k}: {m}')

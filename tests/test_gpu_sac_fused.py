@@ -191,3 +191,54 @@ def test_fused_update_samples_in_the_kernel_is_reproducible_and_learns():
                                 out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     torch.testing.assert_close(out, a, rtol=1e-4, atol=1e-5)
+
+
+def _sac_variant_names():
+    from tests.golden.learner_cases import SAC_CASES
+    return sorted(SAC_CASES)
+
+
+@pytest.mark.parametrize('name', _sac_variant_names())
+def test_fused_update_reproduces_the_reference_sac_agent_in_the_corners(name):
+    """tests/golden/learner_variants.npz (the reference's SACAgent.update with a fixed temperature / tanh trunk / one-sided action
+    interval, and with a tuned temperature / four actions): four fused steps on the reference's index batches and noise."""
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    from tests.golden.learner_cases import SAC_CASES
+    c = SAC_CASES[name]
+    p = f'sac/{name}'
+    V = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'learner_variants.npz'))
+    vsd = lambda pre: {k[len(pre) + 1:]: torch.as_tensor(V[k]) for k in V.files if k.startswith(pre + '/')}       # noqa: E731
+    nu = len(c['low'])
+
+    def fill(dev):
+        buf = DeviceReplay(V[p + '/buffer/obs'].shape[0], c['obs'], nu, dev)
+        t = {k: torch.as_tensor(V[f'{p}/buffer/{k}'], dtype=torch.float32, device=dev) for k in ('obs', 'act', 'rew', 'next_obs', 'mask')}
+        buf.push(t['obs'], t['act'], t['rew'].reshape(-1), t['next_obs'], t['mask'].reshape(-1))
+        return buf
+    cpu = SACAgent(c['obs'], nu, torch.tensor(c['low']), torch.tensor(c['high']), SACConfig(**c['kw'], extra={'cuda_graphs': False}), 'cpu')
+    cpu.ac.load_state_dict(vsd(p + '/init'), strict=False); cpu.ac_targ.load_state_dict(vsd(p + '/init'), strict=False)
+    cbuf = fill('cpu')
+    torch.manual_seed(29)
+    with RecordNoise() as rec:                      # the noise the reference drew (its generator's seed on the eager CPU path)
+        for idx in V[p + '/indices']:
+            idx = torch.as_tensor(idx)
+            cpu.update({k: getattr(cbuf, k)[idx] for k in ('obs', 'act', 'rew', 'next_obs', 'mask')})
+    dev = torch.device('cuda', 0)
+    ag = SACAgent(c['obs'], nu, torch.tensor(c['low'], device=dev), torch.tensor(c['high'], device=dev), SACConfig(**c['kw']), dev)
+    assert ag.use_fused
+    ag.ac.load_state_dict(vsd(p + '/init'), strict=False); ag.ac_targ.load_state_dict(vsd(p + '/init'), strict=False)
+    buf = fill(dev)
+    res = []
+    for k, idx in enumerate(V[p + '/indices']):
+        F = ag._fused_args(buf, 64, idx=torch.as_tensor(idx, dtype=torch.int32, device=dev), eps=rec.draws[2 * k].to(dev).contiguous(),
+                           eps_next=rec.draws[2 * k + 1].to(dev).contiguous())
+        ag._fused_step(F)
+        torch.cuda.synchronize()
+        res.append(F['stats'][:3].tolist())
+    np.testing.assert_allclose(res, V[p + '/results'], rtol=1e-4, atol=1e-5)
+    for prefix, net in ((p + '/final', ag.ac), (p + '/final_targ', ag.ac_targ)):
+        final = vsd(prefix)
+        for k, v in net.state_dict().items():
+            if k in final:
+                torch.testing.assert_close(v.cpu(), final[k], rtol=2e-4, atol=1e-5, msg=lambda m, k=k: f'{prefix} {k}: {m}')
+    np.testing.assert_allclose(float(ag.log_alpha.detach()), float(V[p + '/final_log_alpha']), rtol=1e-5)

@@ -74,3 +74,72 @@ def test_sac_agent_update_reproduces_the_reference():
             if k in final:
                 torch.testing.assert_close(v, final[k], rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f'{prefix} {k}: {m}')
     np.testing.assert_allclose(float(ag.log_alpha), float(G['sac/final_log_alpha']), rtol=1e-5)
+
+
+# ---- the hyper-parameter corners (tests/golden/make_learner_variants.py -> learner_variants.npz)
+from tests.golden.learner_cases import PPO_CASES, SAC_CASES  # noqa: E402
+
+V = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'learner_variants.npz'))
+
+
+def vsd(prefix):
+    return {k[len(prefix) + 1:]: torch.as_tensor(V[k]) for k in V.files if k.startswith(prefix + '/')}
+
+
+@pytest.mark.parametrize('name', sorted(PPO_CASES))
+def test_ppo_agent_update_reproduces_the_reference_in_the_corners(name):
+    """Clipped value loss; an approx-KL gate that closes after the first minibatch (actor steps < critic steps); one whole-batch
+    epoch; plain discounted returns; relu / leaky_relu; 1 / 2 / 4 actions — returns and advantages from the reference's buffers
+    first (oracle.vec.compute_returns_and_advantages is what the GAE kernel is tested against)."""
+    from oracle.vec import compute_returns_and_advantages
+    from safe_control_gym_amd.ppo import PPOAgent, PPOConfig, normal_log_prob
+    c = PPO_CASES[name]
+    p = f'ppo/{name}'
+    ret, adv = compute_returns_and_advantages(V[p + '/raw/rew'].copy(), V[p + '/raw/v'], V[p + '/raw/mask'], V[p + '/raw/terminal_v'],
+                                              V[p + '/raw/last_val'], 0.97, c['use_gae'], 0.9)
+    np.testing.assert_allclose(ret, V[p + '/raw/ret'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(adv, V[p + '/raw/adv'], rtol=1e-5, atol=1e-6)
+    ag = PPOAgent(c['obs'], c['act'], PPOConfig(**c['kw']), 'cpu')
+    ag.ac.load_state_dict(vsd(p + '/init'))
+    data = {k: torch.as_tensor(V[f'{p}/data/{k}']) for k in ('obs', 'act', 'logp', 'adv', 'ret', 'v')}
+    with torch.no_grad():
+        mean, logstd = ag.ac.actor(data['obs'])
+        torch.testing.assert_close(normal_log_prob(mean, logstd, data['act']), data['logp'].reshape(-1), rtol=1e-5, atol=1e-5)
+    flat = {k: (v.reshape(-1) if k in ('logp', 'adv', 'ret', 'v') else v) for k, v in data.items()}
+    res = ag.update(flat, perms=V[p + '/perms'])
+    assert res['actor_steps'] == int(V[p + '/actor_adam_steps']) and res['minibatches'] == int(V[p + '/critic_adam_steps'])
+    np.testing.assert_allclose([res['policy_loss'], res['value_loss'], res['entropy_loss'], res['approx_kl']], V[p + '/results'],
+                               rtol=5e-5, atol=5e-6)
+    final = vsd(p + '/final')
+    for k, v in ag.ac.state_dict().items():
+        torch.testing.assert_close(v, final[k], rtol=1e-4, atol=5e-6, msg=lambda m, k=k: f'{name} {k}: {m}')
+
+
+@pytest.mark.parametrize('name', sorted(SAC_CASES))
+def test_sac_agent_update_reproduces_the_reference_in_the_corners(name):
+    """Fixed temperature (entropy_loss 0, log_alpha untouched) with a tanh trunk and a one-sided action interval; tuned temperature
+    with four actions and mixed bounds — four consecutive updates on the reference's index batches and noise stream."""
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    c = SAC_CASES[name]
+    p = f'sac/{name}'
+    low, high = torch.tensor(c['low']), torch.tensor(c['high'])
+    ag = SACAgent(c['obs'], len(c['low']), low, high, SACConfig(**c['kw'], extra={'cuda_graphs': False}), 'cpu')
+    ag.ac.load_state_dict(vsd(p + '/init'), strict=False)
+    ag.ac_targ.load_state_dict(vsd(p + '/init'), strict=False)
+    n = V[p + '/buffer/obs'].shape[0]
+    buf = DeviceReplay(n, c['obs'], len(c['low']), 'cpu')
+    t = {k: torch.as_tensor(V[f'{p}/buffer/{k}'], dtype=torch.float32) for k in ('obs', 'act', 'rew', 'next_obs', 'mask')}
+    buf.push(t['obs'], t['act'], t['rew'].reshape(-1), t['next_obs'], t['mask'].reshape(-1))
+    torch.manual_seed(29)
+    res = []
+    for idx in V[p + '/indices']:
+        idx = torch.as_tensor(idx)
+        r = ag.update({k: getattr(buf, k)[idx] for k in ('obs', 'act', 'rew', 'next_obs', 'mask')})
+        res.append([float(r['policy_loss']), float(r['critic_loss']), float(r['entropy_loss'])])
+    np.testing.assert_allclose(res, V[p + '/results'], rtol=5e-5, atol=5e-6)
+    for prefix, net in ((p + '/final', ag.ac), (p + '/final_targ', ag.ac_targ)):
+        final = vsd(prefix)
+        for k, v in net.state_dict().items():
+            if k in final:
+                torch.testing.assert_close(v, final[k], rtol=1e-4, atol=5e-6, msg=lambda m, k=k: f'{prefix} {k}: {m}')
+    np.testing.assert_allclose(float(ag.log_alpha.detach()), float(V[p + '/final_log_alpha']), rtol=1e-5)
