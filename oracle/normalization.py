@@ -23,6 +23,9 @@ class MeanStdNormalizer:
     def __init__(self, shape=(), clip=10.0, epsilon=1e-8):
         self.rms, self.clip, self.epsilon, self.read_only = RunningMeanStd(shape=shape), clip, epsilon, False
 
+    def set_read_only(self):                # normalization.py:70-72
+        self.read_only = True
+
     def __call__(self, x):
         x = np.asarray(x)
         if not self.read_only:
