@@ -27,7 +27,7 @@ class ReplayVecEnv:
         self.flags = (torch.as_tensor(trunc, device=device).to(torch.uint8) & self.done)            # bit 0 = TimeLimit.truncated
         N = self.num_envs
         self.seen_act = torch.zeros(self.T, N, spec.nu, **f)
-        self.seen_adv = torch.zeros(self.T, N, max(1, spec.adversary_dim or 1), **f)
+        self.seen_adv = torch.zeros(self.T, N, max(1, getattr(spec, 'adversary_dim', None) or 1), **f)
         self._fin = torch.zeros(N, 4, **f)
         self.out = StepTensors()
         for k in StepTensors.__slots__:

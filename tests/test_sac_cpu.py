@@ -156,3 +156,35 @@ def test_data_parallel_sac_update_matches_single_process(tmp_path):
     torch.testing.assert_close(got[0], got[1], rtol=0, atol=0)
     ref = _sac_run(0, 256, seed=50)
     torch.testing.assert_close(got[0], ref, rtol=1e-4, atol=1e-5)
+
+
+def test_sac_collector_reproduces_the_reference_buffer():
+    """sac.SAC.train_step against the REFERENCE's own `SAC.train_step` (controllers/sac/sac.py:269-335; tests/golden/
+    make_sac_collector.py): the recorded transitions of 4 envs x 40 vector steps are replayed (tests/replay_env.py) with the actions the
+    reference fed, and the replay ring must hold what the reference's SACBuffer holds — obs, act, rew and the TRUE next_obs / mask of the
+    time-limit fix-up (12 truncated episodes store their terminal observation with mask 1, 8 terminated ones the post-reset observation
+    with mask 0), in ring order after the wrap (160 pushes into 120 slots)."""
+    import os
+
+    import numpy as np
+    from safe_control_gym_amd.sac import SAC
+    from tests.replay_env import ReplayVecEnv, spec_for
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sac_collector.npz'))
+    tr = {k: G[f'transitions/{k}'] for k in ('act', 'next_obs', 'rew', 'done', 'trunc', 'term_obs')}
+    env = ReplayVecEnv(spec_for(dict(episode_len_sec=0.2, randomized_init=True, done_on_out_of_bound=True)), 'cpu', G['obs0'],
+                       tr['next_obs'], tr['rew'], tr['done'], tr['trunc'], tr['term_obs'])
+    cfg = SACConfig(hidden_dim=16, activation='relu', rollout_batch_size=4, warm_up_steps=0, train_interval=10 ** 9, max_buffer_size=120,
+                    extra={'cuda_graphs': False})
+    sac = SAC(env, cfg, seed=0)
+    acts = torch.as_tensor(tr['act'], dtype=torch.float32)
+    sac.agent.ac.act = lambda obs, deterministic=False: acts[env.t % env.T]      # the actions the reference fed (warm-up draws + its samples)
+    for _ in range(acts.shape[0]):
+        res = sac.train_step()
+        assert 'updates' not in res
+    assert sac.total_steps == int(G['total_steps']) and [sac.buffer.pos, sac.buffer.size] == G['buffer/pos_size'].tolist()
+    torch.testing.assert_close(env.seen_act, acts, rtol=0, atol=0)
+    for k in ('obs', 'act', 'rew', 'next_obs', 'mask'):
+        got = getattr(sac.buffer, k).numpy().reshape(G[f'buffer/{k}'].shape)
+        np.testing.assert_allclose(got, G[f'buffer/{k}'], rtol=0, atol=1e-6, err_msg=k)
+    m = G['buffer/mask'].reshape(-1)
+    assert (m == 0).sum() > 0 and (tr['trunc'].sum() > 0)                       # the fixture holds both kinds of episode end
