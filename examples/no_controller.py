@@ -7,7 +7,6 @@ on the HIP env: one env through the reference-compatible facade, and a batch thr
 """
 import argparse, os, sys, time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

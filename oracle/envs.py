@@ -27,7 +27,7 @@ from oracle import bullet
 from oracle.constraints import create_constraint_list
 from oracle.disturbances import create_disturbance_list
 from oracle.rng import (CH_ACTION, CH_DYNAMICS, CH_OBSERVATION, CH_RESET, NumpyEnvRng, PhiloxEnvRng,
-                        make_tag, u01_from_word)
+                        make_tag)
 from oracle.trajectory import generate_trajectory, transform_trajectory
 
 CHANNEL_OF_MODE = {'action': CH_ACTION, 'dynamics': CH_DYNAMICS, 'observation': CH_OBSERVATION}

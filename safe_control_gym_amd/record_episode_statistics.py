@@ -10,7 +10,6 @@ d_fin_*), and this wrapper only moves the finished episodes of a step (usually a
 from collections import deque
 
 import numpy as np
-import torch
 
 TRACKED_IN_KERNEL = {'constraint_violation': 'fin_violation', 'mse': 'fin_mse'}
 

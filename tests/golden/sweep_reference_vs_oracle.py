@@ -8,9 +8,10 @@ step; the oracle and the kernels report False there).
 
     python tests/golden/sweep_reference_vs_oracle.py [first_seed last_seed]
 """
-import os, sys, tempfile, traceback
+import os
+import sys
+import tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np
 from tests.golden import make_golden
 from tests.config_fuzz import SYSTEMS, fuzz_config
 import tests.test_oracle_golden as T

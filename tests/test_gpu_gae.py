@@ -1,6 +1,5 @@
 """scg_gae (both kernels) against the oracle restatement of ppo_utils.py:374-400 and the reference's
 own known answers (tests/golden/gae.npz)."""
-import ctypes as C
 import os
 
 import numpy as np

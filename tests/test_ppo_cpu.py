@@ -5,7 +5,6 @@ import os
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -212,7 +211,7 @@ def test_safety_layer_projection_and_training():
 
 
 def test_state_constraint_values_match_the_oracle_constraints():
-    import json, os, glob
+    import json, os
     import numpy as np
     import torch
     from oracle.envs import make_oracle_env, make_rng
