@@ -109,7 +109,11 @@ class BenchmarkEnv:
         if spec.adversary_disturbance is not None:
             self.adversary_action_space = spec.adversary_action_space
             self.adversary_observation_space = spec.observation_space
-        self.symbolic = AnalyticModel(self.NAME, spec, spec.kw.get('prior_prop') or {})
+        self.PRIOR_PROP = spec.kw.get('prior_prop')
+        # like upstream (quadrotor.py:326, cartpole.py:236: `self._setup_symbolic()` with NO argument): the model built at
+        # construction carries the env's TRUE parameters — the config's `prior_prop` is only stored (benchmark_env.py:155);
+        # controllers install it through BaseController.get_prior -> env._setup_symbolic(prior_prop=...) (base_controller.py:177-191)
+        self._setup_symbolic()
         self.np_random = np.random.default_rng(seed)
         self.action_space.seed(seed)
         self.initial_reset = False
@@ -119,6 +123,11 @@ class BenchmarkEnv:
         self._last_c_values = np.zeros(self.num_constraints)
         self._last_violation = False
         self.state = None
+
+    def _setup_symbolic(self, prior_prop={}, **kwargs):           # noqa: B006  (upstream's signature, benchmark_env.py:271)
+        """(Re)build `self.symbolic` with the given prior inertial properties (cartpole.py:390-401: pole_length / pole_mass /
+        cart_mass; quadrotor.py:468-483,514-515: M / Ixx / Iyy / Izz); missing keys fall back to the env's own values."""
+        self.symbolic = AnalyticModel(self.NAME, self._venv.spec, dict(prior_prop or {}))
 
     # ---- seeding (benchmark_env.py:193-214)
     def seed(self, seed=None):

@@ -197,3 +197,33 @@ def test_staged_reference_python_stays_out_of_history_and_out_of_the_product():
                 assert 'oracle/_ref' not in src and 'reference_root' not in src and 'ref_stubs' not in src, os.path.join(d, f)
     bench = open(os.path.join(ROOT, 'bench.py')).read()
     assert 'ref_stubs' not in bench and 'reference_root' not in bench and '/root/reference' not in bench
+
+
+def test_facade_symbolic_model_follows_upstreams_prior_prop_flow():
+    """Upstream builds `env.symbolic` at construction with the env's TRUE parameters — `_setup_symbolic()` is called without
+    arguments (quadrotor.py:326, cartpole.py:236), the config's `prior_prop` is only stored (benchmark_env.py:155) — and controllers
+    install a prior through `BaseController.get_prior -> env._setup_symbolic(prior_prop=...)` (base_controller.py:177-191).  The
+    facade's half of that, without a GPU: the method on an instance whose batch-of-1 handle is replaced by its EnvSpec.
+    (tests/golden/sweep_symbolic.py compares both models with the reference's own expressions on random parameters.)"""
+    import types
+
+    import numpy as np
+    from safe_control_gym_amd.benchmark_env import CartPole, Quadrotor
+    from safe_control_gym_amd.env_config import EnvSpec
+    from safe_control_gym_amd.registration import load_task
+    env_id, cfg = load_task('quadrotor_2D_track')
+    q = Quadrotor.__new__(Quadrotor)
+    q._venv = types.SimpleNamespace(spec=EnvSpec(env_id, dict(cfg, prior_prop={'M': 0.04, 'Iyy': 2e-5})))
+    q._setup_symbolic()                                       # what the constructor does: the stored prior_prop is NOT applied
+    assert q.symbolic.quad_mass == 0.027 and np.allclose(q.symbolic.U_EQ, 0.027 * 9.8 / 2)
+    x, u = np.array([0.1, 0.2, 1.0, -0.1, 0.05, 0.3]), np.array([0.15, 0.12])
+    f_true = q.symbolic.f(x, u)
+    q._setup_symbolic(prior_prop={'M': 0.04, 'Iyy': 2e-5})    # what BaseController.get_prior does
+    assert q.symbolic.quad_mass == 0.04 and q.symbolic.quad_Iyy == 2e-5 and np.allclose(q.symbolic.U_EQ, 0.04 * 9.8 / 2)
+    f_prior = q.symbolic.f(x, u)
+    assert np.allclose(f_prior[[0, 2, 4]], f_true[[0, 2, 4]]) and not np.allclose(f_prior[[1, 3, 5]], f_true[[1, 3, 5]])
+    env_id, cfg = load_task('cartpole_stab')
+    c = CartPole.__new__(CartPole)
+    c._venv = types.SimpleNamespace(spec=EnvSpec(env_id, dict(cfg)))
+    c._setup_symbolic(prior_prop={'pole_length': 0.7})
+    assert c.symbolic.pole_length == 0.7 and c.symbolic.cart_mass == c._venv.spec.CART_MASS
