@@ -110,6 +110,10 @@ class BenchmarkEnv:
             self.adversary_action_space = spec.adversary_action_space
             self.adversary_observation_space = spec.observation_space
         self.PRIOR_PROP = spec.kw.get('prior_prop')
+        # the randomisation tables the reset kernel draws from (quadrotor.py:208,233 / cartpole.py: the class tables unless
+        # `respect_randomization_info`); read by gp_mpc.py:715-741
+        self.INIT_STATE_RAND_INFO = spec.init_rand_info
+        self.INERTIAL_PROP_RAND_INFO = spec.param_rand_info
         # like upstream (quadrotor.py:326, cartpole.py:236: `self._setup_symbolic()` with NO argument): the model built at
         # construction carries the env's TRUE parameters — the config's `prior_prop` is only stored (benchmark_env.py:155);
         # controllers install it through BaseController.get_prior -> env._setup_symbolic(prior_prop=...) (base_controller.py:177-191)
@@ -128,6 +132,21 @@ class BenchmarkEnv:
         """(Re)build `self.symbolic` with the given prior inertial properties (cartpole.py:390-401: pole_length / pole_mass /
         cart_mass; quadrotor.py:468-483,514-515: M / Ixx / Iyy / Izz); missing keys fall back to the env's own values."""
         self.symbolic = AnalyticModel(self.NAME, self._venv.spec, dict(prior_prop or {}))
+
+    def _randomize_values_by_info(self, original_values, randomization_info):
+        """benchmark_env.py:237-268, on the HOST generator `self.np_random` (upstream's only non-env caller is
+        BaseController.get_prior with `randomize_prior_prop`, base_controller.py:180-187): every key of `original_values` that has
+        an entry {distrib, args, **kwargs} gets a draw of that numpy Generator method ADDED to it.  (The env's own reset
+        randomisation happens in the reset kernel on the Philox streams, not here.)"""
+        import copy
+        randomized = copy.deepcopy(original_values)
+        info = copy.deepcopy(randomization_info)
+        for key in original_values:
+            if key in info:
+                distrib = getattr(self.np_random, info[key].pop('distrib'))
+                d_args = info[key].pop('args', [])
+                randomized[key] += distrib(*d_args, **info[key])
+        return randomized
 
     # ---- seeding (benchmark_env.py:193-214)
     def seed(self, seed=None):

@@ -227,3 +227,10 @@ def test_facade_symbolic_model_follows_upstreams_prior_prop_flow():
     c._venv = types.SimpleNamespace(spec=EnvSpec(env_id, dict(cfg)))
     c._setup_symbolic(prior_prop={'pole_length': 0.7})
     assert c.symbolic.pole_length == 0.7 and c.symbolic.cart_mass == c._venv.spec.CART_MASS
+
+    # BaseController.get_prior with `randomize_prior_prop` (base_controller.py:180-187): additive draws from the env's host generator
+    q.np_random = np.random.default_rng(4)
+    got = q._randomize_values_by_info({'M': 0.03, 'Iyy': 1.4e-5}, {'M': {'distrib': 'uniform', 'low': -0.001, 'high': 0.001},
+                                                                   'Iyy': {'distrib': 'choice', 'args': [[1e-6, 2e-6]]}})
+    ref = np.random.default_rng(4)
+    assert got['M'] == 0.03 + ref.uniform(low=-0.001, high=0.001) and got['Iyy'] == 1.4e-5 + ref.choice([1e-6, 2e-6])
