@@ -214,7 +214,7 @@ def _fixture_cases():
     return cases
 
 
-@pytest.mark.parametrize('file,prefix,c', _fixture_cases(), ids=lambda v: v.split('/')[-1] if isinstance(v, str) and '/' in v else None)
+@pytest.mark.parametrize('file,prefix,c', _fixture_cases(), ids=[p.split('/')[-1] for _, p, _ in _fixture_cases()])
 def test_fused_update_reproduces_the_reference_ppo_agent(file, prefix, c):
     """scg_ppo_grad + scg_adam_gated, minibatch by minibatch on the index rows the reference's sampler drew, from the reference's
     initial weights: the reference's final weights, Adam step counts (the approx-KL gate) and averaged loss statistics."""
