@@ -75,19 +75,24 @@ def run(tag, tasks, rounds):
         ov = OracleVecEnv(o)
         ov.reset(); gpu.reset_tensors()
         rng = np.random.default_rng(0)
-        worst, bad = np.zeros(o.state_dim), 0
+        worst, bad, worst_c, worst_o, worst_r = np.zeros(o.state_dim), 0, 0.0, 0.0, 0.0
         for _ in range(60):
             gpu.set_raw_state(_raw_state(o)); gpu.set_counters(o.ctrl_step_counter, o.episode)
             if o.RANDOMIZED_INERTIAL_PROP:
                 gpu.set_params(_params(o))
             act = rng.uniform(-1, 1, (n, o.action_dim))
-            _, _, done_o, _ = ov.step(act)
+            obs_o, rew_o, done_o, info = ov.step(act)
             out = gpu.step_tensors(torch.as_tensor(act, dtype=torch.float32, device=gpu.device))
             same = out.done.cpu().numpy().astype(bool) == done_o
             bad += int((~same).sum())
             keep = same & ~done_o
             worst = np.maximum(worst, np.abs(out.state.cpu().numpy().T[keep] - o.state[keep]).max(axis=0))
-        print(f'{task:32s} variant float32 one-step max |state error| {worst.max():.2e} (tolerance 2e-5 x scale), done mismatches {bad}, '
+            worst_o = max(worst_o, float(np.abs(out.obs.cpu().numpy()[keep] - obs_o[keep]).max()))
+            worst_r = max(worst_r, float(np.abs(out.reward.cpu().numpy() - rew_o).max()))
+            if 'constraint_values' in info and out.c_values is not None:      # every row of every env (also the finished episodes')
+                worst_c = max(worst_c, float(np.abs(out.c_values.cpu().numpy().T - info['constraint_values']).max()))
+        print(f'{task:32s} variant float32 one-step max |error|: state {worst.max():.2e}, obs {worst_o:.2e}, reward {worst_r:.2e}, '
+              f'constraint values {worst_c:.2e} (tolerances of the parity tests: 2e-5 / 2e-5 / 3e-5 / 5e-5 x scale), done mismatches {bad}, '
               f'specialised {gpu.specialized}')
         gpu.close()
 
