@@ -234,3 +234,42 @@ def test_facade_symbolic_model_follows_upstreams_prior_prop_flow():
                                                                    'Iyy': {'distrib': 'choice', 'args': [[1e-6, 2e-6]]}})
     ref = np.random.default_rng(4)
     assert got['M'] == 0.03 + ref.uniform(low=-0.001, high=0.001) and got['Iyy'] == 1.4e-5 + ref.choice([1e-6, 2e-6])
+
+
+def test_facade_constructors_run_on_a_stub_handle(monkeypatch):
+    """The whole `BenchmarkEnv.__init__` of the single-env facade (attribute surface the reference's controllers read, prior model,
+    randomisation tables) with the batch-of-1 HIP handle replaced by a stub that only carries the EnvSpec: constructor regressions show
+    up in the CPU suite, not first on the GPU box."""
+    import safe_control_gym_amd.benchmark_env as B
+    from safe_control_gym_amd.env_config import EnvSpec
+    from safe_control_gym_amd.registration import load_task
+
+    class StubVec:
+        def __init__(self, name, n, seed=0, device=None, dtype=None, return_numpy=False, auto_reset=False, specialize='auto', **cfg):
+            assert n == 1 and auto_reset is False
+            self.spec = EnvSpec(name, cfg)
+            self.dtype, self.device, self._adv = dtype, 'cpu', None
+
+        def seed(self, s):
+            pass
+
+        def close(self):
+            pass
+    monkeypatch.setattr(B, 'HipVecEnv', StubVec)
+    for task, cls, prior in (('cartpole_stab', B.CartPole, {'pole_length': 0.6}), ('quadrotor_2D_track', B.Quadrotor, {'M': 0.03}),
+                             ('quadrotor_3D_track_disturbed', B.Quadrotor, {'M': 0.03, 'Izz': 3e-5})):
+        env_id, cfg = load_task(task)
+        e = cls(seed=3, **dict(cfg, prior_prop=prior))
+        for k in ('X_GOAL', 'U_GOAL', 'TASK', 'COST', 'NAME', 'CTRL_FREQ', 'PYB_FREQ', 'CTRL_TIMESTEP', 'EPISODE_LEN_SEC', 'TASK_INFO',
+                  'action_space', 'observation_space', 'state_space', 'physical_action_bounds', 'constraints', 'STATE_LABELS', 'STATE_UNITS',
+                  'ACTION_LABELS', 'ACTION_UNITS', 'np_random', 'INIT_STATE_RAND_INFO', 'INERTIAL_PROP_RAND_INFO', 'PRIOR_PROP', 'symbolic',
+                  'done_on_out_of_bound', 'pyb_step_counter', 'ctrl_step_counter', 'state_dim', 'action_dim', 'obs_dim'):
+            assert hasattr(e, k), (task, k)
+        assert e.PRIOR_PROP == prior and e.symbolic.nx == e.state_dim
+        if env_id == 'quadrotor':
+            assert e.symbolic.quad_mass == 0.027 and e.QUAD_TYPE in (2, 3)          # the stored prior is not applied at construction
+            e._setup_symbolic(prior_prop=e.PRIOR_PROP)
+            assert e.symbolic.quad_mass == 0.03
+        with pytest.raises(RuntimeError):
+            e.step([0.0] * e.action_dim)                                           # before reset (benchmark_env.py:230-235)
+        e.close()
