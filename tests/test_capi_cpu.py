@@ -273,3 +273,88 @@ def test_facade_constructors_run_on_a_stub_handle(monkeypatch):
         with pytest.raises(RuntimeError):
             e.step([0.0] * e.action_dim)                                           # before reset (benchmark_env.py:230-235)
         e.close()
+
+
+class _OracleBackedVec:
+    """Stand-in for the batch-of-1 HipVecEnv under the facade (CPU suite only): the slice of the tensor interface BenchmarkEnv uses,
+    filled from a private oracle instance — so tests/test_gpu_config_fuzz.py::facade_vs_oracle exercises the FACADE's host logic (flag
+    decoding, info key sets, TimeLimit.truncated, action attributes, reset info) without a GPU.  The kernels' half of that comparison is
+    the GPU test of the same name."""
+
+    def __init__(self, name, n, seed=0, device=None, dtype=None, return_numpy=False, auto_reset=False, specialize='auto', **cfg):
+        import types
+
+        import torch
+        from oracle.envs import make_oracle_env, make_rng
+        from safe_control_gym_amd.env_config import EnvSpec
+        assert n == 1 and auto_reset is False
+        self.spec = EnvSpec(name, cfg)
+        self.spec.num_constraints_or_zero = len(self.spec.con_rows)
+        self.o = make_oracle_env(name, 1, make_rng('philox', 1, seed), **cfg)
+        self.dtype, self.device, self._adv, self.num_envs = torch.float64, torch.device('cpu'), None, 1
+        self.out = types.SimpleNamespace(state=None, c_values=None)
+        self._torch = torch
+
+    def seed(self, s):
+        pass
+
+    def close(self):
+        pass
+
+    def _t(self, a):
+        return self._torch.as_tensor(np.asarray(a, dtype=np.float64))
+
+    def _fill(self, obs, c_values):
+        self.out.obs = self._t(obs)
+        self.out.state = self._t(self.o.state.T)
+        self.out.c_values = None if c_values is None else self._t(np.asarray(c_values).T)
+
+    def reset_tensors(self):
+        obs, info = self.o.reset()
+        nrows = len(self.spec.con_rows)
+        c = None
+        if nrows:
+            c = np.zeros((1, nrows))
+            if 'constraint_values' in info:
+                c[:, :info['constraint_values'].shape[1]] = info['constraint_values']
+        self._fill(obs, c)
+        return self.out.obs
+
+    def _reset_info(self, host, i, with_constraints=False):
+        from safe_control_gym_amd.vec_env import HipVecEnv
+        return HipVecEnv._reset_info(self, host, i, with_constraints)
+
+    def physical_parameters(self, i):
+        return {}
+
+    def set_adversary_control(self, a):
+        from safe_control_gym_amd.vec_env import HipVecEnv
+        self._as_device = lambda x, cols: self._t(x).reshape(1, cols)
+        HipVecEnv.set_adversary_control(self, a)
+
+    def step_tensors(self, a, adv=None):
+        o = self.o
+        if adv is not None:
+            o.adv_action = adv.numpy().copy()                       # already clipped / scaled / offset by set_adversary_control
+        obs, rew, done, info = o.step(a.numpy())
+        flags = (info['TimeLimit.truncated'] & info['time_limit_reached']).astype(np.uint8) * 1 + (info['constraint_violation'] > 0).astype(np.uint8) * 2
+        if 'out_of_bounds' in info:
+            flags = flags + info['out_of_bounds'].astype(np.uint8) * 4
+        if 'goal_reached' in info:
+            flags = flags + info['goal_reached'].astype(np.uint8) * 8
+        self._fill(obs, info.get('constraint_values'))
+        self.out.reward, self.out.done, self.out.flags = self._t(rew), self._t(done.astype(np.uint8)), self._torch.as_tensor(flags)
+        self.out.mse, self.out.noisy_action = self._t(info['mse']), self._t(np.asarray(o.current_noisy_physical_action).T)
+        return self.out
+
+
+@pytest.mark.parametrize('seed', range(3))
+@pytest.mark.parametrize('system', ['cartpole', 'quadrotor_1D', 'quadrotor_2D', 'quadrotor_3D'])
+def test_facade_host_logic_on_an_oracle_backed_handle(system, seed, monkeypatch):
+    import safe_control_gym_amd.benchmark_env as B
+    from tests.test_gpu_config_fuzz import facade_vs_oracle
+    monkeypatch.setattr(B, 'HipVecEnv', _OracleBackedVec)
+
+    def make(env_id, seed=None, **cfg):
+        return {'cartpole': B.CartPole, 'quadrotor': B.Quadrotor}[env_id](seed=seed, **cfg)
+    facade_vs_oracle(system, seed, make)

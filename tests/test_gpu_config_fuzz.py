@@ -215,8 +215,14 @@ def test_single_env_facade_vs_oracle_on_a_random_config(system, seed):
     the facade on a batch-of-1 handle (`auto_reset` off — another branch of the step kernel) against the oracle's un-vectorised
     step: observations, rewards, done, and the info dict — the same KEYS (TimeLimit.truncated only once the time is up,
     out_of_bounds / goal_reached only where upstream defines them) and values — and the action attributes controllers read."""
-    from oracle.envs import make_oracle_env, make_rng
     from safe_control_gym_amd.registration import make
+    facade_vs_oracle(system, seed, make)
+
+
+def facade_vs_oracle(system, seed, make):
+    """Body of the facade test; `make(env_id, seed=..., **cfg)` builds the facade (tests/test_capi_cpu.py runs it on a stub handle
+    backed by a second oracle instance: the facade's host logic in the CPU suite)."""
+    from oracle.envs import make_oracle_env, make_rng
     env_id, cfg = fuzz_config(system, seed)
     env = make(env_id, seed=31 + seed, **cfg)
     o = make_oracle_env(env_id, 1, make_rng('philox', 1, 31 + seed), **cfg)
