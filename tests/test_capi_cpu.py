@@ -358,3 +358,46 @@ def test_facade_host_logic_on_an_oracle_backed_handle(system, seed, monkeypatch)
     def make(env_id, seed=None, **cfg):
         return {'cartpole': B.CartPole, 'quadrotor': B.Quadrotor}[env_id](seed=seed, **cfg)
     facade_vs_oracle(system, seed, make)
+
+
+@pytest.mark.parametrize('system', ['cartpole', 'quadrotor_2D'])
+def test_the_references_own_lqr_controller_drives_the_facade(system, monkeypatch, tmp_path):
+    """BASELINE config #1 (examples/lqr/lqr_experiment.py: LQR stabilisation, one env) with the REFERENCE's own controller class
+    (controllers/lqr/lqr.py + lqr_utils.py, imported from the reference checkout): `LQR(env_func, q_lqr, r_lqr)` builds its env through
+    `env_func()`, takes the prior model through `BaseController.get_prior`, linearises it with `model.df_func(X_EQ, U_EQ)`, solves the
+    discrete Riccati equation, and `select_action(obs, info)` closes the loop on `env.step` — every call lands on this package's facade
+    (here on the oracle-backed handle of the CPU suite) and the task is solved."""
+    import functools
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout (build container, or the scratch copy staged by tools/stage_reference.py)')
+    ref_stubs.install()
+    from safe_control_gym.controllers.lqr.lqr import LQR
+    import safe_control_gym_amd.benchmark_env as B
+    monkeypatch.setattr(B, 'HipVecEnv', _OracleBackedVec)
+    if system == 'cartpole':
+        cls, q, r = B.CartPole, [1, 1, 1, 1], [0.1]
+        cfg = dict(ctrl_freq=15, pyb_freq=750, task='stabilization', task_info={'stabilization_goal': [1.0, 0.0], 'stabilization_goal_tolerance': 0.0},
+                   episode_len_sec=6, cost='quadratic', rew_state_weight=q, rew_act_weight=r, done_on_out_of_bound=True, randomized_init=False,
+                   normalized_rl_action_space=False, init_state={'init_x': -0.5, 'init_x_dot': 0.05, 'init_theta': 0.1, 'init_theta_dot': -0.05})
+    else:
+        cls, q, r = B.Quadrotor, [1, 1, 1, 1, 1, 1], [0.1, 0.1]
+        cfg = dict(quad_type=2, ctrl_freq=50, pyb_freq=1000, task='stabilization', episode_len_sec=5, cost='quadratic', rew_state_weight=q,
+                   rew_act_weight=r, task_info={'stabilization_goal': [0.5, 1.2], 'stabilization_goal_tolerance': 0.0}, done_on_out_of_bound=True,
+                   randomized_init=False, normalized_rl_action_space=False, init_state={'init_x': 0.0, 'init_z': 1.0, 'init_theta': 0.05})
+    env_func = functools.partial(cls, **cfg)
+    ctrl = LQR(env_func, q_lqr=q, r_lqr=r, discrete_dynamics=True, output_dir=str(tmp_path), training=False, seed=42)
+    assert ctrl.gain.shape == (len(r), len(q)) and ctrl.model is ctrl.env.symbolic
+    env = env_func(seed=42)
+    obs, info = env.reset()
+    done, steps = False, 0
+    while not done:
+        obs, rew, done, info = env.step(ctrl.select_action(obs, info))
+        steps += 1
+    assert steps == env.CTRL_STEPS and info['TimeLimit.truncated'] is True          # the controller kept it in bounds to the time limit
+    assert np.linalg.norm(obs - env.X_GOAL) < 0.05, obs
+    ctrl.close(); env.close()
+    for m in [k for k in sys.modules if k.startswith('safe_control_gym.') or k == 'safe_control_gym']:
+        sys.modules.pop(m, None)                        # (keep the reference package out of the other tests' module table)
