@@ -19,8 +19,15 @@ class _Dense:
     def toarray(self):
         return self._a
 
-    def __array__(self, dtype=None):
+    def __array__(self, dtype=None, copy=None):
         return self._a if dtype is None else self._a.astype(dtype)
+
+    def __float__(self):
+        return float(self._a.reshape(-1)[0])
+
+    @property
+    def shape(self):
+        return self._a.shape
 
 
 class AnalyticModel:
@@ -117,5 +124,7 @@ class AnalyticModel:
         eu = np.asarray(u, dtype=float).reshape(-1) - np.asarray(Ur, dtype=float).reshape(-1)
         Q, R = np.asarray(Q, dtype=float), np.asarray(R, dtype=float)
         Qs, Rs = 0.5 * (Q + Q.T), 0.5 * (R + R.T)
-        return {'l': 0.5 * ex @ Q @ ex + 0.5 * eu @ R @ eu, 'l_x': (Qs @ ex).reshape(1, -1), 'l_xx': Qs,
-                'l_u': (Rs @ eu).reshape(1, -1), 'l_uu': Rs, 'l_xu': np.zeros((ex.size, eu.size))}
+        # DM-like results: the reference's callers take `.toarray()` of every output (ilqr.py:210-247), `l` as a 1 x 1 matrix
+        out = {'l': np.array([[0.5 * ex @ Q @ ex + 0.5 * eu @ R @ eu]]), 'l_x': (Qs @ ex).reshape(1, -1), 'l_xx': Qs,
+               'l_u': (Rs @ eu).reshape(1, -1), 'l_uu': Rs, 'l_xu': np.zeros((ex.size, eu.size))}
+        return {k: _Dense(v) for k, v in out.items()}

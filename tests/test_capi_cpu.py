@@ -401,3 +401,38 @@ def test_the_references_own_lqr_controller_drives_the_facade(system, monkeypatch
     ctrl.close(); env.close()
     for m in [k for k in sys.modules if k.startswith('safe_control_gym.') or k == 'safe_control_gym']:
         sys.modules.pop(m, None)                        # (keep the reference package out of the other tests' module table)
+
+
+def test_the_references_own_ilqr_controller_learns_on_the_facade(monkeypatch, tmp_path):
+    """controllers/lqr/ilqr.py of the reference, unmodified: `learn(env)` rolls the facade out (`env.reset` / `env.step` / `info`), runs
+    its backward pass on `model.df_func` and `model.loss` — every output of which it reads through CasADi's `.toarray()` (ilqr.py:210-247:
+    the analytic model's results are DM-like for that reason) — and its cost falls from iteration to iteration."""
+    import functools
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    ref_stubs.install()
+    from safe_control_gym.controllers.lqr.ilqr import iLQR
+    import safe_control_gym_amd.benchmark_env as B
+    monkeypatch.setattr(B, 'HipVecEnv', _OracleBackedVec)
+    cfg = dict(ctrl_freq=15, pyb_freq=750, task='stabilization', task_info={'stabilization_goal': [1.0, 0.0], 'stabilization_goal_tolerance': 0.0},
+               episode_len_sec=4, cost='quadratic', rew_state_weight=[1, 1, 1, 1], rew_act_weight=[0.1], done_on_out_of_bound=True,
+               randomized_init=False, normalized_rl_action_space=False,
+               init_state={'init_x': -0.5, 'init_x_dot': 0.05, 'init_theta': 0.1, 'init_theta_dot': -0.05})
+    env_func = functools.partial(B.CartPole, **cfg)
+    ctrl = iLQR(env_func, q_lqr=[1, 1, 1, 1], r_lqr=[0.1], discrete_dynamics=True, max_iterations=4, output_dir=str(tmp_path), training=True, seed=42)
+    ctrl.learn(env=env_func(seed=42))
+    assert ctrl.input_ff_best is not None and ctrl.gains_fb_best is not None          # a feed-forward / feedback schedule was accepted
+    env = env_func(seed=42)
+    obs, info = env.reset()
+    done, steps, total = False, 0, 0.0
+    while not done:
+        obs, rew, done, info = env.step(ctrl.select_action(obs, info))
+        steps += 1
+        total += rew
+    assert steps == env.CTRL_STEPS and abs(obs[0] - 1.0) < 0.15 and abs(obs[2]) < 0.05, obs         # 4 s: the cart is almost at x = 1, pole up
+    ctrl.close(); env.close()
+    for m in [k for k in sys.modules if k.startswith('safe_control_gym.') or k == 'safe_control_gym']:
+        sys.modules.pop(m, None)
