@@ -436,3 +436,45 @@ def test_the_references_own_ilqr_controller_learns_on_the_facade(monkeypatch, tm
     ctrl.close(); env.close()
     for m in [k for k in sys.modules if k.startswith('safe_control_gym.') or k == 'safe_control_gym']:
         sys.modules.pop(m, None)
+
+
+def test_the_references_experiment_harness_runs_lqr_on_the_facade(monkeypatch, tmp_path, capsys):
+    """examples/lqr/lqr_experiment.py's flow with the reference's OWN harness and controller: `BaseExperiment(env, ctrl, train_env)`,
+    `launch_training()`, `run_evaluation(n_episodes=1)` — its `RecordDataWrapper` around the facade, `_execute_evaluations`' reset / step /
+    `select_action` loop, `MetricExtractor` (experiments/base_experiment.py:90-165,310-492) — on envs built the way the example builds them
+    (`env_func(randomized_init=False, init_state=<obs of a random env's reset>)`)."""
+    import functools
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    ref_stubs.install()
+    from safe_control_gym.controllers.lqr.lqr import LQR
+    from safe_control_gym.experiments.base_experiment import BaseExperiment
+    import safe_control_gym_amd.benchmark_env as B
+    monkeypatch.setattr(B, 'HipVecEnv', _OracleBackedVec)
+    cfg = dict(ctrl_freq=15, pyb_freq=750, task='stabilization', task_info={'stabilization_goal': [1.0, 0.0], 'stabilization_goal_tolerance': 0.0},
+               episode_len_sec=6, cost='quadratic', rew_state_weight=[1, 1, 1, 1], rew_act_weight=[0.1], done_on_out_of_bound=True,
+               randomized_init=True, normalized_rl_action_space=False)
+    env_func = functools.partial(B.CartPole, seed=42, **cfg)
+    random_env = env_func()
+    ctrl = LQR(env_func, q_lqr=[1, 1, 1, 1], r_lqr=[0.1], discrete_dynamics=True, output_dir=str(tmp_path), training=False)
+    init_state, _ = random_env.reset()
+    static_env = env_func(randomized_init=False, init_state=init_state)
+    static_train_env = env_func(randomized_init=False, init_state=init_state)
+    experiment = BaseExperiment(env=static_env, ctrl=ctrl, train_env=static_train_env)
+    experiment.launch_training()
+    trajs, metrics = experiment.run_evaluation(training=True, n_episodes=1)
+    obs = np.asarray(trajs['obs'][0])
+    assert obs.shape == (91, 4) and np.asarray(trajs['action'][0]).shape == (90, 1)            # 6 s at 15 Hz + the reset observation
+    np.testing.assert_allclose(obs[0], init_state, atol=1e-12)                                 # the static env starts where the random one did
+    assert np.linalg.norm(obs[-1] - static_env.X_GOAL) < 0.05
+    for k in ('average_length', 'average_return', 'average_rmse', 'failure_rate', 'average_constraint_violation'):
+        assert k in metrics, sorted(metrics)
+    assert metrics['average_length'] == 90 and metrics['failure_rate'] == 0.0
+    for e in (static_env, static_train_env, random_env):
+        e.close()
+    ctrl.close()
+    for m in [k for k in sys.modules if k.startswith('safe_control_gym.') or k == 'safe_control_gym']:
+        sys.modules.pop(m, None)
