@@ -220,7 +220,7 @@ def test_single_env_facade_vs_oracle_on_a_random_config(system, seed):
 
 
 def facade_vs_oracle(system, seed, make):
-    """Body of the facade test; `make(env_id, seed=..., **cfg)` builds the facade (tests/test_capi_cpu.py runs it on a stub handle
+    """Body of the facade test; `make(env_id, seed=..., **cfg)` builds the facade (tests/test_facade_cpu.py runs it on a stub handle
     backed by a second oracle instance: the facade's host logic in the CPU suite)."""
     from oracle.envs import make_oracle_env, make_rng
     env_id, cfg = fuzz_config(system, seed)
