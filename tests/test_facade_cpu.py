@@ -332,3 +332,28 @@ def test_the_references_own_pid_controller_flies_the_facade(task, rmse_max, monk
     ctrl.close(); env.close()
     for m in [k for k in sys.modules if k.startswith('safe_control_gym.') or k == 'safe_control_gym']:
         sys.modules.pop(m, None)
+
+
+@pytest.mark.parametrize('algo', ['lqr', 'ilqr'])
+def test_the_references_lqr_example_script_runs_unmodified(algo):
+    """BASELINE config #1 as the reference ships it: examples/lqr/lqr_experiment.py with its own ConfigFactory, YAML overrides, registry,
+    controller and experiment harness, run by tools/run_reference_lqr_example.py with the ONE change INTEGRATION.md describes (the
+    registry's `cartpole` id -> this package's facade).  The example's own FINAL METRICS line: the 6 s episode is completed (90 steps at
+    15 Hz), no failure, no constraint violation."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_lqr_example.py'), '--algo', algo, '--stub-handle'],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('FINAL METRICS')]
+    assert line, res.stdout[-2000:]
+    m = dict(re.findall(r'(\w[\w.]*): ([-\d.e]+)', line[0]))
+    assert float(m['average_length']) == 90.0 and float(m['failure_rate']) == 0.0 and float(m['average_constraint_violation']) == 0.0
+    assert float(m['average_rmse']) < 0.6 and -30.0 < float(m['average_return']) < 0.0
