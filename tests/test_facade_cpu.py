@@ -337,7 +337,7 @@ def test_the_references_own_pid_controller_flies_the_facade(task, rmse_max, monk
 @pytest.mark.parametrize('algo', ['lqr', 'ilqr'])
 def test_the_references_lqr_example_script_runs_unmodified(algo):
     """BASELINE config #1 as the reference ships it: examples/lqr/lqr_experiment.py with its own ConfigFactory, YAML overrides, registry,
-    controller and experiment harness, run by tools/run_reference_lqr_example.py with the ONE change INTEGRATION.md describes (the
+    controller and experiment harness, run by tools/run_reference_example.py with the ONE change INTEGRATION.md describes (the
     registry's `cartpole` id -> this package's facade).  The example's own FINAL METRICS line: the 6 s episode is completed (90 steps at
     15 Hz), no failure, no constraint violation."""
     import os
@@ -349,7 +349,7 @@ def test_the_references_lqr_example_script_runs_unmodified(algo):
     if ref_stubs.reference_root() is None:
         pytest.skip('needs the reference checkout')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_lqr_example.py'), '--algo', algo, '--stub-handle'],
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py'), 'lqr', '--algo', algo, '--stub-handle'],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith('FINAL METRICS')]
@@ -357,3 +357,34 @@ def test_the_references_lqr_example_script_runs_unmodified(algo):
     m = dict(re.findall(r'(\w[\w.]*): ([-\d.e]+)', line[0]))
     assert float(m['average_length']) == 90.0 and float(m['failure_rate']) == 0.0 and float(m['average_constraint_violation']) == 0.0
     assert float(m['average_rmse']) < 0.6 and -30.0 < float(m['average_return']) < 0.0
+
+
+# shipped checkpoint -> (episode length, lower bound on the return the reference's own evaluation reports for it here)
+SHIPPED = [('ppo', 'quadrotor_2D', 'track', 250, 230.0), ('sac', 'quadrotor_2D', 'track', 250, 200.0), ('ppo', 'quadrotor_3D', 'track', 250, 200.0),
+           ('ppo', 'cartpole', 'stab', 150, 115.0), ('sac', 'cartpole', 'stab', 150, 115.0)]
+
+
+@pytest.mark.parametrize('algo,system,task,length,min_return', SHIPPED, ids=[f'{a}-{s}-{t}' for a, s, t, _, _ in SHIPPED])
+def test_the_references_rl_example_evaluates_the_shipped_models(algo, system, task, length, min_return):
+    """examples/rl/rl_experiment.py, unmodified (tools/run_reference_example.py rl): the reference's own `PPO` / `SAC` class in
+    evaluation mode loads the checkpoint the reference SHIPS (trained upstream on the real PyBullet env) and its `BaseExperiment` evaluates
+    one episode from the config's initial state — on this package's facade.  The policies hold the whole episode and collect the
+    returns they were trained to: 236.0 / 250 for the Quadrotor2D tracking PPO model (BASELINE.md's reference reward), 214 for the SAC
+    one and for Quadrotor3D PPO, 125 / 150 for CartPole.  A policy trained on Bullet's dynamics flying the restated dynamics to the
+    reward it reached there is also evidence about those dynamics (physics under it in the CPU suite: the oracle)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py'), 'rl', '--algo', algo, '--system', system,
+                          '--task', task, '--stub-handle'], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('METRICS ')]
+    assert line, res.stdout[-2000:]
+    m = json.loads(line[0][len('METRICS '):])
+    assert m['average_length'] == length and m['average_return'] >= min_return, m
