@@ -183,3 +183,28 @@ def test_controller_ids_drive_training_like_train_rl_controller():
     rap.learn()
     assert rap.total_steps == 2 * 256 * 8 and len(rap.impl.adversaries) == 3
     rap.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason='written after the GPU budget of round 3 was spent: verified on the oracle-backed handle of the CPU '
+                                        'suite (tests/test_facade_cpu.py), first run on the HIP handle pending — XPASS is the expected outcome')
+@pytest.mark.parametrize('args,key,expect', [(['lqr', '--algo', 'lqr'], 'FINAL METRICS', None),
+                                             (['rl', '--algo', 'ppo', '--system', 'quadrotor_2D', '--task', 'track'], 'METRICS ', 230.0)],
+                         ids=['lqr_experiment', 'rl_experiment_shipped_ppo_q2_track'])
+def test_reference_example_scripts_on_the_hip_handle(args, key, expect):
+    """tools/run_reference_example.py WITHOUT --stub-handle: the reference's example scripts (its ConfigFactory, registry, controller
+    classes, shipped checkpoint, experiment harness) on the facade over the real batch-of-1 HipVecEnv."""
+    import json
+    import subprocess
+    import sys
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the staged reference checkout (tools/stage_reference.py)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py')] + args, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith(key)]
+    assert line, res.stdout[-2000:]
+    if expect is not None:
+        m = json.loads(line[0][len(key):])
+        assert m['average_length'] == 250 and m['average_return'] >= expect, m
