@@ -201,7 +201,7 @@ def test_reference_example_scripts_on_the_hip_handle(args, key, expect):
     if ref_stubs.reference_root() is None:
         pytest.skip('needs the staged reference checkout (tools/stage_reference.py)')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py')] + args, capture_output=True, text=True, timeout=240)
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py')] + args, capture_output=True, text=True, timeout=90)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith(key)]
     assert line, res.stdout[-2000:]
