@@ -388,3 +388,23 @@ def test_the_references_rl_example_evaluates_the_shipped_models(algo, system, ta
     assert line, res.stdout[-2000:]
     m = json.loads(line[0][len('METRICS '):])
     assert m['average_length'] == length and m['average_return'] >= min_return, m
+
+
+def test_the_references_own_example_test_matrix_passes_on_the_facade():
+    """The reference's tests/test_examples/{test_lqr,test_rl,test_pid}.py parametrisations (its end-to-end test strategy)
+    — LQR / iLQR (12), PPO / SAC / Safe-Explorer PPO evaluating the shipped checkpoints (18), PID (4), each `n_steps=10` through the
+    example's own run() — with the registry's env ids bound to this package's facade (tools/run_reference_example.py matrix).  The other
+    example tests need CasADi + IPOPT (mpc, cbf, mpsc), PyBullet handles (no_controller) or optuna / MySQL (hpo)."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py'), 'matrix', '--stub-handle'],
+                         capture_output=True, text=True, timeout=600)
+    lines = res.stdout.splitlines()
+    assert not [ln for ln in lines if ln.startswith('FAILED')] and res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
+    assert 'MATRIX 34 passed of 34' in lines[-1] and sum(ln.startswith('PASSED') for ln in lines) == 34

@@ -12,6 +12,12 @@ The ONE change is the one INTEGRATION.md describes: the registry's env ids point
 
     python tools/run_reference_example.py lqr [--algo lqr|ilqr] [--stub-handle]
     python tools/run_reference_example.py rl --algo ppo|sac --system cartpole|quadrotor_2D|quadrotor_3D --task stab|track [--stub-handle]
+    python tools/run_reference_example.py matrix [--stub-handle]
+
+  matrix: the reference's OWN TEST MATRIX — tests/test_examples/test_lqr.py (LQR / iLQR x stab / track x cartpole / quadrotor_2D / _3D: 12
+        cases), test_rl.py (ppo / sac / safe_explorer_ppo with the shipped checkpoints: 18), test_pid.py (4) — with the arguments those tests
+        pass (`n_steps=10`, `algo_config.max_iterations=2`, `algo_config.training=False`), one line per case.  (test_mpc / test_cbf / test_mpsc
+        need CasADi + IPOPT, test_no_controller introspects PyBullet handles, test_hpo needs optuna / MySQL: not runnable here at all.)
 
 Needs the reference checkout (build container: /root/reference; GPU box: the scratch copy tools/stage_reference.py stages) and runs it
 under tests/golden/ref_stubs.py (stand-ins for gymnasium / casadi / pybullet / munch / dict_deep / tensorboard, all absent in this image).
@@ -53,9 +59,59 @@ def deep_set(d, key, value):                        # dict_deep.deep_set for --k
     d[ks[-1]] = value
 
 
+def matrix(ref):
+    """The parametrisations of the reference's tests/test_examples/{test_lqr,test_rl,test_pid}.py, called the way those tests call them."""
+    import contextlib
+    import io
+
+    def load(rel, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    os.chdir(ref)                                               # the tests' relative override paths
+    lqr, rl, pid = (load(f'examples/{d}/{d}_experiment.py', f'{d}_experiment') for d in ('lqr', 'rl', 'pid'))
+    models = tempfile.mkdtemp()                                 # rl_experiment.py deletes <curr_path>/temp: give it a scratch curr_path
+    os.makedirs(os.path.join(models, 'models'))
+    for alg in ('ppo', 'sac', 'safe_explorer_ppo'):
+        os.symlink(os.path.join(ref, 'examples', 'rl', 'models', alg), os.path.join(models, 'models', alg))
+    cases = []
+    for SYS in ('cartpole', 'quadrotor_2D', 'quadrotor_3D'):
+        NAME = 'quadrotor' if 'quadrotor' in SYS else SYS
+        for TASK in ('stab', 'track'):
+            for ALGO in ('lqr', 'ilqr'):
+                cases.append((f'test_lqr[{ALGO}-{TASK}-{SYS}]', ['--algo', ALGO, '--task', NAME, '--overrides',
+                              f'./examples/lqr/config_overrides/{SYS}/{SYS}_{TASK}.yaml', f'./examples/lqr/config_overrides/{SYS}/{ALGO}_{SYS}_{TASK}.yaml',
+                              '--kv_overrides', 'algo_config.max_iterations=2'],
+                              lambda: lqr.run(gui=False, plot=False, n_episodes=None, n_steps=10, save_data=False)))
+            for ALGO in ('ppo', 'sac', 'safe_explorer_ppo'):
+                cases.append((f'test_rl[{ALGO}-{TASK}-{SYS}]', ['--algo', ALGO, '--task', NAME, '--overrides',
+                              f'./examples/rl/config_overrides/{SYS}/{SYS}_{TASK}.yaml', f'./examples/rl/config_overrides/{SYS}/{ALGO}_{SYS}.yaml',
+                              '--kv_overrides', 'algo_config.training=False'],
+                              lambda: rl.run(gui=False, plot=False, n_episodes=None, n_steps=10, curr_path=models)))
+    for SYS in ('quadrotor_2D', 'quadrotor_3D'):
+        for TASK in ('stab', 'track'):
+            cases.append((f'test_pid[{TASK}-{SYS}]', ['--algo', 'pid', '--task', 'quadrotor', '--overrides',
+                          f'./examples/pid/config_overrides/{SYS}/{SYS}_{TASK}.yaml'],
+                          lambda: pid.run(gui=False, n_episodes=None, n_steps=10, save_data=False)))
+    n_ok = 0
+    for tag, argv, call in cases:
+        sys.argv[1:] = argv
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                call()
+            n_ok += 1
+            print('PASSED', tag, flush=True)
+        except BaseException as e:                              # noqa: BLE001  (SystemExit from argparse included)
+            print('FAILED', tag, type(e).__name__, str(e)[:200], flush=True)
+    print(f'MATRIX {n_ok} passed of {len(cases)}')
+    return 0 if n_ok == len(cases) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('example', choices=['lqr', 'rl'])
+    ap.add_argument('example', choices=['lqr', 'rl', 'matrix'])
     ap.add_argument('--algo', default=None)
     ap.add_argument('--system', default='quadrotor_2D', choices=['cartpole', 'quadrotor_2D', 'quadrotor_3D'])
     ap.add_argument('--task', default='track', choices=['stab', 'track'])
@@ -84,12 +140,17 @@ def main():
     registry.specs['quadrotor'].entry_point = 'safe_control_gym_amd.benchmark_env:Quadrotor'
     # ----------------------------------------------------------------------------------------------------------------------
     # (controllers/__init__.py registers every controller at once, MPC's casadi / gpytorch imports included: register the one that runs)
-    pkg, cls = {'lqr': ('lqr', 'lqr:LQR'), 'ilqr': ('lqr', 'ilqr:iLQR'), 'ppo': ('ppo', 'ppo:PPO'), 'sac': ('sac', 'sac:SAC')}[a.algo]
-    register(idx=a.algo, entry_point=f'safe_control_gym.controllers.{pkg}.{cls}', config_entry_point=f'safe_control_gym.controllers.{pkg}:{a.algo}.yaml')
+    ctrls = {'lqr': ('lqr', 'lqr:LQR', 'lqr'), 'ilqr': ('lqr', 'ilqr:iLQR', 'ilqr'), 'ppo': ('ppo', 'ppo:PPO', 'ppo'), 'sac': ('sac', 'sac:SAC', 'sac'),
+             'pid': ('pid', 'pid:PID', 'pid'), 'safe_explorer_ppo': ('safe_explorer', 'safe_ppo:SafeExplorerPPO', 'safe_ppo')}
+    for idx in (ctrls if a.example == 'matrix' else [a.algo]):
+        pkg, cls, yml = ctrls[idx]
+        register(idx=idx, entry_point=f'safe_control_gym.controllers.{pkg}.{cls}', config_entry_point=f'safe_control_gym.controllers.{pkg}:{yml}.yaml')
     if a.stub_handle:
         import safe_control_gym_amd.benchmark_env as B
         from tests.test_facade_cpu import _OracleBackedVec
         B.HipVecEnv = _OracleBackedVec
+    if a.example == 'matrix':
+        return matrix(ref)
     with tempfile.TemporaryDirectory() as tmp:
         if a.example == 'lqr':
             ov = os.path.join(ref, 'examples', 'lqr', 'config_overrides', 'cartpole')
@@ -118,4 +179,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

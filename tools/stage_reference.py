@@ -8,9 +8,9 @@ it.  Only the checker side reads it — tests/test_gpu_dropin.py (the reference'
 tools/run_reference_ppo_on_hip.py, tests/golden/pybullet_probe.py — through tests/golden/ref_stubs.py::reference_root()
 ($SCG_REFERENCE_ROOT, /root/reference, oracle/_ref/reference in that order).  Nothing under safe_control_gym_amd/ or in
 bench.py's timed region imports it (tests/test_capi_cpu.py::test_product_never_imports_the_oracle).
-Copied: safe_control_gym/**/*.{py,yaml,urdf,obj,dae}, examples/rl/config_overrides/**, examples/lqr/** (script + overrides),
-examples/rl/rl_experiment.py and ONE shipped checkpoint (ppo_model_quadrotor_2D_track.pt, 0.5 MB) for tools/run_reference_example.py;
-nothing else (the policies the other tests need are the committed fixtures of tests/golden/policies.npz).
+Copied: safe_control_gym/**/*.{py,yaml,urdf,obj,dae}, examples/rl/config_overrides/**, examples/lqr/** and examples/pid/** (scripts +
+overrides), examples/rl/rl_experiment.py and the shipped checkpoints examples/rl/models/{ppo,sac,safe_explorer_ppo}/*.pt (21 MB) that
+tools/run_reference_example.py (`rl`, `matrix`) evaluates; nothing else.
 """
 import argparse
 import os
@@ -30,7 +30,7 @@ def stage(reference='/root/reference', dest=None, verbose=True):
     if os.path.isdir(dest):
         shutil.rmtree(dest)
     n = 0
-    for sub in ('safe_control_gym', os.path.join('examples', 'rl', 'config_overrides'), os.path.join('examples', 'lqr')):
+    for sub in ('safe_control_gym', os.path.join('examples', 'rl', 'config_overrides'), os.path.join('examples', 'lqr'), os.path.join('examples', 'pid')):
         for d, _, files in os.walk(os.path.join(reference, sub)):
             for f in files:
                 if not f.endswith(KEEP):
@@ -40,8 +40,12 @@ def stage(reference='/root/reference', dest=None, verbose=True):
                 os.makedirs(os.path.dirname(out), exist_ok=True)
                 shutil.copyfile(src, out)
                 n += 1
-    # the example script and the one shipped checkpoint tools/run_reference_example.py evaluates on the GPU box
-    for rel in (os.path.join('examples', 'rl', 'rl_experiment.py'), os.path.join('examples', 'rl', 'models', 'ppo', 'ppo_model_quadrotor_2D_track.pt')):
+    # the RL example script and the shipped checkpoints tools/run_reference_example.py evaluates on the GPU box
+    rels = [os.path.join('examples', 'rl', 'rl_experiment.py')]
+    for alg in ('ppo', 'sac', 'safe_explorer_ppo'):
+        d = os.path.join(reference, 'examples', 'rl', 'models', alg)
+        rels += [os.path.join('examples', 'rl', 'models', alg, f) for f in (sorted(os.listdir(d)) if os.path.isdir(d) else []) if f.endswith('.pt')]
+    for rel in rels:
         src = os.path.join(reference, rel)
         if os.path.isfile(src):
             out = os.path.join(dest, rel)
