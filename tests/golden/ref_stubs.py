@@ -30,6 +30,12 @@ import xml.etree.ElementTree as etxml
 import numpy as np
 
 import os
+import tempfile
+
+# The reference checkout is read-only input: CPython would drop __pycache__/*.pyc next to every module imported from it.  From the
+# moment anything of this repo can import the reference, bytecode goes to a scratch prefix instead (sys.pycache_prefix, PEP 3147 extension).
+if sys.pycache_prefix is None:
+    sys.pycache_prefix = os.path.join(tempfile.gettempdir(), 'scg_pycache')
 
 
 def reference_root():

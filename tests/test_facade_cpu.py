@@ -408,3 +408,5 @@ def test_the_references_own_example_test_matrix_passes_on_the_facade():
     lines = res.stdout.splitlines()
     assert not [ln for ln in lines if ln.startswith('FAILED')] and res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
     assert 'MATRIX 34 passed of 34' in lines[-1] and sum(ln.startswith('PASSED') for ln in lines) == 34
+    # the checkout is read-only input: importing ~60 of its modules must not leave bytecode caches in it (ref_stubs sets sys.pycache_prefix)
+    assert not [d for d, sub, _ in os.walk(ref_stubs.reference_root()) if '__pycache__' in sub]
