@@ -80,6 +80,7 @@ class ConstraintView:
 
 class BenchmarkEnv:
     NAME = 'base'
+    PYB_CLIENT = -1         # there is no Bullet client behind this facade (-1 = PyBullet's "not connected"); CARTPOLE_ID / DRONE_ID likewise
 
     def __init__(self, seed=None, device=None, dtype=torch.float64, specialize='auto', output_dir=None, gui=False,
                  verbose=False, **task_config):
@@ -172,7 +173,7 @@ class BenchmarkEnv:
         info = dict(self._venv._reset_info({'c_values': self._host_c(), 'done': [False]}, 0, with_constraints=True))
         info['symbolic_model'] = self.symbolic
         if self.constraints is not None:
-            info['symbolic_constraints'] = [m['form'] for m in self._venv.spec.con_meta]
+            info['symbolic_constraints'] = [m.get_symbolic_model() for m in self._venv.spec.con_meta]    # constraints.py:458-468
         return obs, info
 
     def _host_c(self):
@@ -226,6 +227,7 @@ class BenchmarkEnv:
 
 class CartPole(BenchmarkEnv):
     NAME = 'cartpole'
+    CARTPOLE_ID = -1
 
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
@@ -243,6 +245,7 @@ class CartPole(BenchmarkEnv):
 
 class Quadrotor(BenchmarkEnv):
     NAME = 'quadrotor'
+    DRONE_ID = -1
 
     def __init__(self, **kwargs):
         super().__init__(**kwargs)

@@ -89,6 +89,30 @@ def _diag_weights(w, dim, what):
     raise Exception(f'Wrong dimension for cost weights ({what}).')
 
 
+class ConstraintInfo(dict):
+    """One entry of the `constraints:` list after compilation.  A dict (form / var / first_row / n_rows / strict, what the host side of
+    this package reads) that also answers the attribute reads of the reference's `Constraint` objects (constraints.py:21-87, 186-231,
+    234-283): `constrained_variable`, `dim`, `num_constraints`, `strict`, `decimals`, `constraint_filter`, `A` / `b` or `P` / `b`, and the
+    symbolic form `sym_func` / `get_symbolic_model()` — upstream's own lambdas, which evaluate on NumPy vectors as well as on CasADi
+    symbols (a SymmetricStateConstraint keeps the 2n-row linear form of the BoundedConstraint it derives from, :436-444, while its VALUES
+    are the n rows |x| - bound)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    @property
+    def sym_func(self):
+        if 'P' in self:
+            return lambda x: x.T @ self.constraint_filter.T @ self.P @ self.constraint_filter @ x - self.b
+        return lambda x: self.A @ self.constraint_filter @ x - self.b
+
+    def get_symbolic_model(self):
+        return self.sym_func
+
+
 @dataclass
 class EnvSpec:
     """Everything derived from the YAML config for one environment type (shared by all N copies)."""
@@ -428,6 +452,7 @@ class EnvSpec:
                 # A = [-I; I], b = [-lb; ub], both stored as float32 (constraints.py:267-268,320-321)
                 b32 = np.hstack((-lb, ub)).astype(np.float32)
                 n = len(idx)
+                sym = dict(A=np.vstack((-np.eye(n), np.eye(n))).astype(np.float32), b=b32, lower_bounds=lb, upper_bounds=ub)
                 for j in range(n):
                     self.con_rows.append(dict(kind=L.ROW_SPARSE, var=var_id, index=idx[j], strict=strict, sign=-1.0,
                                               b=float(b32[j]), round_scale=rs))
@@ -439,6 +464,7 @@ class EnvSpec:
                 b = np.asarray(cfg.pop('b'), dtype=np.float32).reshape(-1)
                 assert b.shape[0] == A.shape[0], '[ERROR] Dimension 0 of b does not match A!'
                 full = A @ np.eye(full_dim)[idx]               # A @ constraint_filter, float64
+                sym = dict(A=A, b=b)
                 for r in range(A.shape[0]):
                     self.con_rows.append(dict(kind=L.ROW_DENSE, var=var_id, index=0, strict=strict, sign=1.0,
                                               b=float(b[r]), round_scale=rs, coef=full[r].tolist()))
@@ -450,6 +476,7 @@ class EnvSpec:
                     raise ValueError(f'at most {L.MAX_QUAD_CON} quadratic constraints are supported')
                 F = np.eye(full_dim)[idx]
                 self.quad_P.append(F.T @ P @ F)
+                sym = dict(P=P, b=b)
                 self.con_rows.append(dict(kind=L.ROW_QUADRATIC, var=var_id, index=len(self.quad_P) - 1, strict=strict,
                                           sign=1.0, b=float(b), round_scale=rs))
             else:   # abs_bound (SymmetricStateConstraint, cartpole only)
@@ -460,12 +487,16 @@ class EnvSpec:
                     raise TypeError("bad operand type for unary -: 'list'")   # same failure as upstream (:433)
                 bound = np.array(bound, ndmin=1, dtype=float)
                 assert bound.shape[0] == len(idx)
+                n = len(idx)
+                sym = dict(A=np.vstack((-np.eye(n), np.eye(n))).astype(np.float32), b=np.hstack((bound, bound)).astype(np.float32), bound=bound)
                 for j in range(len(idx)):
                     self.con_rows.append(dict(kind=L.ROW_ABS, var=var_id, index=idx[j], strict=strict, sign=1.0,
                                               b=float(bound[j]), round_scale=rs))
             if cfg:
                 raise TypeError(f'unexpected constraint argument(s) {sorted(cfg)} for {form}')
-            self.con_meta.append(dict(form=form, var=var, first_row=first, n_rows=len(self.con_rows) - first, strict=strict))
+            self.con_meta.append(ConstraintInfo(form=form, var=var, first_row=first, n_rows=len(self.con_rows) - first, strict=strict,
+                                                constrained_variable=var, dim=len(idx), num_constraints=len(self.con_rows) - first,
+                                                decimals=decimals, constraint_filter=np.eye(full_dim)[idx], **sym))
         if len(self.con_rows) > L.MAX_CON_ROWS:
             raise ValueError(f'more than {L.MAX_CON_ROWS} scalar constraint rows')
         self.num_constraints = len(self.con_rows)

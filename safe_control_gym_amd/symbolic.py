@@ -5,7 +5,7 @@ The reference builds its prior model symbolically with CasADi (cartpole.py:390-4
 available in this image, and the model is host-side, single-env bookkeeping for controllers such as LQR — not part of the
 data-parallel hot path.  This class evaluates the same continuous-time equations with NumPy and exposes the members
 controllers read: ``nx nu ny dt X_EQ U_EQ fc_func df_func fd_func loss`` (Jacobians by central differences of the
-analytic right-hand side).
+analytic right-hand side), plus printable ``x_sym u_sym y_sym x_dot cost_func``.
 """
 import numpy as np
 
@@ -30,6 +30,40 @@ class _Dense:
         return self._a.shape
 
 
+class _Names:
+    """Display-only stand-in for a CasADi symbol vector: `str()` reads like CasADi's (`vertcat(x, x_dot, ...)`), `.shape` is (n, 1).
+    Not an expression graph — controllers that BUILD on the symbols (MPC, CBF, MPSC: out of scope) need CasADi."""
+
+    def __init__(self, names):
+        self.names = tuple(names)
+        self.shape = (len(self.names), 1)
+
+    def __str__(self):
+        return 'vertcat(' + ', '.join(self.names) + ')'
+
+    __repr__ = __str__
+
+    def __len__(self):
+        return len(self.names)
+
+    def __iter__(self):
+        return iter(self.names)
+
+
+# x_dot of `AnalyticModel.f`, entry by entry, in the notation of the reference's expressions (cartpole.py:409-414, quadrotor.py:490, 506-509, 540-562)
+_X_DOT = {
+    ('cartpole', 4): ('x_dot', 'tmp - m*l*theta_dd*cos(theta)/(m+M)   [tmp = (F + m*l*theta_dot^2*sin(theta))/(m+M)]', 'theta_dot',
+                      'theta_dd = (g*sin(theta) - cos(theta)*tmp) / (l*(4/3 - m*cos(theta)^2/(m+M)))'),
+    ('quadrotor', 2): ('z_dot', 'T/m - g'),
+    ('quadrotor', 6): ('x_dot', 'sin(theta)*(T1+T2)/m', 'z_dot', 'cos(theta)*(T1+T2)/m - g', 'theta_dot', 'l*(T2-T1)/Iyy/sqrt(2)'),
+    ('quadrotor', 12): ('x_dot', '(Rob @ [0,0,f1+f2+f3+f4])[0]/m', 'y_dot', '(Rob @ [0,0,f1+f2+f3+f4])[1]/m', 'z_dot',
+                        '(Rob @ [0,0,f1+f2+f3+f4])[2]/m - g', '(W(phi,theta) @ [p,q,r])[0]', '(W(phi,theta) @ [p,q,r])[1]', '(W(phi,theta) @ [p,q,r])[2]',
+                        '(J^-1 (Mb - [p,q,r] x J [p,q,r]))[0]   [Mb = (l/sqrt2*(f1+f2-f3-f4), l/sqrt2*(-f1+f2+f3-f4), gamma*(-f1+f2-f3+f4))]',
+                        '(J^-1 (Mb - [p,q,r] x J [p,q,r]))[1]', '(J^-1 (Mb - [p,q,r] x J [p,q,r]))[2]'),
+}
+_U_NAMES = {('cartpole', 1): ('F',), ('quadrotor', 1): ('T',), ('quadrotor', 2): ('T1', 'T2'), ('quadrotor', 4): ('f1', 'f2', 'f3', 'f4')}
+
+
 class AnalyticModel:
     def __init__(self, name, spec, prior_prop=None):
         self.name, self.spec = name, spec
@@ -38,6 +72,11 @@ class AnalyticModel:
         self.nx, self.nu = spec.nx, spec.nu
         self.ny = self.nx
         self.Q, self.R = spec.Q, spec.R
+        # what a caller may PRINT of the symbolic model (examples/no_controller/verbose_api.py:52-58)
+        self.x_sym = self.y_sym = _Names(spec.state_labels)
+        self.u_sym = _Names(_U_NAMES[(name, self.nu)])
+        self.x_dot = _Names(_X_DOT[(name, self.nx)])
+        self.cost_func = '0.5*(X-Xr).T @ Q @ (X-Xr) + 0.5*(U-Ur).T @ R @ (U-Ur)'
         g = spec.GRAVITY_ACC
         if name == 'cartpole':
             self.params = dict(length=prior_prop.get('pole_length', spec.EFFECTIVE_POLE_LENGTH),

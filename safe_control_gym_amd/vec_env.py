@@ -446,7 +446,7 @@ class HipVecEnv(VecEnv):
     def physical_parameters(self, i):
         p = self.get_params(i, 1)[0]
         if self.spec.name == 'cartpole':
-            return {'pole_effective_length': p[0], 'cart_mass': p[1], 'pole_mass': p[2]}
+            return {'pole_effective_length': p[0], 'pole_mass': p[2], 'cart_mass': p[1]}    # cartpole.py:706-710
         return {'quadrotor_mass': p[0], 'quadrotor_inertia': [p[1], p[2], p[3]]}
 
     # ------------------------------------------------------------------ host accessors

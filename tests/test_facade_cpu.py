@@ -141,7 +141,10 @@ class _OracleBackedVec:
         return HipVecEnv._reset_info(self, host, i, with_constraints)
 
     def physical_parameters(self, i):
-        return {}
+        o = self.o
+        if self.spec.name == 'cartpole':
+            return {'pole_effective_length': float(o.pole_length_env[i]), 'pole_mass': float(o.pole_mass_env[i]), 'cart_mass': float(o.cart_mass_env[i])}
+        return {'quadrotor_mass': float(o.mass_env[i]), 'quadrotor_inertia': [float(v) for v in o.J_env[i]]}
 
     def set_adversary_control(self, a):
         from safe_control_gym_amd.vec_env import HipVecEnv
@@ -393,8 +396,8 @@ def test_the_references_rl_example_evaluates_the_shipped_models(algo, system, ta
 def test_the_references_own_example_test_matrix_passes_on_the_facade():
     """The reference's tests/test_examples/{test_lqr,test_rl,test_pid}.py parametrisations (its end-to-end test strategy)
     — LQR / iLQR (12), PPO / SAC / Safe-Explorer PPO evaluating the shipped checkpoints (18), PID (4), each `n_steps=10` through the
-    example's own run() — with the registry's env ids bound to this package's facade (tools/run_reference_example.py matrix).  The other
-    example tests need CasADi + IPOPT (mpc, cbf, mpsc), PyBullet handles (no_controller) or optuna / MySQL (hpo)."""
+    example's own run(), and test_no_controller.py's verbose_api.py on both systems (2) — with the registry's env ids bound to this package's facade (tools/run_reference_example.py matrix).  The other
+    example tests need CasADi + IPOPT (mpc, cbf, mpsc) or optuna / MySQL (hpo)."""
     import os
     import subprocess
     import sys
@@ -407,6 +410,55 @@ def test_the_references_own_example_test_matrix_passes_on_the_facade():
                          capture_output=True, text=True, timeout=600)
     lines = res.stdout.splitlines()
     assert not [ln for ln in lines if ln.startswith('FAILED')] and res.returncode == 0, (res.stdout[-3000:], res.stderr[-2000:])
-    assert 'MATRIX 34 passed of 34' in lines[-1] and sum(ln.startswith('PASSED') for ln in lines) == 34
+    assert 'MATRIX 36 passed of 36' in lines[-1] and sum(ln.startswith('PASSED') for ln in lines) == 36
     # the checkout is read-only input: importing ~60 of its modules must not leave bytecode caches in it (ref_stubs sets sys.pycache_prefix)
     assert not [d for d, sub, _ in os.walk(ref_stubs.reference_root()) if '__pycache__' in sub]
+
+
+@pytest.mark.parametrize('system', ['cartpole', 'quadrotor_2D', 'quadrotor_3D'])
+def test_symbolic_constraint_forms_match_the_references_constraint_objects(system):
+    """`info['symbolic_constraints']` / `env.constraints.constraints[i]`: upstream hands out its Constraint objects' `sym_func` lambdas
+    (constraints.py:222, 274, 458-468).  On random task configs (tests/config_fuzz.py) plus a quadratic and a linear constraint, the facade's
+    ConstraintInfo entries evaluate to the same numbers as the REFERENCE's own objects on random vectors, and carry the same `dim`,
+    `num_constraints`, `strict`, `constrained_variable`, `A` / `b` / `P`."""
+    import inspect
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    from tests.config_fuzz import fuzz_config
+    from tests.golden import make_golden as MG
+    from safe_control_gym_amd.env_config import EnvSpec
+    rng = np.random.default_rng(3)
+    n_checked = 0
+    for seed in range(8):
+        env_id, cfg = fuzz_config(system, seed)
+        cfg = dict(cfg)
+        cons = list(cfg.get('constraints') or [])
+        nx = {'cartpole': 4, 'quadrotor_2D': 6, 'quadrotor_3D': 12}[system]
+        if seed % 2 == 0:
+            P = rng.uniform(0.1, 1.0, (2, 2)); P = (P @ P.T).tolist()
+            cons += [{'constraint_form': 'quadratic_constraint', 'constrained_variable': 'state', 'P': P, 'b': 3.0, 'active_dims': [0, 2]},
+                     {'constraint_form': 'linear_constraint', 'constrained_variable': 'state', 'A': rng.normal(0, 1, (3, nx)).tolist(), 'b': [1.0, 2.0, 3.0]}]
+        if not cons:
+            continue
+        cfg['constraints'] = cons
+        ref = MG.ENV_CLS[env_id](**dict(cfg, output_dir='/tmp'))
+        spec = EnvSpec(env_id, dict(cfg))
+        assert len(ref.constraints.constraints) == len(spec.con_meta)
+        for rc, mine in zip(ref.constraints.constraints, spec.con_meta):
+            assert (rc.dim, rc.strict, str(rc.constrained_variable.value), rc.decimals) == (mine.dim, mine.strict, mine.constrained_variable, mine.decimals)
+            if type(rc).__name__ != 'SymmetricStateConstraint':         # (that class overrides num_constraints to n while its sym_func keeps 2n rows)
+                assert rc.num_constraints == mine.num_constraints
+            np.testing.assert_array_equal(rc.constraint_filter, mine.constraint_filter)
+            for k in ('A', 'b', 'P'):
+                assert hasattr(rc, k) == (k in mine)
+                if k in mine:
+                    np.testing.assert_array_equal(np.asarray(getattr(rc, k)), np.asarray(mine[k]))
+            for _ in range(3):
+                x = rng.normal(0, 1, mine.constraint_filter.shape[1])
+                np.testing.assert_array_equal(np.asarray(rc.sym_func(x)), np.asarray(mine.get_symbolic_model()(x)))
+            assert 'lambda x' in inspect.getsource(mine.sym_func)        # examples/no_controller/verbose_api.py:59-61 prints the source
+            n_checked += 1
+        ref.close()
+    assert n_checked >= 4

@@ -16,8 +16,9 @@ The ONE change is the one INTEGRATION.md describes: the registry's env ids point
 
   matrix: the reference's OWN TEST MATRIX — tests/test_examples/test_lqr.py (LQR / iLQR x stab / track x cartpole / quadrotor_2D / _3D: 12
         cases), test_rl.py (ppo / sac / safe_explorer_ppo with the shipped checkpoints: 18), test_pid.py (4) — with the arguments those tests
-        pass (`n_steps=10`, `algo_config.max_iterations=2`, `algo_config.training=False`), one line per case.  (test_mpc / test_cbf / test_mpsc
-        need CasADi + IPOPT, test_no_controller introspects PyBullet handles, test_hpo needs optuna / MySQL: not runnable here at all.)
+        pass (`n_steps=10`, `algo_config.max_iterations=2`, `algo_config.training=False`), and test_no_controller.py (verbose_api.py on both
+        systems: 2), one line per case.  (test_mpc / test_cbf / test_mpsc need CasADi + IPOPT, test_hpo needs optuna / MySQL: not runnable
+        here at all.)
 
 Needs the reference checkout (build container: /root/reference; GPU box: the scratch copy tools/stage_reference.py stages) and runs it
 under tests/golden/ref_stubs.py (stand-ins for gymnasium / casadi / pybullet / munch / dict_deep / tensorboard, all absent in this image).
@@ -94,6 +95,12 @@ def matrix(ref):
             cases.append((f'test_pid[{TASK}-{SYS}]', ['--algo', 'pid', '--task', 'quadrotor', '--overrides',
                           f'./examples/pid/config_overrides/{SYS}/{SYS}_{TASK}.yaml'],
                           lambda: pid.run(gui=False, n_episodes=None, n_steps=10, save_data=False)))
+    # tests/test_examples/test_no_controller.py: examples/no_controller/verbose_api.py prints `pybullet.getDynamicsInfo(env.DRONE_ID, env.PYB_CLIENT)`
+    # first — there is no Bullet body behind the facade (ids -1), so the Bullet stand-in of this harness answers that one call with a note
+    vb = load('examples/no_controller/verbose_api.py', 'verbose_api')
+    sys.modules['pybullet'].getDynamicsInfo = lambda **k: ('no Bullet body behind the HIP facade',)
+    for t in ('cartpole', 'quadrotor'):
+        cases.append((f'test_verbose_api_{t}', ['--task', t, '--overrides', './examples/no_controller/verbose_api.yaml'], vb.run))
     n_ok = 0
     for tag, argv, call in cases:
         sys.argv[1:] = argv

@@ -8,7 +8,7 @@ it.  Only the checker side reads it — tests/test_gpu_dropin.py (the reference'
 tools/run_reference_ppo_on_hip.py, tests/golden/pybullet_probe.py — through tests/golden/ref_stubs.py::reference_root()
 ($SCG_REFERENCE_ROOT, /root/reference, oracle/_ref/reference in that order).  Nothing under safe_control_gym_amd/ or in
 bench.py's timed region imports it (tests/test_capi_cpu.py::test_product_never_imports_the_oracle).
-Copied: safe_control_gym/**/*.{py,yaml,urdf,obj,dae}, examples/rl/config_overrides/**, examples/lqr/** and examples/pid/** (scripts +
+Copied: safe_control_gym/**/*.{py,yaml,urdf,obj,dae}, examples/rl/config_overrides/**, examples/lqr/**, examples/pid/** and examples/no_controller/** (scripts +
 overrides), examples/rl/rl_experiment.py and the shipped checkpoints examples/rl/models/{ppo,sac,safe_explorer_ppo}/*.pt (21 MB) that
 tools/run_reference_example.py (`rl`, `matrix`) evaluates; nothing else.
 """
@@ -30,7 +30,8 @@ def stage(reference='/root/reference', dest=None, verbose=True):
     if os.path.isdir(dest):
         shutil.rmtree(dest)
     n = 0
-    for sub in ('safe_control_gym', os.path.join('examples', 'rl', 'config_overrides'), os.path.join('examples', 'lqr'), os.path.join('examples', 'pid')):
+    for sub in ('safe_control_gym', os.path.join('examples', 'rl', 'config_overrides'), os.path.join('examples', 'lqr'), os.path.join('examples', 'pid'),
+                os.path.join('examples', 'no_controller')):
         for d, _, files in os.walk(os.path.join(reference, sub)):
             for f in files:
                 if not f.endswith(KEEP):
