@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from safe_control_gym_amd.symbolic import AnalyticModel
-from safe_control_gym_amd.vec_env import HipVecEnv
+from safe_control_gym_amd.vec_env import HipVecEnv, checked_seed
 
 
 class Cost(str, Enum):
@@ -88,7 +88,7 @@ class BenchmarkEnv:
             raise NotImplementedError('no GUI / rendering in the HIP simulator')
         self.idx = 0
         self.output_dir, self.GUI, self.VERBOSE = output_dir, gui, verbose
-        self._seed_value = 0 if seed is None else int(seed)
+        self._seed_value = 0 if seed is None else checked_seed(seed)
         self._venv = HipVecEnv(self.NAME, 1, seed=self._seed_value, device=device, dtype=dtype, return_numpy=False,
                                auto_reset=False, specialize=specialize, **task_config)
         spec = self._venv.spec
@@ -151,7 +151,7 @@ class BenchmarkEnv:
 
     # ---- seeding (benchmark_env.py:193-214)
     def seed(self, seed=None):
-        self._seed_value = 0 if seed is None else int(seed)
+        self._seed_value = 0 if seed is None else checked_seed(seed)
         self.np_random = np.random.default_rng(seed)
         self.action_space.seed(seed)
         self._venv.seed(self._seed_value)

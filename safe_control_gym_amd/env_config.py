@@ -252,6 +252,8 @@ class EnvSpec:
     # ------------------------------------------------------------------ quadrotor
     def _init_quadrotor(self):
         kw = self.kw
+        if _enum_str(kw['physics']) not in ('pyb', 'dyn', 'pyb_gnd', 'pyb_drag', 'pyb_dw', 'pyb_gnd_drag_dw'):
+            raise ValueError(f"'{kw['physics']}' is not a valid Physics")                              # base_aviary.py:32-40, quadrotor.py:…Physics(physics)
         if _enum_str(kw['physics']) != 'pyb':
             # base_aviary.py:32-40: only Physics.PYB is used by the shipped configs (DYN is broken upstream).
             raise NotImplementedError("only physics='pyb' is implemented by the HIP kernels")
@@ -418,18 +420,43 @@ class EnvSpec:
             cfg = {k: v for k, v in spec.items() if k != 'constraint_form'}
             var = _enum_str(cfg.pop('constrained_variable'))
             if var not in ('state', 'input'):
-                raise NotImplementedError('only STATE and INPUT constraints are supported '
-                                          '(INPUT_AND_STATE is not evaluable upstream either)')
+                if form != 'default_constraint' and var != 'input_and_state':
+                    raise ValueError(f"'{var}' is not a valid ConstrainedVariableType")               # constraints.py:55
+                raise NotImplementedError('[ERROR] DefaultConstraint can only be of type STATE or INPUT' if form == 'default_constraint' else
+                                          'only STATE and INPUT constraints are supported (INPUT_AND_STATE is not evaluable upstream either)')
             var_id = 0 if var == 'state' else 1
             full_dim = self.nx if var_id == 0 else self.nu
             strict = bool(cfg.pop('strict', False))
             decimals = cfg.pop('decimals', 8)
-            cfg.pop('tolerance', None)
+            tolerance = cfg.pop('tolerance', None)
             active = cfg.pop('active_dims', None)
+            # the checks each class makes BEFORE Constraint.__init__ looks at active_dims (same exception types, same order)
+            if form == 'default_constraint' and active is not None:
+                raise TypeError("DefaultConstraint.__init__() got an unexpected keyword argument 'active_dims'")
+            if form == 'bounded_constraint':
+                missing = [k for k in ('lower_bounds', 'upper_bounds') if k not in cfg]
+                if missing:
+                    raise TypeError(f'BoundedConstraint.__init__() missing {len(missing)} required positional argument' + ('s' if len(missing) > 1 else '') +
+                                    ': ' + ' and '.join(f"'{k}'" for k in missing))
+                n_lb, n_ub = np.array(cfg['lower_bounds'], ndmin=1).shape[0], np.array(cfg['upper_bounds'], ndmin=1).shape[0]
+                if isinstance(active, list):                                                          # constraints.py:314-319
+                    assert n_lb == len(active), '[Error] active_dims and lower_bounds must have the same dimension.'
+                if isinstance(active, int):
+                    assert n_lb == 1, '[Error] active_dims and lower_bounds must have the same dimension.'
+                    assert n_ub == 1, '[Error] active_dims and upper_bounds must have the same dimension.'
+            if form == 'abs_bound':
+                assert cfg.get('bound') is not None
+                if isinstance(cfg['bound'], (list, tuple)):
+                    raise TypeError("bad operand type for unary -: 'list'")   # same failure as upstream (:433)
             if isinstance(active, int):
                 active = [active]
+            if active is not None:                                                                    # constraints.py:68-78
+                assert isinstance(active, (list, np.ndarray)), '[ERROR] active_dims is not a list/array.'
+                assert len(active) <= full_dim, '[ERROR] more active_dim than constrainable self.dim'
+                assert all(isinstance(n, int) for n in active), '[ERROR] non-integer active_dim.'
+                assert all(n < full_dim for n in active), '[ERROR] active_dim not stricly smaller than self.dim.'
+                assert len(active) == len(set(active)), '[ERROR] duplicates in active_dim'
             idx = list(range(full_dim)) if active is None else list(active)
-            assert all(isinstance(n, int) and n < full_dim for n in idx), '[ERROR] active_dim out of range.'
             rs = 10.0 ** decimals
             first = len(self.con_rows)
             if form in ('default_constraint', 'bounded_constraint'):
@@ -443,12 +470,13 @@ class EnvSpec:
                     lb, ub = cfg.pop('lower_bounds', None), cfg.pop('upper_bounds', None)
                     lb = lo_d if lb is None else np.array(lb, ndmin=1)
                     ub = hi_d if ub is None else np.array(ub, ndmin=1)
-                    assert len(lb) == full_dim and len(ub) == full_dim, '[ERROR]: bound must have length equal to space dimension.'
+                    assert len(ub) == full_dim, '[ERROR]: Upper bound must have length equal to space dimension.'      # constraints.py:380-387
+                    assert len(lb) == full_dim, '[ERROR]: Lower bound must have length equal to space dimension.'
                     lb, ub = lb.astype(np.float64), ub.astype(np.float64)
                 else:
                     lb = np.array(cfg.pop('lower_bounds'), ndmin=1, dtype=np.float64)
                     ub = np.array(cfg.pop('upper_bounds'), ndmin=1, dtype=np.float64)
-                    assert lb.shape[0] == len(idx) and ub.shape[0] == len(idx)
+                    assert lb.shape[0] == len(idx) and ub.shape[0] == len(idx), '[ERROR] Dimension 0 of b does not match A!'   # constraints.py:272
                 # A = [-I; I], b = [-lb; ub], both stored as float32 (constraints.py:267-268,320-321)
                 b32 = np.hstack((-lb, ub)).astype(np.float32)
                 n = len(idx)
@@ -469,7 +497,9 @@ class EnvSpec:
                     self.con_rows.append(dict(kind=L.ROW_DENSE, var=var_id, index=0, strict=strict, sign=1.0,
                                               b=float(b[r]), round_scale=rs, coef=full[r].tolist()))
             elif form == 'quadratic_constraint':
-                P = np.array(cfg.pop('P'), ndmin=1, dtype=float).reshape(len(idx), len(idx))
+                P = np.array(cfg.pop('P'), ndmin=1, dtype=float)
+                assert P.shape == (len(idx), len(idx)), ('[ERROR] P has the wrong dimension! It should match the dimension of'
+                                                         'the constrained_variable or the same length as active_dims.')
                 b = cfg.pop('b')
                 assert isinstance(b, float), '[ERROR] b is not a scalar!'
                 if len(self.quad_P) >= L.MAX_QUAD_CON:
@@ -480,20 +510,22 @@ class EnvSpec:
                 self.con_rows.append(dict(kind=L.ROW_QUADRATIC, var=var_id, index=len(self.quad_P) - 1, strict=strict,
                                           sign=1.0, b=float(b), round_scale=rs))
             else:   # abs_bound (SymmetricStateConstraint, cartpole only)
-                assert self.COST == 'rl_reward', '[ERROR] SymmetricStateConstraint is meant for RL environments'
                 bound = cfg.pop('bound')
-                assert bound is not None
-                if isinstance(bound, (list, tuple)):
-                    raise TypeError("bad operand type for unary -: 'list'")   # same failure as upstream (:433)
                 bound = np.array(bound, ndmin=1, dtype=float)
                 assert bound.shape[0] == len(idx)
                 n = len(idx)
                 sym = dict(A=np.vstack((-np.eye(n), np.eye(n))).astype(np.float32), b=np.hstack((bound, bound)).astype(np.float32), bound=bound)
+                if tolerance is not None and len(np.array(tolerance, ndmin=1)) != n:                  # constraints.py:449-455
+                    raise ValueError('[ERROR] the tolerance dimension does not match the number of constraints.')
+                tolerance = None
+                assert self.COST == 'rl_reward', '[ERROR] SymmetricStateConstraint is meant for RL environments'   # after super().__init__ (:446-447)
                 for j in range(len(idx)):
                     self.con_rows.append(dict(kind=L.ROW_ABS, var=var_id, index=idx[j], strict=strict, sign=1.0,
                                               b=float(bound[j]), round_scale=rs))
             if cfg:
                 raise TypeError(f'unexpected constraint argument(s) {sorted(cfg)} for {form}')
+            if tolerance is not None and len(np.array(tolerance, ndmin=1)) != len(self.con_rows) - first:      # check_tolerance_shape, constraints.py:175-178
+                raise ValueError('[ERROR] the tolerance dimension does not match the number of constraints.')
             self.con_meta.append(ConstraintInfo(form=form, var=var, first_row=first, n_rows=len(self.con_rows) - first, strict=strict,
                                                 constrained_variable=var, dim=len(idx), num_constraints=len(self.con_rows) - first,
                                                 decimals=decimals, constraint_filter=np.eye(full_dim)[idx], **sym))
@@ -547,19 +579,23 @@ class EnvSpec:
                     if dim != self.nx and any(s.get('disturbance_func') in ('uniform', 'white_noise', 'periodic') or
                                               s.get('mask') is not None for s in specs):
                         # upstream adds an obs_dim-sized noise vector to the state-sized observation
-                        # (quadrotor.py:717,805-807) which raises when a goal horizon is configured.
+                        # (quadrotor.py:717,805-807) which raises when a goal horizon is configured — after its constructors have
+                        # checked the spec against dim = obs_dim (their AssertionErrors come first)
+                        for s in specs:
+                            assert 'disturbance_func' in s.keys(), '[ERROR]: Every distrubance must specify a disturbance_func.'
+                            self._compile_disturbance(s, self.obs_dim, max_step)
                         raise ValueError('observation disturbances with per-dimension noise need obs_dim == state_dim')
                     dim = self.nx
                 if len(specs) > L.MAX_DISTURB:
                     raise ValueError(f'at most {L.MAX_DISTURB} disturbances per channel')
                 for s in specs:
-                    assert 'disturbance_func' in s, '[ERROR]: Every distrubance must specify a disturbance_func.'
+                    assert 'disturbance_func' in s.keys(), '[ERROR]: Every distrubance must specify a disturbance_func.'
                     self.dist[chan[mode]].append(self._compile_disturbance(s, dim, max_step))
         adv = self.kw['adversary_disturbance']
         self.adversary_disturbance = adv
         self.adversary_channel = -1
         if adv is not None:
-            assert adv in dims, '[ERROR] adversary disturbance mode not available.'
+            assert adv in dims, '[ERROR] in Cartpole._setup_disturbances()'      # (benchmark_env.py:290 — the base class says Cartpole for both robots)
             if adv == 'observation':
                 raise NotImplementedError('adversary on the observation channel is never applied upstream either')
             self.adversary_channel = chan[adv]
@@ -639,6 +675,9 @@ class EnvSpec:
                 hi = list(high)
             else:
                 raise ValueError('[ERROR] UniformNoise.__init__(): high must be specified as a float or list.')
+            # np_random.uniform(low, high, size=dim) (disturbances.py:188): the bounds broadcast against (dim,) — a one-element list is
+            # fine, any other length mismatch is numpy's ValueError (upstream: at the first step; here: at construction)
+            lo, hi = np.broadcast_to(np.asarray(lo, dtype=float), (dim,)), np.broadcast_to(np.asarray(hi, dtype=float), (dim,))
             d.update(kind=L.DIST_UNIFORM, a=[float(v) for v in lo], b=[float(v) for v in hi])
         elif kind == 'white_noise':
             std = cfg.pop('std', 1.0)
@@ -669,6 +708,16 @@ class EnvSpec:
         info = dict(info)
         distrib = info.pop('distrib')
         args = list(info.pop('args', []))
+        # upstream: getattr(np_random, distrib)(*args, **kwargs) at the first reset (benchmark_env.py:232-262) — same exception types, at construction
+        if not hasattr(np.random.Generator, distrib):
+            raise AttributeError(f"'numpy.random._generator.Generator' object has no attribute '{distrib}'")
+        allowed = {'uniform': ('low', 'high'), 'normal': ('loc', 'scale'), 'choice': ('a',)}.get(distrib, ())
+        numpy_only = {'uniform': ('size',), 'normal': ('size',), 'choice': ('size', 'replace', 'p', 'axis', 'shuffle')}.get(distrib, ())
+        for k in info:
+            if k in numpy_only:
+                raise NotImplementedError(f"{distrib}(..., {k}=) is not available in the HIP kernels")
+            if allowed and k not in allowed:
+                raise TypeError(f"{distrib}() got an unexpected keyword argument '{k}'")
         if distrib == 'uniform':
             r.kind = L.RAND_UNIFORM
             r.p0 = float(args[0] if len(args) > 0 else info.get('low', 0.0))

@@ -85,6 +85,16 @@ class VecEnv(ABC):
         return indices
 
 
+def checked_seed(seed):
+    """BenchmarkEnv.seed -> gymnasium's seeding.np_random (benchmark_env.py:193-214): a seed is a non-negative integer.  gymnasium ^0.28 raises
+    its own `error.Error` there; that class does not exist here (no gymnasium), so: ValueError, instead of silently truncating / wrapping."""
+    if isinstance(seed, bool) or not isinstance(seed, (int, np.integer)):
+        raise ValueError(f'Seed must be a python integer, actual type: {type(seed)}')
+    if seed < 0:
+        raise ValueError(f'Seed must be greater or equal to zero, actual value: {seed}')
+    return int(seed)
+
+
 class StepTensors:
     """Device-resident outputs of one vectorised step (all torch tensors on the env's device)."""
     __slots__ = ('obs', 'reward', 'done', 'flags', 'c_values', 'mse', 'terminal_obs', 'state', 'noisy_action', 'fin_stats')
@@ -202,7 +212,7 @@ class HipVecEnv(VecEnv):
         self._cdtype = L.F64 if dtype == torch.float64 else L.F32
         if dtype not in (torch.float32, torch.float64):
             raise ValueError('dtype must be torch.float32 or torch.float64')
-        self.seed_value = int(seed)
+        self.seed_value = checked_seed(seed)
         self.env_id_offset = int(env_id_offset)
         self.return_numpy = return_numpy
         VecEnv.__init__(self, int(num_envs), spec.observation_space, spec.action_space)
@@ -508,7 +518,7 @@ class HipVecEnv(VecEnv):
 
     def seed(self, seed):
         """New Philox key for every env of the batch (BenchmarkEnv.seed, benchmark_env.py:193-214)."""
-        self.seed_value = int(seed)
+        self.seed_value = checked_seed(seed)
         self._chk(self._lib.scg_set_seed(self._h, C.c_uint64(self.seed_value & 0xFFFFFFFFFFFFFFFF)))
         # the key is a kernel argument: HIP graphs captured before this call replay the OLD key — owners of such graphs
         # (ppo.evaluate's cache here, PPO's rollout graph via seed_epoch) re-capture

@@ -265,7 +265,7 @@ def _make_pybullet():
         return clients[physicsClientId]
 
     def connect(mode, **k):
-        cid = len(clients)
+        cid = min(set(range(len(clients) + 1)) - set(clients))    # Bullet hands out the lowest free id (len() would reuse a LIVE id after a disconnect)
         clients[cid] = _Client()
         return cid
 
