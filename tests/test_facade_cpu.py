@@ -462,3 +462,24 @@ def test_symbolic_constraint_forms_match_the_references_constraint_objects(syste
             n_checked += 1
         ref.close()
     assert n_checked >= 4
+
+
+@pytest.mark.parametrize('algo,system,task', [('ppo', 'cartpole', 'stab'), ('sac', 'quadrotor_2D', 'track'), ('safe_explorer_ppo', 'quadrotor_3D', 'stab')])
+def test_the_references_training_script_trains_on_the_facade(algo, system, task):
+    """safe_control_gym/experiments/train_rl_controller.py::train() — the script behind BASELINE config #3 — unmodified, with the arguments of
+    examples/rl/train_rl_model.sh and a small budget (tools/run_reference_example.py train): the reference's own PPO / SAC / Safe-Explorer
+    training loop, its make_vec_envs -> DummyVecEnv of facade envs, RecordEpisodeStatistics, buffers, updates, evaluation, logger and
+    checkpointing (model_latest.pt / model_best.pt incl. `env_random_state` gathered from the facade envs) run to completion."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py'), 'train', '--algo', algo, '--system', system,
+                          '--task', task, '--env-steps', '800', '--stub-handle'], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'Training done.' in res.stdout, (res.stdout[-2000:], res.stderr[-2000:])
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('TRAINED')]
+    assert line and 'model_latest.pt' in line[0] and "'agent'" in line[0], res.stdout[-1500:]

@@ -13,6 +13,7 @@ The ONE change is the one INTEGRATION.md describes: the registry's env ids point
     python tools/run_reference_example.py lqr [--algo lqr|ilqr] [--stub-handle]
     python tools/run_reference_example.py rl --algo ppo|sac --system cartpole|quadrotor_2D|quadrotor_3D --task stab|track [--stub-handle]
     python tools/run_reference_example.py matrix [--stub-handle]
+    python tools/run_reference_example.py train --algo ppo|sac|safe_explorer_ppo --system … --task … [--env-steps 1200] [--stub-handle]
 
   matrix: the reference's OWN TEST MATRIX — tests/test_examples/test_lqr.py (LQR / iLQR x stab / track x cartpole / quadrotor_2D / _3D: 12
         cases), test_rl.py (ppo / sac / safe_explorer_ppo with the shipped checkpoints: 18), test_pid.py (4) — with the arguments those tests
@@ -51,6 +52,12 @@ def munchify(x):
     if isinstance(x, dict):
         return Munch({k: munchify(v) for k, v in x.items()})
     return [munchify(v) for v in x] if isinstance(x, list) else x
+
+
+def unmunchify(x):
+    if isinstance(x, dict):
+        return {k: unmunchify(v) for k, v in x.items()}
+    return [unmunchify(v) for v in x] if isinstance(x, (list, tuple)) else x
 
 
 def deep_set(d, key, value):                        # dict_deep.deep_set for --kv_overrides
@@ -116,9 +123,37 @@ def matrix(ref):
     return 0 if n_ok == len(cases) else 1
 
 
+def train(ref, a):
+    """safe_control_gym/experiments/train_rl_controller.py::train(), unmodified, with the arguments of examples/rl/train_rl_model.sh and a small
+    budget: the reference's own PPO / SAC / Safe-Explorer training loop — its make_vec_envs (DummyVecEnv of `rollout_batch_size` facade envs),
+    RecordEpisodeStatistics wrappers, buffers, agent updates, periodic evaluation, logger, checkpointing."""
+    for n in ('tensorboard', 'tensorboard.backend', 'tensorboard.backend.event_processing', 'tensorboard.backend.event_processing.event_accumulator'):
+        sys.modules.setdefault(n, __import__('types').ModuleType(n))      # utils/plotting.py reads TensorBoard logs; plotting is skipped below
+    sys.modules['tensorboard.backend.event_processing.event_accumulator'].EventAccumulator = object
+    os.chdir(ref)
+    import safe_control_gym.experiments.train_rl_controller as TR
+    TR.make_plots = lambda config: None
+    name = 'cartpole' if a.system == 'cartpole' else 'quadrotor'
+    out = tempfile.mkdtemp()
+    kv = ['task_config.init_state=None', 'task_config.randomized_init=True', f'algo_config.max_env_steps={a.env_steps}',
+          'algo_config.rollout_batch_size=2', 'algo_config.eval_batch_size=2', f'algo_config.eval_interval={a.env_steps // 2}',
+          f'algo_config.log_interval={a.env_steps // 2}', 'algo_config.save_interval=0', 'algo_config.num_checkpoints=0']
+    kv += ['algo_config.rollout_steps=100', 'algo_config.mini_batch_size=64'] if a.algo != 'sac' else ['algo_config.warm_up_steps=200', 'algo_config.train_interval=100', 'algo_config.train_batch_size=64']
+    overrides = [f'./examples/rl/config_overrides/{a.system}/{a.algo}_{a.system}.yaml', f'./examples/rl/config_overrides/{a.system}/{a.system}_{a.task}.yaml']
+    if a.algo == 'safe_explorer_ppo':                                        # (train_rl_model.sh: the shipped pre-trained safety layer)
+        kv += [f'algo_config.pretrained={ref}/examples/rl/models/{a.algo}/{a.algo}_pretrain_{a.system}_{a.task}.pt']
+    sys.argv[1:] = ['--algo', a.algo, '--task', name, '--overrides'] + overrides + ['--output_dir', out, '--seed', '2', '--kv_overrides'] + kv
+    TR.train()
+    import torch
+    ck = torch.load(os.path.join(out, 'model_latest.pt'), weights_only=False, map_location='cpu')
+    print('TRAINED', a.algo, a.system, a.task, 'checkpoint keys', sorted(ck)[:6], 'files', sorted(os.listdir(out)))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('example', choices=['lqr', 'rl', 'matrix'])
+    ap.add_argument('example', choices=['lqr', 'rl', 'matrix', 'train'])
+    ap.add_argument('--env-steps', type=int, default=1200)
     ap.add_argument('--algo', default=None)
     ap.add_argument('--system', default='quadrotor_2D', choices=['cartpole', 'quadrotor_2D', 'quadrotor_3D'])
     ap.add_argument('--task', default='track', choices=['stab', 'track'])
@@ -132,7 +167,7 @@ def main():
     if ref is None:
         sys.exit('no reference checkout on this machine')
     ref_stubs.install()
-    sys.modules['munch'].munchify, sys.modules['munch'].Munch = munchify, Munch
+    sys.modules['munch'].munchify, sys.modules['munch'].Munch, sys.modules['munch'].unmunchify = munchify, Munch, unmunchify
     sys.modules['dict_deep'].deep_set = deep_set
     tb = types.ModuleType('torch.utils.tensorboard')           # ExperimentLogger's writer (utils/logging.py); nothing is logged here
     tb.SummaryWriter = type('SummaryWriter', (), {'__init__': lambda s, *a, **k: None, 'add_scalar': lambda s, *a, **k: None,
@@ -149,7 +184,7 @@ def main():
     # (controllers/__init__.py registers every controller at once, MPC's casadi / gpytorch imports included: register the one that runs)
     ctrls = {'lqr': ('lqr', 'lqr:LQR', 'lqr'), 'ilqr': ('lqr', 'ilqr:iLQR', 'ilqr'), 'ppo': ('ppo', 'ppo:PPO', 'ppo'), 'sac': ('sac', 'sac:SAC', 'sac'),
              'pid': ('pid', 'pid:PID', 'pid'), 'safe_explorer_ppo': ('safe_explorer', 'safe_ppo:SafeExplorerPPO', 'safe_ppo')}
-    for idx in (ctrls if a.example == 'matrix' else [a.algo]):
+    for idx in (ctrls if a.example in ('matrix', 'train') else [a.algo]):
         pkg, cls, yml = ctrls[idx]
         register(idx=idx, entry_point=f'safe_control_gym.controllers.{pkg}.{cls}', config_entry_point=f'safe_control_gym.controllers.{pkg}:{yml}.yaml')
     if a.stub_handle:
@@ -158,6 +193,8 @@ def main():
         B.HipVecEnv = _OracleBackedVec
     if a.example == 'matrix':
         return matrix(ref)
+    if a.example == 'train':
+        return train(ref, a)
     with tempfile.TemporaryDirectory() as tmp:
         if a.example == 'lqr':
             ov = os.path.join(ref, 'examples', 'lqr', 'config_overrides', 'cartpole')

@@ -22,6 +22,7 @@ for k in ('ppo', 'sac'):
     print(k, {q: r.get(q) for q in ('median_s', 'reached_two_consecutive', 'error')})
 PY
 ( time timeout 300 python tools/run_reference_example.py matrix ) > $O/matrix_hip.log 2>&1; tail -4 $O/matrix_hip.log | cut -c1-300
+( time timeout 200 python tools/run_reference_example.py train --algo ppo --system cartpole --task stab --env-steps 800 ) > $O/train_hip.log 2>&1; grep 'TRAINED\|Training done\|rror' $O/train_hip.log | tail -3 | cut -c1-300
 for tag in wide st17 recur; do
   timeout 150 python tools/ab_variant.py run $tag --tasks quadrotor_2D_track,quadrotor_3D_track --rounds 2 2>&1 | tee $O/ab_$tag.log | tail -12 | cut -c1-250
 done
