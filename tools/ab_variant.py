@@ -5,7 +5,7 @@
       compiles libscg_spec_<hash>_<tag>.so for the shipped task configs (float32) from the sources in DIR (default: the tree's
       csrc — pass a scratch copy to leave the product untouched) with the extra flags, stamped with the tree's source hash so that
       `SCG_SPEC_TAG=<tag>` loads it, and runs the store-hazard lint on it;
-  run (GPU box):          python tools/ab_variant.py run <tag> [--tasks ...] [--rounds 2]
+  run (GPU box):          python tools/ab_variant.py run <tag> [--tasks ...] [--rounds 2] [--envs 65536,262144] [--no-gate]
       alternates `bench.py --task T` (headline only) with SCG_SPEC_TAG=<tag> and without, prints the launch periods, then the float32
       one-step errors of the variant against the oracle (512 envs x 60 re-synchronised steps) — the quick gate before the full suite;
   clean:                  python tools/ab_variant.py clean <tag>
@@ -49,16 +49,19 @@ def build(tag, src, flags, tasks):
         print(f'{task}: {os.path.basename(out)}')
 
 
-def run(tag, tasks, rounds):
+def run(tag, tasks, rounds, envs=(65536,), gate=True):
     base = ['--steps', '4000', '--warmup', '500', '--no-secondary', '--no-cpu-baseline', '--ppo-seeds', '0', '--sac-seeds', '0']
-    for task in tasks:
+    for task, n_envs in ((t, e) for t in tasks for e in envs):
         for _ in range(rounds):
             for t in (tag, ''):
                 env = dict(os.environ, SCG_SPEC_TAG=t)
-                out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--task', task] + base, env=env, capture_output=True, text=True).stdout
+                out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--task', task, '--envs', str(n_envs)] + base, env=env,
+                                     capture_output=True, text=True).stdout
                 d = json.loads(out.strip().splitlines()[-1])
-                print(f'{task:32s} tag=[{t:8s}] {d["roofline"]["avg_launch_us"]:.4f} us  frac {d["roofline"]["frac"] or 0:.4f}  '
+                print(f'{task:32s} {n_envs:8d} envs tag=[{t:8s}] {d["roofline"]["avg_launch_us"]:.4f} us  frac {d["roofline"]["frac"] or 0:.4f}  '
                       f'{d["config"]["kernel_build"]}  finite={d["config"]["finite_outputs"]}', flush=True)
+    if not gate:
+        return
     os.environ['SCG_SPEC_TAG'] = tag
     import numpy as np
     import torch
@@ -105,12 +108,14 @@ def main():
     ap.add_argument('--flags', default='')
     ap.add_argument('--tasks', default=TASKS[0])
     ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--envs', default='65536', help='comma-separated env counts for the launch-period A/B')
+    ap.add_argument('--no-gate', action='store_true', help='skip the one-step parity gate (e.g. on a second call for another env count)')
     a = ap.parse_args()
     tasks = TASKS if a.tasks == 'all' else tuple(a.tasks.split(','))
     if a.cmd == 'build':
         build(a.tag, a.src, a.flags, tasks)
     elif a.cmd == 'run':
-        run(a.tag, tasks, a.rounds)
+        run(a.tag, tasks, a.rounds, [int(e) for e in a.envs.split(',')], not a.no_gate)
     else:
         from safe_control_gym_amd import _lib
         for p in glob.glob(os.path.join(_lib.SPEC_DIR, f'*_{a.tag}.so')):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, first GPU session (≈ 9 GPU-minutes; run tools/sessions/s81_prepare.sh HERE first — it builds the tagged variants):
+# round 4, first GPU session (≈ 11 GPU-minutes; run tools/sessions/s81_prepare.sh HERE first — it builds the tagged variants):
 #   1. the whole GPU suite on the tree round 3 ended with (its last commits changed only host code and were verified on the CPU:
 #      facade members, EnvSpec's error behaviour, seed validation) — incl. the three non-strict xfail cases of tests/test_gpu_dropin.py that
 #      run the reference's examples / test matrix on the HIP handle (XPASS expected: then drop the xfail marks);
@@ -23,7 +23,8 @@ for k in ('ppo', 'sac'):
 PY
 ( time timeout 300 python tools/run_reference_example.py matrix ) > $O/matrix_hip.log 2>&1; tail -4 $O/matrix_hip.log | cut -c1-300
 ( time timeout 200 python tools/run_reference_example.py train --algo ppo --system cartpole --task stab --env-steps 800 ) > $O/train_hip.log 2>&1; grep 'TRAINED\|Training done\|rror' $O/train_hip.log | tail -3 | cut -c1-300
-for tag in wide st17 recur; do
-  timeout 150 python tools/ab_variant.py run $tag --tasks quadrotor_2D_track,quadrotor_3D_track --rounds 2 2>&1 | tee $O/ab_$tag.log | tail -12 | cut -c1-250
+for tag in wide wide2 st17 recur; do
+  E=65536; case $tag in wide*) E=65536,262144;; esac          # the LDS footprint of the wide-row variants matters from 4 workgroups per CU on
+  timeout 240 python tools/ab_variant.py run $tag --tasks quadrotor_2D_track,quadrotor_3D_track --rounds 2 --envs $E 2>&1 | tee $O/ab_$tag.log | tail -22 | cut -c1-250
 done
 timeout 100 python tools/ab_variant.py run widerecur --tasks quadrotor_2D_track --rounds 2 2>&1 | tee $O/ab_widerecur.log | tail -8 | cut -c1-250

@@ -6,6 +6,7 @@ set -e
 cd "$(dirname "$0")/../.." || exit 1
 R=$PWD
 for v in "wide r04_wide_soa_row_stores.patch -DSCG_EXP_WIDE_ROWS" \
+         "wide2 r04_wide_soa_row_stores.patch -DSCG_EXP_WIDE_ROWS=2" \
          "st17 r04_store_cache_policy.patch -DSCG_EXP_ST_AUX=17" \
          "recur r04_q2_recurrence_integrator.patch -DSCG_EXP_Q2_RECUR"; do
   set -- $v
@@ -18,4 +19,4 @@ P=/tmp/scg_cand_widerecur; S=$P/safe_control_gym_amd/csrc; rm -rf $P; mkdir -p $
 patch -s -d $S scg_env_core.h < tools/candidates/r04_wide_soa_row_stores.patch
 patch -s -d $S scg_env_core.h < tools/candidates/r04_q2_recurrence_integrator.patch && \
   python tools/ab_variant.py build widerecur --src $S "--flags=-DSCG_EXP_WIDE_ROWS -DSCG_EXP_Q2_RECUR" --tasks quadrotor_2D_track || echo "combined variant: patches do not compose cleanly, skipped"
-ls safe_control_gym_amd/spec/ | grep -c '_wide.so\|_st17.so\|_recur.so\|_widerecur.so'
+ls safe_control_gym_amd/spec/ | grep -c '_wide.so\|_wide2.so\|_st17.so\|_recur.so\|_widerecur.so'
