@@ -55,27 +55,55 @@ QUADROTOR_DEFAULT_CONFIG = dict(
 
 
 class ConstraintView:
-    """What `env.constraints` exposes to callers that only read sizes / values (ConstraintList, constraints.py:473-636)."""
+    """What `env.constraints` exposes: the reference's ConstraintList (constraints.py:471-636) over the rows the step kernel evaluates — sizes,
+    per-kind lists of ConstraintInfo entries (which answer like the reference's Constraint objects), values and flags of the LAST step."""
 
     def __init__(self, env):
         self._env = env
         spec = env._venv.spec
-        self.num_constraints = len(spec.con_rows)
-        self.num_state_constraints = spec.n_state_con_rows
-        self.num_input_constraints = sum(1 for r in spec.con_rows if r['var'] == 1)
         self.constraints = spec.con_meta
+        self.constraint_lengths = [m.num_constraints for m in self.constraints]
+        self.constraint_indices = np.cumsum(self.constraint_lengths[:-1])
+        self.num_constraints = len(spec.con_rows)
         self.state_constraints = [m for m in spec.con_meta if m['var'] == 'state']
+        self.num_state_constraints = spec.n_state_con_rows
         self.input_constraints = [m for m in spec.con_meta if m['var'] == 'input']
+        self.num_input_constraints = sum(1 for r in spec.con_rows if r['var'] == 1)
+        self.input_state_constraints, self.num_input_state_constraints = [], 0     # (not evaluable upstream either; EnvSpec refuses them)
 
     def __len__(self):
         return len(self.constraints)
+
+    def get_all_symbolic_models(self):
+        return [m.get_symbolic_model() for m in self.constraints]
+
+    def get_state_constraint_symbolic_models(self):
+        return [m.get_symbolic_model() for m in self.state_constraints]
+
+    def get_input_constraint_symbolic_models(self):
+        return [m.get_symbolic_model() for m in self.input_constraints]
+
+    def get_input_and_state_constraint_symbolic_models(self):
+        return []
+
+    def get_stacked_symbolic_model(self, env=None):
+        raise NotImplementedError('a CasADi Function over env.symbolic.x_sym / u_sym: no CasADi behind this facade (MPC-type callers are out of scope)')
 
     def get_values(self, env=None, only_state=False):
         c = self._env._last_c_values
         return c[:self.num_state_constraints] if only_state else c
 
+    def get_violations(self, env=None, only_state=False):
+        return [m.is_violated(self._env) for m in (self.state_constraints if only_state else self.constraints)]
+
     def is_violated(self, env=None, c_value=None):
+        if c_value is not None:
+            return any(m.is_violated(self._env, c_value=c) for m, c in zip(self.constraints, np.split(np.asarray(c_value), self.constraint_indices)))
         return bool(self._env._last_violation)
+
+    def is_almost_active(self, env=None, c_value=None):
+        cs = np.split(np.asarray(self.get_values() if c_value is None else c_value), self.constraint_indices)
+        return any(m.is_almost_active(self._env, c_value=c) for m, c in zip(self.constraints, cs))
 
 
 class BenchmarkEnv:
@@ -170,7 +198,10 @@ class BenchmarkEnv:
         self.current_noisy_physical_action = self.current_clipped_action = None
         obs = self._venv.reset_tensors()[0].cpu().numpy().astype(np.float64)
         self._info_common()
-        info = dict(self._venv._reset_info({'c_values': self._host_c(), 'done': [False]}, 0, with_constraints=True))
+        host_c = self._host_c()
+        info = dict(self._venv._reset_info({'c_values': host_c, 'done': [False]}, 0, with_constraints=True))
+        if host_c is not None:              # env.constraints.get_values() / is_almost_active() between reset and the first step: the state rows
+            self._last_c_values, self._last_violation = np.asarray(host_c[0], dtype=np.float64), False
         info['symbolic_model'] = self.symbolic
         if self.constraints is not None:
             info['symbolic_constraints'] = [m.get_symbolic_model() for m in self._venv.spec.con_meta]    # constraints.py:458-468

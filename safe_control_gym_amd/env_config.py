@@ -112,6 +112,20 @@ class ConstraintInfo(dict):
     def get_symbolic_model(self):
         return self.sym_func
 
+    # values / flags of THIS constraint on the single-env facade (constraints.py:97-165): sliced out of the rows the step kernel evaluated
+    def get_value(self, env):
+        return np.asarray(env.constraints.get_values(env))[self.first_row:self.first_row + self.n_rows]
+
+    def is_violated(self, env, c_value=None):
+        c = self.get_value(env) if c_value is None else np.asarray(c_value)
+        return bool(np.any(np.greater_equal(c, 0.) if self.strict else np.greater(c, 0.)))
+
+    def is_almost_active(self, env, c_value=None):
+        if self.get('tolerance') is None:
+            return False
+        c = self.get_value(env) if c_value is None else np.asarray(c_value)
+        return bool(np.any(np.greater(c + self['tolerance'], 0.)))
+
 
 @dataclass
 class EnvSpec:
@@ -517,7 +531,6 @@ class EnvSpec:
                 sym = dict(A=np.vstack((-np.eye(n), np.eye(n))).astype(np.float32), b=np.hstack((bound, bound)).astype(np.float32), bound=bound)
                 if tolerance is not None and len(np.array(tolerance, ndmin=1)) != n:                  # constraints.py:449-455
                     raise ValueError('[ERROR] the tolerance dimension does not match the number of constraints.')
-                tolerance = None
                 assert self.COST == 'rl_reward', '[ERROR] SymmetricStateConstraint is meant for RL environments'   # after super().__init__ (:446-447)
                 for j in range(len(idx)):
                     self.con_rows.append(dict(kind=L.ROW_ABS, var=var_id, index=idx[j], strict=strict, sign=1.0,
@@ -528,7 +541,8 @@ class EnvSpec:
                 raise ValueError('[ERROR] the tolerance dimension does not match the number of constraints.')
             self.con_meta.append(ConstraintInfo(form=form, var=var, first_row=first, n_rows=len(self.con_rows) - first, strict=strict,
                                                 constrained_variable=var, dim=len(idx), num_constraints=len(self.con_rows) - first,
-                                                decimals=decimals, constraint_filter=np.eye(full_dim)[idx], **sym))
+                                                decimals=decimals, constraint_filter=np.eye(full_dim)[idx],
+                                                tolerance=None if tolerance is None else np.array(tolerance, ndmin=1), **sym))
         if len(self.con_rows) > L.MAX_CON_ROWS:
             raise ValueError(f'more than {L.MAX_CON_ROWS} scalar constraint rows')
         self.num_constraints = len(self.con_rows)

@@ -483,3 +483,58 @@ def test_the_references_training_script_trains_on_the_facade(algo, system, task)
     assert res.returncode == 0 and 'Training done.' in res.stdout, (res.stdout[-2000:], res.stderr[-2000:])
     line = [ln for ln in res.stdout.splitlines() if ln.startswith('TRAINED')]
     assert line and 'model_latest.pt' in line[0] and "'agent'" in line[0], res.stdout[-1500:]
+
+
+@pytest.mark.parametrize('system', ['cartpole', 'quadrotor_2D'])
+def test_constraint_list_api_follows_the_references_env(system, monkeypatch):
+    """`env.constraints` as the reference's ConstraintList: sizes, per-kind lists, `get_values`, `get_violations`, `is_violated`,
+    `is_almost_active` (with `tolerance`), per-constraint `get_value / is_violated / is_almost_active` — the facade (oracle-backed handle)
+    and the REFERENCE's own env stepped with the same actions from the same deterministic start agree at every step."""
+    from tests.golden import ref_stubs
+    if ref_stubs.reference_root() is None:
+        pytest.skip('needs the reference checkout')
+    import safe_control_gym_amd.benchmark_env as B
+    from tests.config_fuzz import fuzz_config
+    from tests.golden import make_golden as MG
+    monkeypatch.setattr(B, 'HipVecEnv', _OracleBackedVec)
+    env_id, cfg = fuzz_config(system, 2)
+    cfg = dict(cfg, randomized_init=False, randomized_inertial_prop=False, disturbances=None, adversary_disturbance=None, done_on_violation=False,
+               done_on_out_of_bound=False, cost='rl_reward')
+    nx = 4 if system == 'cartpole' else 6
+    lo, hi = ([-0.4, -0.3], [0.4, 0.3]) if system == 'cartpole' else ([-0.5, 0.6], [0.5, 1.4])
+    cfg['constraints'] = [
+        {'constraint_form': 'bounded_constraint', 'constrained_variable': 'state', 'lower_bounds': lo, 'upper_bounds': hi, 'active_dims': [0, 2],
+         'tolerance': [0.2, 0.2, 0.2, 0.2]},
+        {'constraint_form': 'default_constraint', 'constrained_variable': 'input', 'strict': True},
+        {'constraint_form': 'quadratic_constraint', 'constrained_variable': 'state', 'P': np.eye(nx).tolist(), 'b': 1.5, 'tolerance': [0.5]}]
+    ref = MG.ENV_CLS[env_id](**dict(cfg, output_dir='/tmp', seed=5))
+    mine = (B.CartPole if env_id == 'cartpole' else B.Quadrotor)(**dict(cfg, seed=5))
+    rc, mc = ref.constraints, mine.constraints
+    for k in ('num_constraints', 'num_state_constraints', 'num_input_constraints', 'num_input_state_constraints', 'constraint_lengths'):
+        assert getattr(rc, k) == getattr(mc, k), k
+    np.testing.assert_array_equal(rc.constraint_indices, mc.constraint_indices)
+    assert (len(rc), len(rc.state_constraints), len(rc.input_constraints)) == (len(mc), len(mc.state_constraints), len(mc.input_constraints))
+    assert len(mc.get_all_symbolic_models()) == 3 and len(mc.get_state_constraint_symbolic_models()) == 2 and len(mc.get_input_constraint_symbolic_models()) == 1
+    ro, ri = ref.reset()
+    mo, mi = mine.reset()
+    np.testing.assert_allclose(mo, ro, atol=1e-12)
+    np.testing.assert_allclose(mc.get_values(mine, only_state=True), rc.get_values(ref, only_state=True), atol=1e-8)
+    rng = np.random.default_rng(0)
+    seen = set()
+    for t in range(60):
+        a = rng.uniform(ref.action_space.low, ref.action_space.high) * (1.3 if t % 7 == 0 else 1.0)      # sometimes beyond the input bounds
+        ro, rr, rd, ri = ref.step(a)
+        mo, mr, md, mi = mine.step(a)
+        np.testing.assert_allclose(mo, ro, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(mc.get_values(mine), rc.get_values(ref), atol=2e-8)
+        assert mc.get_violations(mine) == rc.get_violations(ref) and mc.is_violated(mine) == rc.is_violated(ref)
+        assert mc.is_violated(mine, c_value=mi['constraint_values']) == rc.is_violated(ref, c_value=ri['constraint_values'])
+        assert mc.is_almost_active(mine) == rc.is_almost_active(ref)
+        for m, r in zip(mc.constraints, rc.constraints):
+            np.testing.assert_allclose(m.get_value(mine), r.get_value(ref), atol=2e-8)
+            assert m.is_violated(mine) == r.is_violated(ref) and m.is_almost_active(mine) == r.is_almost_active(ref)
+        seen.add((tuple(rc.get_violations(ref)), rc.is_almost_active(ref)))
+        if rd:
+            break
+    assert len(seen) >= 2, seen                                           # the flags actually changed along the way
+    ref.close(); mine.close()
