@@ -11,6 +11,8 @@ runs without one:
     the scratch copy tools/stage_reference.py stages) under tests/golden/ref_stubs.py and are skipped where there is none.
 The kernels' half of the same comparisons is tests/test_gpu_config_fuzz.py / tests/test_gpu_facade.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -538,3 +540,43 @@ def test_constraint_list_api_follows_the_references_env(system, monkeypatch):
             break
     assert len(seen) >= 2, seen                                           # the flags actually changed along the way
     ref.close(); mine.close()
+
+
+def test_every_env_attribute_the_references_callers_read_exists(monkeypatch):
+    """Static audit: every `env.<name>` / `self.env.<name>` that the reference's in-scope callers touch (PPO / SAC / Safe-Explorer / RARL /
+    LQR / PID controllers, base_controller, experiments, env wrappers, metrics, utils) exists either on the single-env facade or — for the
+    names that belong to the reference's wrapper / vec-env layer — on HipVecEnv / this package's episode-statistics wrapper."""
+    import glob
+    import re
+
+    from tests.golden import ref_stubs
+    root = ref_stubs.reference_root()
+    if root is None:
+        pytest.skip('needs the reference checkout')
+    import safe_control_gym_amd.benchmark_env as B
+    import safe_control_gym_amd.record_episode_statistics as R
+    import safe_control_gym_amd.vec_env as V
+    from tests.config_fuzz import fuzz_config
+    monkeypatch.setattr(B, 'HipVecEnv', _OracleBackedVec)
+    ref = os.path.join(root, 'safe_control_gym')
+    files = [os.path.join(ref, 'controllers', 'base_controller.py')]
+    for d in ('controllers/ppo', 'controllers/sac', 'controllers/safe_explorer', 'controllers/rarl', 'controllers/lqr', 'controllers/pid', 'experiments',
+              'envs/env_wrappers', 'envs/env_wrappers/vectorized_env', 'math_and_models/metrics', 'utils'):
+        files += glob.glob(os.path.join(ref, d, '*.py'))
+    names = set()
+    for f in files:
+        names |= set(re.findall(r'\b(?:self\.)?(?:env|train_env|eval_env|test_env)\.([A-Za-z_][A-Za-z_0-9]*)', open(f).read()))
+    assert len(names) >= 35
+    envs = []
+    for system, extra in (('cartpole', {}), ('quadrotor_2D', {'adversary_disturbance': 'dynamics'})):
+        env_id, cfg = fuzz_config(system, 2)
+        envs.append((B.CartPole if env_id == 'cartpole' else B.Quadrotor)(**dict(cfg, **extra)))
+    wrapper_src = open(R.__file__).read() + open(V.__file__).read()
+    missing = []
+    for n in sorted(names):
+        on_facade = hasattr(envs[1], n) and (hasattr(envs[0], n) or n in ('QUAD_TYPE', 'adversary_action_space', 'adversary_observation_space'))
+        on_vec_layer = hasattr(V.HipVecEnv, n) or re.search(rf'def {n}\b|self\.{n}\b', wrapper_src)
+        experiment_wrapper = n in ('data', 'clear_data', 'save_data')        # RecordDataWrapper's own members (experiments/base_experiment.py wraps the env in it)
+        if not (on_facade or on_vec_layer or experiment_wrapper):
+            missing.append(n)
+    assert not missing, missing
