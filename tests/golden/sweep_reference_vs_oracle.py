@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Live sweep (build container only: needs /root/reference): the REFERENCE's own Python against the oracle on tests/config_fuzz.py
 configs beyond the committed rollout_fuzz_* fixtures — nothing is written, every case is generated into a temp dir, replayed by
-tests/test_oracle_golden.py's checker and deleted.  Last run (round 3): seeds 3..18 of the four systems = 64 configs, 63 reproduced to
+tests/test_oracle_golden.py's checker and deleted.  Last runs (round 3): seeds 3..18 and 19..50 of the four systems = 192 configs, 191 reproduced to
 1e-9; quadrotor_2D seed 3 makes the REFERENCE raise (AttributeError: 'Quadrotor' object has no attribute 'out_of_bounds' — its _get_info
 reads the attribute _get_done only sets when it does not return early on goal_reached, quadrotor.py:871-892, here on an episode's first
 step; the oracle and the kernels report False there).
