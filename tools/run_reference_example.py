@@ -134,11 +134,15 @@ def train(ref, a):
     import safe_control_gym.experiments.train_rl_controller as TR
     TR.make_plots = lambda config: None
     name = 'cartpole' if a.system == 'cartpole' else 'quadrotor'
-    out = tempfile.mkdtemp()
-    kv = ['task_config.init_state=None', 'task_config.randomized_init=True', f'algo_config.max_env_steps={a.env_steps}',
-          'algo_config.rollout_batch_size=2', 'algo_config.eval_batch_size=2', f'algo_config.eval_interval={a.env_steps // 2}',
-          f'algo_config.log_interval={a.env_steps // 2}', 'algo_config.save_interval=0', 'algo_config.num_checkpoints=0']
-    kv += ['algo_config.rollout_steps=100', 'algo_config.mini_batch_size=64'] if a.algo != 'sac' else ['algo_config.warm_up_steps=200', 'algo_config.train_interval=100', 'algo_config.train_batch_size=64']
+    out = a.output_dir or tempfile.mkdtemp()
+    if a.env_steps == 0:                                                     # the reference's own budget, exactly train_rl_model.sh's arguments
+        kv = ['task_config.init_state=None', 'task_config.randomized_init=True']
+    else:
+        kv = ['task_config.init_state=None', 'task_config.randomized_init=True', f'algo_config.max_env_steps={a.env_steps}',
+              'algo_config.rollout_batch_size=2', 'algo_config.eval_batch_size=2', f'algo_config.eval_interval={a.env_steps // 2}',
+              f'algo_config.log_interval={a.env_steps // 2}', 'algo_config.save_interval=0', 'algo_config.num_checkpoints=0']
+        kv += (['algo_config.rollout_steps=100', 'algo_config.mini_batch_size=64'] if a.algo != 'sac' else
+               ['algo_config.warm_up_steps=200', 'algo_config.train_interval=100', 'algo_config.train_batch_size=64'])
     overrides = [f'./examples/rl/config_overrides/{a.system}/{a.algo}_{a.system}.yaml', f'./examples/rl/config_overrides/{a.system}/{a.system}_{a.task}.yaml']
     if a.algo == 'safe_explorer_ppo':                                        # (train_rl_model.sh: the shipped pre-trained safety layer)
         kv += [f'algo_config.pretrained={ref}/examples/rl/models/{a.algo}/{a.algo}_pretrain_{a.system}_{a.task}.pt']
@@ -153,7 +157,8 @@ def train(ref, a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('example', choices=['lqr', 'rl', 'matrix', 'train'])
-    ap.add_argument('--env-steps', type=int, default=1200)
+    ap.add_argument('--env-steps', type=int, default=1200, help='train: small budget (0 = the YAML budget of the reference, e.g. 300 000 steps for PPO on cartpole)')
+    ap.add_argument('--output-dir', default=None)
     ap.add_argument('--algo', default=None)
     ap.add_argument('--system', default='quadrotor_2D', choices=['cartpole', 'quadrotor_2D', 'quadrotor_3D'])
     ap.add_argument('--task', default='track', choices=['stab', 'track'])
