@@ -42,6 +42,13 @@ RAP_DEFAULTS = dict({k: v for k, v in RARL_DEFAULTS.items() if k not in ('pretra
                     num_adversaries=2)                                                  # controllers/rarl/rap.yaml
 
 
+# controllers/safe_explorer/safe_ppo.yaml
+SAFE_EXPLORER_PPO_DEFAULTS = dict({k: v for k, v in PPO_DEFAULTS.items() if k != 'activation'}, pretraining=True, pretrained=None,
+                                  constraint_hidden_dim=10, constraint_lr=0.0001, constraint_batch_size=256,
+                                  constraint_steps_per_epoch=6000, constraint_epochs=25, constraint_eval_steps=1500,
+                                  constraint_eval_interval=5, constraint_buffer_size=1000000, constraint_slack=None)
+
+
 class _Deterministic:
     def __init__(self, ac):
         self.ac = ac
@@ -245,4 +252,100 @@ class SAC(HipController):
         self.impl.load(path, training=self.training)
 
 
-# (the ids 'ppo', 'sac', 'rarl', 'rap' are registered in registration.py with lazy entry points to these classes)
+class SafeExplorerPPO(PPO):
+    """controllers/safe_explorer/safe_ppo.py:32-466 — two phases selected by the config, as upstream:
+      pretraining: True    learn() = `constraint_epochs` x pretrain_step (random-action transitions -> constraint models); the
+                           checkpoint's 'safety_layer' is what the second phase loads;
+      pretraining: False   reset() loads the safety layer from `pretrained` (a checkpoint file, or a directory holding
+                           model_latest.pt; safe_ppo.py:96-100) and learn() is PPO with the safety-filtered policy."""
+    DEFAULTS = SAFE_EXPLORER_PPO_DEFAULTS
+
+    def _policy_shape(self):
+        return None                                 # the safety layer sits inside the actor: no fused collector
+
+    def _build(self):
+        self.activation = self.algo_config.setdefault('activation', 'tanh')         # (safe_ppo_utils.py: the PPO networks' default)
+        super()._build()
+        self.safety_layer = self.impl.safety_layer
+        self.num_constraints = self.impl.C
+        self._pretrain_steps = 0
+
+    def _make_impl(self, pcfg):
+        from safe_control_gym_amd import safe_explorer
+        slack = self.constraint_slack
+        if not isinstance(slack, (int, float, list, tuple)):        # safe_explorer_utils.py:47 asserts the same (the YAML default is null)
+            raise AssertionError('constraint_slack must be a number or a list (one value per state constraint)')
+        return safe_explorer.SafeExplorerPPO(self.env, pcfg, seed=self.seed, constraint_hidden_dim=self.constraint_hidden_dim,
+                                             constraint_lr=self.constraint_lr, constraint_slack=slack,
+                                             constraint_batch_size=self.constraint_batch_size,
+                                             constraint_buffer_size=self.constraint_buffer_size)
+
+    @property
+    def total_steps(self):
+        return self._pretrain_steps if (self.training and self.pretraining) else self.impl.total_steps
+
+    def reset(self):
+        super().reset()
+        if self.training and not self.pretraining:
+            if not self.pretrained:
+                raise AssertionError('Must provide a pre-trained model for adaptation.')         # safe_ppo.py:97
+            self.impl.load_safety_layer(self.pretrained)
+
+    def pretrain_step(self):
+        import time
+        t0 = time.perf_counter()
+        losses = self.impl.pretrain_step(self.constraint_steps_per_epoch, self.constraint_batch_size)
+        self._pretrain_steps += 1
+        res = {f'constraint_{i}_loss': v for i, v in enumerate(losses)}
+        res.update({'step': self._pretrain_steps, 'elapsed_time': time.perf_counter() - t0})
+        return res
+
+    def eval_constraint_models(self):
+        return {f'constraint_{i}_loss': v for i, v in
+                enumerate(self.impl.eval_constraint_models(self.constraint_eval_steps, self.constraint_batch_size))}
+
+    def select_action(self, obs, info=None):
+        """safe_ppo.py:215-228: the current constraint values are the policy's second input."""
+        with torch.inference_mode():
+            o = torch.as_tensor(np.asarray(obs), dtype=torch.float32, device=self.device)
+            c = torch.as_tensor(np.asarray(info['constraint_values'])[..., :self.num_constraints], dtype=torch.float32, device=self.device)
+            nz = self.impl.obs_normalizer
+            frozen = nz.read_only
+            nz.set_read_only()
+            o = nz(o)
+            nz.read_only = frozen
+            batched = o.dim() == 2
+            a = self.impl.agent.ac.act(o if batched else o[None], c if batched else c[None])
+            return (a if batched else a[0]).cpu().numpy()
+
+    def run(self, env=None, render=False, n_episodes=10, verbose=False, **kwargs):
+        if render:
+            raise NotImplementedError('no renderer: the simulator has no GUI')
+        ev = env if isinstance(env, HipVecEnv) else None
+        if ev is None:
+            if getattr(self, '_run_env', None) is None or self._run_env.num_envs != n_episodes:
+                self._run_env = self._vec(n_episodes, self.seed * 111)
+            ev = self._run_env
+        tot = self.impl.evaluate(ev)
+        out = {'ep_returns': tot['ret'].double().cpu().numpy(), 'ep_lengths': tot['length'].double().cpu().numpy(),
+               'constraint_violation': tot['viol'].double().cpu().numpy(), 'mse': tot['mse'].double().cpu().numpy()}
+        self.results_dict = out
+        return out
+
+    def learn(self, env=None, **kwargs):
+        if not self.pretraining:
+            return super().learn(env, **kwargs)
+        hist = []                                   # safe_ppo.py:178-213 with final_step = constraint_epochs, train_func = pretrain_step
+        while self._pretrain_steps < self.constraint_epochs:
+            results = self.pretrain_step()
+            k = self._pretrain_steps
+            if k >= self.constraint_epochs or (self.save_interval and k % self.save_interval == 0):
+                self.save(self.checkpoint_path)
+            if self.eval_interval and k % self.eval_interval == 0:
+                results['eval'] = self.eval_constraint_models()
+            if self.log_interval and k % self.log_interval == 0:
+                hist.append({q: v for q, v in results.items() if not isinstance(v, dict)})
+        return hist
+
+
+# (the ids 'ppo', 'sac', 'rarl', 'rap', 'safe_explorer_ppo' are registered in registration.py with lazy entry points to these classes)

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/scg_hip.h"
+#include "scg_once.h"
 #include "scg_params.h"
 #include "scg_rng.h"
 #ifdef SCG_SPEC
@@ -777,11 +778,12 @@ extern "C" int scg_rollout_policy(scg_env* env, const scg_policy* pol, int k_ste
     // overrides (tests run both geometries on small batches; results do not depend on it: Philox streams are per env).
     int epw = env->cfg.num_envs <= 32768 ? 32 : 64;
     if (const char* o = getenv("SCG_ROLLOUT_EPW")) { if (atoi(o) == 32 || atoi(o) == 64) epw = atoi(o); }
-    static bool attr = false;
-    if (!attr) {
+    static scg::PerDeviceOnce attr;         // (per device, scg_once.h: the caller has made the handle's device current)
+    int attr_dev;
+    if (attr.pending(&attr_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr = true;
+        attr.commit(attr_dev);
     }
     if (epw == 64) {
         rollout_policy_kernel<S, DD, 64><<<dim3((env->cfg.num_envs + 255) / 256), dim3(256), bytes, (hipStream_t)stream>>>(I, A);

@@ -27,6 +27,7 @@
 
 #include "../../include/scg_learn.h"
 #include "scg_mlp.h"
+#include "scg_once.h"
 
 #ifndef SCG_L_NIN
 #error "compile with -DSCG_L_NIN= -DSCG_L_H= -DSCG_L_NU= -DSCG_L_ACT="
@@ -675,13 +676,15 @@ extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layo
     hipStream_t st = (hipStream_t)stream;
     if (nout == NU) {
         const size_t bytes = MlpLds<NIN, HID, NU>::END * sizeof(float);
-        static bool set_a = false;          // (once per process: the attribute call costs more host time than the launch)
-        if (!set_a) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_a = true; }
+        static scg::PerDeviceOnce set_a;    // (once per device: the attribute call costs more host time than the launch)
+        int dev;
+        if (set_a.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_a.commit(dev); }
         mlp_forward_kernel<NU><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else if (nout == 1) {
         const size_t bytes = MlpLds<NIN, HID, 1>::END * sizeof(float);
-        static bool set_c = false;
-        if (!set_c) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_c = true; }
+        static scg::PerDeviceOnce set_c;
+        int dev;
+        if (set_c.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_c.commit(dev); }
         mlp_forward_kernel<1><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else {
         return fail(-1, "scg_mlp_forward: this library serves nout = act_dim or 1");
@@ -711,8 +714,9 @@ extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
     G.idx = a->d_idx; G.batch = a->batch; G.clip_param = a->clip_param; G.use_clipped_value = a->use_clipped_value;
     G.partials = (float*)a->d_workspace;
     const size_t bytes = grad_lds_words() * sizeof(float);
-    static bool set_g = false;
-    if (!set_g) { HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_g = true; }
+    static scg::PerDeviceOnce set_g;
+    int dev;
+    if (set_g.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_g.commit(dev); }
     ppo_grad_kernel<<<dim3(a->n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
     HIP_TRY(hipGetLastError());
     ReduceArgs R;

@@ -33,6 +33,7 @@
 
 #include "../../include/scg_sac.h"
 #include "scg_mlp.h"
+#include "scg_once.h"
 #include "scg_rng.h"
 
 #ifndef SCG_S_NOBS
@@ -811,15 +812,16 @@ static size_t wide_lds_q() { return wide::Lds<1>::END * sizeof(float); }
 // One-time kernel attributes (dynamic LDS above 64 KB).  Call once before capturing scg_sac_update into a HIP graph: the
 // attribute calls are not stream operations.  scg_sac_update calls it itself otherwise.
 extern "C" int scg_sac_prepare(void) {
-    static bool done = false;
-    if (done) return 0;
+    static scg::PerDeviceOnce once;         // per device (scg_once.h): call with the agent's device current
+    int dev;
+    if (!once.pending(&dev)) return 0;
     const size_t lds_a = lds_actor_bytes();
     if (lds_a > 160 * 1024 || wide_lds_actor() > 160 * 1024 || wide_lds_q() > 160 * 1024)
         return fail(-1, "scg_sac: network image does not fit the LDS");
     if (set_lds(actor_act_kernel, lds_a)) return -2;
     if (set_lds(wide::actor_fwd_kernel, wide_lds_actor()) || set_lds(wide::actor_grad_kernel, wide_lds_actor()) ||
         set_lds(wide::q_kernel<0>, wide_lds_q()) || set_lds(wide::q_kernel<1>, wide_lds_q()) || set_lds(wide::q_kernel<2>, wide_lds_q())) return -2;
-    done = true;
+    once.commit(dev);
     return 0;
 }
 

@@ -38,6 +38,23 @@ class RunningMeanStd:
             batch_var = x.var(0, unbiased=False)
         self.update_from_moments(batch_mean, batch_var, n.reshape(()))
 
+    def update_masked(self, arr, mask):
+        """Update from the rows of `arr` selected by the boolean `mask` — the statistics of `update(arr[mask])`, computed with static
+        shapes and no host value (a data-dependent row count inside a captured graph); no selected row: the statistics stay."""
+        x = arr.to(torch.float64)
+        w = mask.to(torch.float64).reshape((-1,) + (1,) * (x.dim() - 1))
+        n, s1 = w.sum().reshape(1), (w * x).sum(0)
+        if parallel.world_size() > 1:
+            flat = torch.cat([n, s1.reshape(-1)])
+            parallel.all_reduce_sum_(flat)
+            n, s1 = flat[:1], flat[1:].reshape(s1.shape)
+        n1 = n.clamp(min=1.0)
+        batch_mean = s1 / n1
+        s2 = (w * (x - batch_mean) ** 2).sum(0)
+        if parallel.world_size() > 1:
+            parallel.all_reduce_sum_(s2)
+        self.update_from_moments(batch_mean, s2 / n1, n.reshape(()))
+
     def update_from_moments(self, batch_mean, batch_var, batch_count):
         delta = batch_mean - self.mean
         tot = self.count + batch_count
@@ -76,9 +93,14 @@ class MeanStdNormalizer(BaseNormalizer):
         self.rms = RunningMeanStd(shape, device)
         self.clip, self.epsilon = float(clip), float(epsilon)
 
-    def __call__(self, x):
+    def __call__(self, x, mask=None):
+        """`mask` (bool [batch]): only those rows enter the statistics — upstream's call on a gathered subset of rows
+        (sac.py:296-297: the truncated envs' terminal observations); every row is normalised."""
         if not self.read_only:
-            self.rms.update(x)
+            if mask is None:
+                self.rms.update(x)
+            else:
+                self.rms.update_masked(x, mask)
         y = (x.to(torch.float64) - self.rms.mean) / torch.sqrt(self.rms.var + self.epsilon)
         return y.clamp(-self.clip, self.clip).to(x.dtype)
 

@@ -146,9 +146,10 @@ def _same_config(a, b):
 
 
 def _grouped(env_id, base_cfg, cfgs, kwargs, seed):
-    """One HipVecEnv per distinct per-env config (first-occurrence order); env k of group g gets the Philox stream of global
-    env id k (env_id_offset = its first member, members keep their relative order), so a grouped batch and a homogeneous one
-    draw the same numbers for the same env index whenever the groups are contiguous."""
+    """One HipVecEnv per distinct per-env config (first-occurrence order).  The groups get DISJOINT ranges of global env ids
+    (env_id_offset = the number of envs in the groups before it; the kernel's Philox counter word 0 is offset + row), so no two
+    envs of the batch share a random stream whatever the interleaving; when the groups are contiguous runs of the batch that is
+    exactly "env k draws the stream of global env id k", i.e. the same numbers as a homogeneous batch."""
     from safe_control_gym_amd.vec_env import GroupedVecEnv, HipVecEnv
     reps, members = [], []
     for k, c in enumerate(cfgs):
@@ -159,11 +160,12 @@ def _grouped(env_id, base_cfg, cfgs, kwargs, seed):
         else:
             reps.append(c)
             members.append([k])
-    groups = []
+    groups, first_id = [], 0
     for r, idx in zip(reps, members):
         c = dict(base_cfg)
         c.update(r)
         c.update(kwargs)
         c.pop('seed', None)
-        groups.append((HipVecEnv(env_id, len(idx), seed=seed, env_id_offset=idx[0], **c), idx))
+        groups.append((HipVecEnv(env_id, len(idx), seed=seed, env_id_offset=first_id, **c), idx))
+        first_id += len(idx)
     return GroupedVecEnv(groups)

@@ -107,6 +107,6 @@ register(idx='quadrotor', entry_point='safe_control_gym_amd.benchmark_env:Quadro
          config_entry_point='safe_control_gym_amd.benchmark_env:QUADROTOR_DEFAULT_CONFIG')
 
 # controller ids of the reference (controllers/__init__.py:29-47); classes and YAML defaults load lazily (they import torch)
-for _idx, _cls in (('ppo', 'PPO'), ('sac', 'SAC'), ('rarl', 'RARL'), ('rap', 'RAP')):
+for _idx, _cls in (('ppo', 'PPO'), ('sac', 'SAC'), ('rarl', 'RARL'), ('rap', 'RAP'), ('safe_explorer_ppo', 'SafeExplorerPPO')):
     register(idx=_idx, entry_point=f'safe_control_gym_amd.controllers:{_cls}',
              config_entry_point=f'safe_control_gym_amd.controllers:{_idx.upper()}_DEFAULTS')

@@ -242,8 +242,9 @@ class SACAgent:
         from safe_control_gym_amd import _sac
         fl, cfg = self._flat, self.cfg
         D = _sac.lib(self.obs_dim, cfg.hidden_dim, self.act_dim, cfg.activation)
-        _sac.check(D, D.scg_sac_prepare())
         dev = fl['p'].device
+        with torch.cuda.device(dev):            # kernel attributes are per device (csrc/scg_once.h)
+            _sac.check(D, D.scg_sac_prepare())
         ws = torch.empty(D.scg_sac_workspace_bytes(int(batch_size)), dtype=torch.uint8, device=dev)
         stats, acc = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
         p = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
@@ -307,14 +308,55 @@ class SACAgent:
         st = (F['acc'] / n_updates).tolist()
         return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
 
+    # ---- the two Adam layouts: torch.optim per-parameter state <-> the fused update's flat m / v / steps
+    def _opt_groups(self):
+        return ((self.actor_opt, 0), (self.critic_opt, 1), (self.alpha_opt, 2))
+
+    def _flat_offset(self, p):
+        fl = self._flat['p']
+        return (p.data_ptr() - fl.data_ptr()) // fl.element_size()
+
+    def _adam_flat_to_torch(self):
+        """Write the flat moments into the torch optimisers' state (what their state_dict() then carries): a checkpoint of a fused
+        agent resumes in an agent that steps torch.optim (CPU, unsupported shape, fused_update off) and in the reference's SACAgent."""
+        fl = self._flat
+        steps = fl['steps'].tolist()
+        for opt, which in self._opt_groups():
+            if steps[which] <= 0:
+                continue
+            for p in opt.param_groups[0]['params']:
+                o, k = self._flat_offset(p), p.numel()
+                st = opt.state[p]
+                st['exp_avg'] = fl['m'][o:o + k].view_as(p).clone()
+                st['exp_avg_sq'] = fl['v'][o:o + k].view_as(p).clone()
+                st['step'] = torch.tensor(float(steps[which]), device=p.device if opt.defaults.get('capturable') else 'cpu')
+
+    def _adam_torch_to_flat(self):
+        """The converse: per-parameter torch.optim state (the reference's training checkpoints, or one saved with fused_update off)
+        scattered into the flat moments the fused kernels step."""
+        fl = self._flat
+        for opt, which in self._opt_groups():
+            n_steps = 0.0
+            for p in opt.param_groups[0]['params']:
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                o, k = self._flat_offset(p), p.numel()
+                fl['m'][o:o + k].copy_(st['exp_avg'].reshape(-1))
+                fl['v'][o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
+                n_steps = float(st['step'])
+            fl['steps'][which] = n_steps
+
     # same keys as the reference's SACAgent (sac_utils.py:85-108), so its checkpoints load directly; the action bounds are
     # buffers here (not in upstream's state dict), hence strict=False
     def state_dict(self):
+        if self._flat is not None:
+            self._adam_flat_to_torch()
         sd = {'ac': self.ac.state_dict(), 'log_alpha': self.log_alpha.detach().clone(), 'ac_targ': self.ac_targ.state_dict(),
               'actor_opt': self.actor_opt.state_dict(), 'critic_opt': self.critic_opt.state_dict(),
               'alpha_opt': self.alpha_opt.state_dict()}
-        if self._flat is not None:          # fused mode: the Adam moments live in the flat buffers (the torch optimisers never step)
-            sd['flat_adam'] = {k: self._flat[k].clone() for k in ('m', 'v', 'steps', 'counter')}
+        if self._flat is not None:          # fused mode: the sampling counter of the update kernels (the moments travel in torch's layout above)
+            sd['flat_adam'] = {'counter': self._flat['counter'].clone()}
         return sd
 
     def load_state_dict(self, sd, with_optimizers=True):
@@ -330,14 +372,16 @@ class SACAgent:
             self.actor_opt.load_state_dict(sd['actor_opt'])
             self.critic_opt.load_state_dict(sd['critic_opt'])
             self.alpha_opt.load_state_dict(sd['alpha_opt'])
+            for opt, _ in self._opt_groups():               # (a checkpoint mapped onto the GPU: eager Adam keeps its step counts on the host)
+                if not opt.defaults.get('capturable'):
+                    for st in opt.state.values():
+                        if torch.is_tensor(st.get('step')):
+                            st['step'] = st['step'].cpu()
             self._graph = None
-            if self._flat is not None:
-                if 'flat_adam' in sd:
-                    for k, t in sd['flat_adam'].items():
-                        self._flat[k].copy_(t.to(self._flat[k].device))       # in place: captured graphs alias these buffers
-                elif sd['actor_opt'].get('state'):
-                    raise ValueError('checkpoint carries torch.optim state only (saved with fused_update off); load it with '
-                                     "extra={'fused_update': False} — the flat Adam moments would silently restart from zero")
+            if self._flat is not None:      # in place: captured graphs alias the flat buffers
+                self._adam_torch_to_flat()
+                for k, t in sd.get('flat_adam', {}).items():        # (round-3 checkpoints carry m / v / steps here as well: same values)
+                    self._flat[k].copy_(t.to(self._flat[k].device))
 
     def policy_loss(self, batch):
         obs = batch['obs']
@@ -438,10 +482,14 @@ class SAC:
         self.device = env.device
         if env.dtype != torch.float32:
             raise ValueError('the SAC collector runs on float32 environments')
-        if cfg.extra.get('norm_obs') or cfg.extra.get('norm_reward'):
-            # sac.yaml:6-9 / sac.py:66-71: running normalisers around env.step.  Not built for SAC here — refuse rather than train
-            # unnormalised behind a config that asks for them (PPO has them: normalization.py)
-            raise NotImplementedError('norm_obs / norm_reward are not implemented for the SAC collector (defaults: False)')
+        # sac.yaml:6-9 / sac.py:75-81: running normalisers around env.step (defaults off), device-resident (normalization.py)
+        from safe_control_gym_amd.normalization import BaseNormalizer, MeanStdNormalizer, RewardStdNormalizer
+        x = cfg.extra
+        self.obs_normalizer = (MeanStdNormalizer((env.spec.obs_dim,), self.device, clip=x.get('clip_obs', 10.0)) if x.get('norm_obs')
+                               else BaseNormalizer())
+        self.reward_normalizer = (RewardStdNormalizer(cfg.gamma, self.device, clip=x.get('clip_reward', 10.0)) if x.get('norm_reward')
+                                  else BaseNormalizer())
+        self._normalise = bool(x.get('norm_obs') or x.get('norm_reward'))
         spec = env.spec
         self.N, self.obs_dim, self.act_dim = env.num_envs, spec.obs_dim, spec.nu
         rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
@@ -450,7 +498,7 @@ class SAC:
         self.high = torch.as_tensor(spec.action_space.high, dtype=torch.float32, device=self.device)
         self.agent = SACAgent(self.obs_dim, self.act_dim, self.low, self.high, cfg, self.device)
         self.buffer = DeviceReplay(cfg.max_buffer_size, self.obs_dim, self.act_dim, self.device)
-        self.obs = env.reset_tensors().clone()
+        self.obs = self.obs_normalizer(env.reset_tensors()).clone()         # sac.py:103-104
         self.total_steps = 0
         self._since_update = 0
 
@@ -465,10 +513,19 @@ class SAC:
         done = out.done.bool()
         trunc = (out.flags & 1).bool() & done
         # time truncation is not termination: the stored next state is the terminal observation, mask 1 (sac.py:287-305)
-        next_obs = torch.where(trunc[:, None], out.terminal_obs, out.obs)
+        if self._normalise:
+            # sac.py:281-297, in upstream's order: next_obs, then the reward (running returns, its index-array reset), then the
+            # terminal observations of the TRUNCATED envs only — each call updates the running statistics
+            self.obs_normalizer.unset_read_only()
+            obs_n = self.obs_normalizer(out.obs)
+            rew = self.reward_normalizer(out.reward, done)
+            term_n = self.obs_normalizer(out.terminal_obs, mask=trunc)
+        else:
+            obs_n, rew, term_n = out.obs, out.reward, out.terminal_obs
+        next_obs = torch.where(trunc[:, None], term_n, obs_n)
         mask = torch.where(trunc, torch.ones_like(out.reward), 1.0 - done.to(torch.float32))
-        self.buffer.push(self.obs, act, out.reward, next_obs, mask)
-        self.obs = out.obs.clone()
+        self.buffer.push(self.obs, act, rew, next_obs, mask)
+        self.obs = obs_n.clone()
         world = parallel.world_size()
         self.total_steps += self.N * world
         self._since_update += self.N * world
@@ -487,7 +544,13 @@ class SAC:
     def save(self, path, training=True, save_buffer=False):
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        state = {'agent': self.agent.state_dict()}
+        state = {'agent': self.agent.state_dict(), 'obs_normalizer': self.obs_normalizer.state_dict(),
+                 'reward_normalizer': self.reward_normalizer.state_dict()}            # sac.py:124-128
+        for name, nz in (('obs', self.obs_normalizer), ('reward', self.reward_normalizer)):
+            if hasattr(nz, 'rms'):              # (upstream's state dict drops the count: a resumed run would re-weight new batches)
+                state[f'{name}_normalizer_count'] = float(nz.rms.count)
+        if getattr(self.reward_normalizer, 'ret', None) is not None:
+            state['reward_normalizer_ret'] = self.reward_normalizer.ret.cpu()
         if training:
             state.update({'total_steps': self.total_steps, 'since_update': self._since_update, 'obs': self.obs.cpu(),
                           'random_state': {'torch': torch.get_rng_state(),
@@ -500,6 +563,13 @@ class SAC:
     def load(self, path, training=True):
         state = torch.load(path, map_location=self.device, weights_only=False)
         self.agent.load_state_dict(state['agent'], with_optimizers=training)
+        for name, nz in (('obs', self.obs_normalizer), ('reward', self.reward_normalizer)):         # sac.py:147-149
+            if state.get(f'{name}_normalizer') and hasattr(nz, 'rms'):
+                nz.load_state_dict(state[f'{name}_normalizer'])
+                if f'{name}_normalizer_count' in state:
+                    nz.rms.count.fill_(state[f'{name}_normalizer_count'])
+        if 'reward_normalizer_ret' in state and hasattr(self.reward_normalizer, 'rms'):
+            self.reward_normalizer.ret = state['reward_normalizer_ret'].to(self.device)
         if training and 'total_steps' in state:
             self.total_steps = int(state['total_steps'])
             self._since_update = int(state.get('since_update', 0))

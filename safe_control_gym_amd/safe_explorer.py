@@ -116,14 +116,14 @@ class SafeExplorerPPO(PPO):
         self.obs[0].copy_(self.obs_normalizer(env.reset_tensors()))
         self.c = self._reset_c(env.out)
 
-    def _reset_c(self, out):
-        return self.env.spec.state_constraint_values(out.state.t()).to(torch.float32)
+    def _reset_c(self, out, env=None):
+        return (env or self.env).spec.state_constraint_values(out.state.t()).to(torch.float32)
 
-    def _next_c(self, out):
+    def _next_c(self, out, env=None):
         """c of the NEXT policy step and c_next of THIS transition (terminal values where the episode ended)."""
         c_step = out.c_values[:self.C].t().to(torch.float32)
         done = out.done.bool()
-        c_now = torch.where(done[:, None], self._reset_c(out), c_step) if bool(self.env.auto_reset) else c_step
+        c_now = torch.where(done[:, None], self._reset_c(out, env), c_step) if bool((env or self.env).auto_reset) else c_step
         return c_now, c_step
 
     # ---- pre-training of the constraint models (safe_ppo.py:196-296, :425-449)
@@ -143,6 +143,87 @@ class SafeExplorerPPO(PPO):
             steps += self.N * parallel.world_size()
         self.obs[0].copy_(obs)
         self.c = c
+
+    def pretrain_step(self, steps_per_epoch, batch_size=None):
+        """One epoch of upstream's pre-training (safe_ppo.py:281-297): fresh random-action transitions, one pass of shuffled
+        minibatches over them, buffer cleared.  Returns the mean per-constraint losses."""
+        self.obs_normalizer.unset_read_only()
+        self.collect_constraint_data(steps_per_epoch)
+        bs = min(int(batch_size or self.constraint_batch_size), self.constraint_buffer.size)
+        acc, k = torch.zeros(self.C, device=self.device), 0
+        for batch in self.constraint_buffer.sampler(bs):
+            acc += self.safety_layer.update(batch)
+            k += 1
+        self.constraint_buffer.pos = self.constraint_buffer.size = 0
+        return (acc / max(k, 1)).tolist()
+
+    @torch.no_grad()
+    def eval_constraint_models(self, num_steps, batch_size=None):
+        """safe_ppo.py:451-466: mean per-constraint loss on freshly collected random-action data, statistics frozen, no update."""
+        frozen = self.obs_normalizer.read_only
+        self.obs_normalizer.set_read_only()
+        self.collect_constraint_data(num_steps)
+        self.obs_normalizer.read_only = frozen
+        bs = min(int(batch_size or self.constraint_batch_size), self.constraint_buffer.size)
+        acc, k = torch.zeros(self.C, device=self.device), 0
+        for batch in self.constraint_buffer.sampler(bs):
+            acc += self.safety_layer.compute_loss(batch)
+            k += 1
+        self.constraint_buffer.pos = self.constraint_buffer.size = 0
+        return (acc / max(k, 1)).tolist()
+
+    @torch.no_grad()
+    def evaluate(self, env, episodes_per_env=1):
+        """SafeExplorerPPO.run (safe_ppo.py:230-279) batched: the deterministic, safety-filtered policy on every env of `env` with
+        the constraint values of the current state as its second input; per-env totals of the first `episodes_per_env` episodes."""
+        N, dev = env.num_envs, env.device
+        acc = {k: torch.zeros(N, device=dev) for k in ('count', 'ret', 'length', 'viol', 'mse')}
+        nz = self.obs_normalizer
+        frozen = nz.read_only
+        nz.set_read_only()
+        obs = nz(env.reset_tensors())
+        c = self._reset_c(env.out, env)
+        for _ in range(env.spec.max_episode_steps * episodes_per_env):
+            out = env.step_tensors(self.agent.ac.act(obs, c))
+            df = (out.done.bool() & (acc['count'] < episodes_per_env)).to(torch.float32)
+            acc['ret'] += out.fin_return * df
+            acc['length'] += out.fin_length * df
+            acc['viol'] += out.fin_violation * df
+            acc['mse'] += out.fin_mse * df
+            acc['count'] += df
+            c, _ = self._next_c(out, env)
+            obs = nz(out.obs)
+        nz.read_only = frozen
+        return acc
+
+    # ---- checkpoints with upstream's keys (safe_ppo.py:146-176): agent, safety_layer, normalisers
+    def save(self, path, training=True):
+        super().save(path, training)
+        state = torch.load(path, map_location='cpu', weights_only=False)
+        state['safety_layer'] = self.safety_layer.state_dict()
+        if training:
+            state['c'] = self.c.cpu()
+        torch.save(state, path)
+
+    def load(self, path, training=True):
+        state = torch.load(path, map_location='cpu', weights_only=False)
+        super().load(path, training)
+        self.load_safety_layer(state)
+        if training and 'c' in state:
+            self.c = state['c'].to(self.device)
+
+    def load_safety_layer(self, state_or_path):
+        """The `pretrained` hand-over of the second phase (safe_ppo.py:96-100): only the safety layer of a checkpoint."""
+        import os
+        if isinstance(state_or_path, (str, os.PathLike)):
+            p = os.fspath(state_or_path)
+            if os.path.isdir(p):
+                p = os.path.join(p, 'model_latest.pt')
+            state_or_path = torch.load(p, map_location='cpu', weights_only=False)
+        sd = state_or_path['safety_layer']
+        self.safety_layer.constraint_models.load_state_dict(sd['constraint_models'])
+        for o, st in zip(self.safety_layer.optimizers, sd.get('optimizers', [])):
+            o.load_state_dict(st)
 
     def pretrain(self, num_steps, epochs=5):
         self.collect_constraint_data(num_steps)

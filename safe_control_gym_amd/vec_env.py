@@ -129,7 +129,9 @@ class StepTensors:
 
 class LazyInfoList(Sequence):
     """``info['n']``: behaves like the reference's tuple of per-env dicts
-    (dummy_vec_env.py:41) but copies the columnar device arrays to the host only on first access."""
+    (dummy_vec_env.py:41) but copies the columnar device arrays to the host only on first access.
+    It is a VIEW of the step's output buffers, which the next step() overwrites (all columns together, the step counter
+    included): read it — or index it once, which snapshots every column on the host — before stepping again."""
 
     def __init__(self, venv, out, is_reset):
         self._venv, self._out, self._is_reset, self._host = venv, out, is_reset, None
@@ -144,7 +146,8 @@ class LazyInfoList(Sequence):
             fin = o.fin_stats.cpu().numpy()
             h.update(fin_return=fin[:, 0], fin_length=fin[:, 1], fin_violation=fin[:, 2], fin_mse=fin[:, 3])
             h['c_values'] = o.c_values.t().cpu().numpy() if o.c_values is not None else None
-            h['step'] = self._venv.get_counters()[0]       # ctrl_step_counter of the running episodes (benchmark_env.py:466)
+            if not self._is_reset:      # ctrl_step_counter of the running episodes (benchmark_env.py:466); a reset's is 0 by definition
+                h['step'] = self._venv.get_counters()[0]
             self._host = h
         return self._host
 

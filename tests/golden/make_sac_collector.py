@@ -7,6 +7,9 @@ its policy's samples) and what its SACBuffer holds afterwards — obs, act, rew,
 (:287-305: a truncated episode stores the terminal observation with mask 1, a terminated one the post-reset observation with mask 0).
 
     python tests/golden/make_sac_collector.py       (build container only: needs /root/reference) -> sac_collector.npz
+    python tests/golden/make_sac_collector.py --norm    the same run with `norm_obs: True, norm_reward: True` (sac.py:75-81: the running
+        normalisers around env.step — next_obs, then the reward, then the truncated envs' terminal observations, each call updating the
+        statistics) -> sac_collector_norm.npz, which also holds the normalisers' state afterwards (mean / var / count, running returns)
 """
 import functools
 import os
@@ -26,11 +29,11 @@ import yaml  # noqa: E402
 OVER = dict(episode_len_sec=0.2, randomized_init=True, done_on_out_of_bound=True)
 
 
-def main():
+def main(norm=False):
     import safe_control_gym.controllers.sac.sac as mod
     cfg = yaml.safe_load(open(os.path.join(A.REF, 'safe_control_gym/controllers/sac/sac.yaml')))
     cfg.update(hidden_dim=16, rollout_batch_size=4, warm_up_steps=8, train_interval=10 ** 9, max_buffer_size=120, num_workers=1,
-               tensorboard=False, norm_obs=False, norm_reward=False)
+               tensorboard=False, norm_obs=norm, norm_reward=norm, clip_obs=4.0, clip_reward=2.0)
     tc = yaml.safe_load(open(os.path.join(A.REF, 'examples/rl/config_overrides/quadrotor_2D/quadrotor_2D_track.yaml')))['task_config']
     tc.update(OVER)
     tc.pop('seed', None)
@@ -39,8 +42,12 @@ def main():
         env_func = functools.partial(A.make, 'quadrotor', output_dir=tmp, **tc)
         torch.manual_seed(4)
         ctrl = mod.SAC(env_func, training=True, output_dir=tmp, use_gpu=False, seed=6, **cfg)
+        raw0 = []
+        reset0 = ctrl.env.reset
+        ctrl.env.reset = lambda *a, **k: (lambda r: (raw0.append(np.asarray(r[0], dtype=float).copy()), r)[1])(reset0(*a, **k))
         ctrl.reset()
-        out['obs0'] = np.asarray(ctrl.obs, dtype=float).copy()
+        ctrl.env.reset = reset0
+        out['obs0'] = raw0[0]                               # what env.reset returned (ctrl.obs is its normalised image under --norm)
         steps, T = [], 40
         env = ctrl.env
         orig = env.__class__.step
@@ -66,13 +73,19 @@ def main():
             out[f'buffer/{k}'] = np.asarray(b.__dict__[k], dtype=np.float64).copy()
         out['buffer/pos_size'] = np.array([b.pos, b.buffer_size])
         out['total_steps'] = np.array(ctrl.total_steps)
+        if norm:
+            o, r = ctrl.obs_normalizer, ctrl.reward_normalizer
+            out['norm/obs_mean'], out['norm/obs_var'], out['norm/obs_count'] = o.rms.mean.copy(), o.rms.var.copy(), np.array(o.rms.count)
+            out['norm/rew_var'], out['norm/rew_count'], out['norm/ret'] = np.array(r.rms.var), np.array(r.rms.count), r.ret.copy()
+            out['final_obs'] = np.asarray(ctrl.obs, dtype=float).copy()
     d, tr = out['transitions/done'], out['transitions/trunc']
     print('vector steps', T, 'dones', int(d.sum()), 'truncations', int(tr.sum()), 'terminations', int((d & ~tr).sum()),
           'buffer pos/size', out['buffer/pos_size'].tolist())
     assert tr.sum() > 0 and (d & ~tr).sum() > 0
-    np.savez_compressed(os.path.join(HERE, 'sac_collector.npz'), **out)
-    print('sac_collector.npz written,', len(out), 'arrays')
+    name = 'sac_collector_norm.npz' if norm else 'sac_collector.npz'
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, 'written,', len(out), 'arrays')
 
 
 if __name__ == '__main__':
-    main()
+    main(norm='--norm' in sys.argv[1:])

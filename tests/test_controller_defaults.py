@@ -9,7 +9,8 @@ import yaml
 from safe_control_gym_amd.registration import get_config, spec
 
 REF = '/root/reference/safe_control_gym/controllers'
-FILES = {'ppo': 'ppo/ppo.yaml', 'sac': 'sac/sac.yaml', 'rarl': 'rarl/rarl.yaml', 'rap': 'rarl/rap.yaml'}
+FILES = {'ppo': 'ppo/ppo.yaml', 'sac': 'sac/sac.yaml', 'rarl': 'rarl/rarl.yaml', 'rap': 'rarl/rap.yaml',
+         'safe_explorer_ppo': 'safe_explorer/safe_ppo.yaml'}
 
 
 @pytest.mark.parametrize('idx', sorted(FILES))
@@ -35,3 +36,5 @@ def test_pinned_defaults_without_the_reference():
     assert (p['hidden_dim'], p['activation'], p['opt_epochs'], p['mini_batch_size'], p['target_kl'], p['rollout_steps']) == (64, 'tanh', 10, 64, 0.01, 100)
     assert (s['hidden_dim'], s['activation'], s['tau'], s['train_interval'], s['warm_up_steps']) == (256, 'relu', 0.005, 100, 1000)
     assert get_config('rap')['num_adversaries'] == 2 and get_config('rarl')['agent_iterations'] == 10
+    e = get_config('safe_explorer_ppo')
+    assert (e['pretraining'], e['pretrained'], e['constraint_hidden_dim'], e['constraint_epochs'], e['constraint_slack']) == (True, None, 10, 25, None)

@@ -107,6 +107,31 @@ def test_make_vec_envs_dropin_and_the_train_step_protocol():
 
 
 @pytest.mark.gpu
+def test_grouped_envs_never_share_a_random_stream():
+    """Interleaved heterogeneous env_configs with randomized_init: every env of the batch must draw its own initial state (the groups
+    get disjoint global env ids), on reset and after auto-resets."""
+    from safe_control_gym_amd.record_episode_statistics import make_vec_envs
+    from safe_control_gym_amd.registration import load_task, make
+    env_id, cfg = load_task('quadrotor_2D_track')
+    env_func = functools.partial(make, env_id, output_dir='/tmp/scg', **dict(cfg, randomized_init=True, episode_len_sec=0.1))
+    per_env = [dict(episode_len_sec=0.1) if k % 3 == 0 else (dict(episode_len_sec=0.12) if k % 3 == 1 else dict(episode_len_sec=0.14))
+               for k in range(12)]
+    het = make_vec_envs(env_func, per_env, 12, 1, 7)
+    assert sorted(g.env_id_offset for g, _ in het.groups) == [0, 4, 8]
+    o, _ = het.reset()
+    assert len({tuple(np.round(r[:6], 9)) for r in o}) == 12, o[:, :6]
+    seen = [o[:, :6].copy()]
+    for t in range(8):                                                          # 5 / 6 / 7-step episodes: every env auto-resets at least once
+        o, r, d, info = het.step(np.zeros((12, 2)))
+        if d.any():
+            assert len({tuple(np.round(r_[:6], 9)) for r_ in o[d]}) == int(d.sum())       # fresh initial states: all distinct
+            seen.append(o[d][:, :6].copy())
+    allrows = np.concatenate(seen)
+    assert len({tuple(np.round(r_, 9)) for r_ in allrows}) == len(allrows)
+    het.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('algo', ['ppo', 'sac'])
 def test_reference_controllers_run_on_hipvecenv(algo):
     """The reference's own PPO / SAC classes through the binding (tools/run_reference_ppo_on_hip.py).  The reference's Python
@@ -174,9 +199,25 @@ def test_controller_ids_drive_training_like_train_rl_controller():
         assert torch.equal(again.env.get_raw_state_tensor(), sac.env.get_raw_state_tensor()) if hasattr(sac.env, 'get_raw_state_tensor') else True
         again.learn()
         assert again.total_steps == 256 * 10
-        with pytest.raises(NotImplementedError):
-            make('sac', env_func, training=True, output_dir=out, seed=1, hidden_dim=64, rollout_batch_size=64, norm_obs=True)
         sac.close(); again.close()
+        # norm_obs / norm_reward (sac.yaml:6-9, sac.py:75-81): the running normalisers around env.step, in the checkpoint like upstream
+        nsac = make('sac', env_func, training=True, output_dir=out, seed=1, hidden_dim=64, rollout_batch_size=64, norm_obs=True,
+                    norm_reward=True, clip_obs=5.0, warm_up_steps=128, train_interval=64, train_batch_size=64, max_env_steps=64 * 6,
+                    max_buffer_size=4096)
+        nsac.reset(); nsac.learn()
+        nz = nsac.impl.obs_normalizer
+        assert float(nz.rms.count) > 64 * 6 and float(nsac.impl.buffer.obs.abs().max()) <= 5.0 + 1e-6
+        assert float(nsac.impl.reward_normalizer.rms.count) > 64 * 5
+        nsac.save(os.path.join(out, 'nsac.pt'))
+        st = torch.load(os.path.join(out, 'nsac.pt'), weights_only=False)
+        assert set(st['obs_normalizer']) == {'mean', 'var'} and set(st['reward_normalizer']) == {'mean', 'var'}        # sac.py:124-128
+        ev = make('sac', env_func, training=False, output_dir=out, seed=1, hidden_dim=64, norm_obs=True, norm_reward=True, clip_obs=5.0)
+        ev.load(os.path.join(out, 'nsac.pt'))
+        torch.testing.assert_close(ev.impl.obs_normalizer.rms.mean, nz.rms.mean, rtol=0, atol=0)
+        c0 = float(ev.impl.obs_normalizer.rms.count)
+        assert ev.run(n_episodes=8)['ep_returns'].shape == (8,) and ev.select_action(np.zeros(12)).shape == (2,)
+        assert float(ev.impl.obs_normalizer.rms.count) == c0                    # evaluation never updates the statistics (sac.py:215)
+        nsac.close(); ev.close()
     adv_func = functools.partial(make, env_id, **dict(cfg, adversary_disturbance='dynamics', adversary_disturbance_scale=0.05))
     rap = make('rap', adv_func, seed=2, hidden_dim=32, use_gae=True, rollout_batch_size=256, rollout_steps=8, opt_epochs=1,
                mini_batch_size=512, max_env_steps=2 * 256 * 8, num_adversaries=3)
@@ -186,8 +227,6 @@ def test_controller_ids_drive_training_like_train_rl_controller():
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason='written after the GPU budget of round 3 was spent: verified on the oracle-backed handle of the CPU '
-                                        'suite (tests/test_facade_cpu.py), first run on the HIP handle pending — XPASS is the expected outcome')
 @pytest.mark.parametrize('args,key,expect', [(['lqr', '--algo', 'lqr'], 'FINAL METRICS', None),
                                              (['rl', '--algo', 'ppo', '--system', 'quadrotor_2D', '--task', 'track'], 'METRICS ', 230.0)],
                          ids=['lqr_experiment', 'rl_experiment_shipped_ppo_q2_track'])
@@ -211,8 +250,6 @@ def test_reference_example_scripts_on_the_hip_handle(args, key, expect):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason='written after the GPU budget of round 3 was spent: 36 / 36 on the oracle-backed handle of the CPU suite '
-                                        '(tests/test_facade_cpu.py), first run on the HIP handle pending — XPASS is the expected outcome')
 def test_reference_example_test_matrix_on_the_hip_handle():
     """tools/run_reference_example.py matrix WITHOUT --stub-handle: the reference's own test_lqr / test_rl / test_pid parametrisations
     (36 cases, its controllers and shipped checkpoints) on the facade over batch-of-1 HipVecEnv instances."""
@@ -225,3 +262,76 @@ def test_reference_example_test_matrix_on_the_hip_handle():
         pytest.skip('needs the staged reference checkout (tools/stage_reference.py)')
     res = subprocess.run([sys.executable, os.path.join(root, 'tools', 'run_reference_example.py'), 'matrix'], capture_output=True, text=True, timeout=240)
     assert res.returncode == 0 and 'MATRIX 36 passed of 36' in res.stdout, (res.stdout[-3000:], res.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_safe_explorer_ppo_controller_id_and_its_two_phases():
+    """controllers/__init__.py:41-43 registers 'safe_explorer_ppo'; safe_ppo.py:93-100,178-213: `pretraining: True` -> learn() runs
+    `constraint_epochs` pre-training epochs on random-action transitions and the checkpoint carries 'safety_layer'; `pretraining:
+    False` -> reset() loads the safety layer from `pretrained` (a file or a directory with model_latest.pt; missing -> upstream's
+    assertion) and learn() is PPO with the safety-filtered policy, whose second input is the current constraint values."""
+    torch = pytest.importorskip('torch')
+    import tempfile
+    from safe_control_gym_amd.registration import get_config, load_task, make
+    env_id, cfg = load_task('quadrotor_2D_track')
+    env_func = functools.partial(make, env_id, output_dir='/tmp/scg', seed=1337, **cfg)
+    d = get_config('safe_explorer_ppo')
+    assert d['pretraining'] is True and d['pretrained'] is None and d['constraint_epochs'] == 25
+    slack = [0.05, 0.05, 0.05, 0.05, 0.01, 0.01] * 2                    # safe_explorer_ppo_quadrotor_2D*.yaml
+    common = dict(hidden_dim=32, use_gae=True, rollout_batch_size=256, rollout_steps=8, opt_epochs=1, mini_batch_size=512,
+                  constraint_hidden_dim=16, constraint_slack=slack, constraint_batch_size=256)
+    with tempfile.TemporaryDirectory() as out:
+        pre = make('safe_explorer_ppo', env_func, training=True, checkpoint_path=os.path.join(out, 'pre', 'model_latest.pt'),
+                   output_dir=os.path.join(out, 'pre'), seed=2, pretraining=True, constraint_steps_per_epoch=256 * 12, constraint_epochs=4,
+                   constraint_eval_steps=256 * 4, eval_interval=2, log_interval=1, **common)
+        assert pre.num_constraints == 12
+        pre.reset()
+        hist = pre.learn()
+        assert pre.total_steps == 4 and len(hist) == 4 and pre.impl.total_steps == 0            # epochs, not env steps (safe_ppo.py:180-182)
+        first, last = (np.mean([h[f'constraint_{i}_loss'] for i in range(12)]) for h in (hist[0], hist[-1]))
+        assert last < first
+        st = torch.load(os.path.join(out, 'pre', 'model_latest.pt'), weights_only=False)
+        assert {'agent', 'safety_layer', 'obs_normalizer', 'reward_normalizer'} <= set(st)
+        assert set(st['safety_layer']) == {'constraint_models', 'optimizers'} and '11.fcs.1.weight' in st['safety_layer']['constraint_models']
+        trained = {k: v.clone() for k, v in pre.safety_layer.constraint_models.state_dict().items()}
+        pre.close()
+        with pytest.raises(AssertionError):                                                  # second phase without `pretrained`
+            c = make('safe_explorer_ppo', env_func, training=True, output_dir=out, seed=2, pretraining=False, **common)
+            c.reset()
+        c.close()
+        ctrl = make('safe_explorer_ppo', env_func, training=True, checkpoint_path=os.path.join(out, 'model_latest.pt'), output_dir=out, seed=2,
+                    pretraining=False, pretrained=os.path.join(out, 'pre'), max_env_steps=3 * 256 * 8, log_interval=256 * 8, **common)
+        ctrl.reset()                                                                        # loads <pretrained>/model_latest.pt
+        for k, v in ctrl.safety_layer.constraint_models.state_dict().items():
+            assert torch.equal(v, trained[k]), k
+        hist = ctrl.learn()
+        assert ctrl.total_steps == 3 * 256 * 8 and len(hist) == 3
+        for k, v in ctrl.safety_layer.constraint_models.state_dict().items():               # PPO moves the policy, never the layer
+            assert torch.equal(v, trained[k]), k
+        res = ctrl.run(n_episodes=8)
+        assert res['ep_returns'].shape == (8,) and (res['ep_lengths'] > 0).all()
+        obs, info = np.zeros(12), {'constraint_values': np.full(16, -0.5)}                   # (state + input rows: the first 12 are used)
+        assert ctrl.select_action(obs, info).shape == (2,)
+        ctrl.close()
+    # the reference's SHIPPED pre-trained safety layer (examples/rl/models/safe_explorer_ppo/*_pretrain_*.pt, what train_rl_model.sh
+    # hands to the second phase) loads through `pretrained`, and the shipped second-phase model through load()
+    from tests.golden.ref_stubs import reference_root
+    ref = reference_root()
+    if ref is None:
+        pytest.skip('first part passed; the shipped checkpoints need the staged reference copy (tools/stage_reference.py)')
+    models = os.path.join(ref, 'examples', 'rl', 'models', 'safe_explorer_ppo')
+    ship = dict(common, hidden_dim=128, constraint_hidden_dim=150)
+    c = make('safe_explorer_ppo', env_func, training=True, output_dir='/tmp/scg', seed=2, pretraining=False,
+             pretrained=os.path.join(models, 'safe_explorer_ppo_pretrain_quadrotor_2D_track.pt'), **ship)
+    c.reset()
+    sd0 = torch.load(os.path.join(models, 'safe_explorer_ppo_pretrain_quadrotor_2D_track.pt'), weights_only=False, map_location='cpu')
+    for k, v in c.safety_layer.constraint_models.state_dict().items():
+        assert torch.equal(v.cpu(), sd0['safety_layer']['constraint_models'][k]), k
+    c.close()
+    t = make('safe_explorer_ppo', env_func, training=False, output_dir='/tmp/scg', seed=2, pretraining=False, **ship)
+    t.load(os.path.join(models, 'safe_explorer_ppo_model_quadrotor_2D_track.pt'))
+    res = t.run(n_episodes=16)
+    # the shipped safety-filtered policy flies the figure-8: full-length episodes with a high return (the reference's own harness
+    # scores this checkpoint on this facade in tools/run_reference_example.py matrix)
+    assert res['ep_lengths'].mean() > 200 and res['ep_returns'].mean() > 150, res
+    t.close()

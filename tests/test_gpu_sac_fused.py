@@ -242,3 +242,48 @@ def test_fused_update_reproduces_the_reference_sac_agent_in_the_corners(name):
             if k in final:
                 torch.testing.assert_close(v.cpu(), final[k], rtol=2e-4, atol=1e-5, msg=lambda m, k=k: f'{prefix} {k}: {m}')
     np.testing.assert_allclose(float(ag.log_alpha.detach()), float(V[p + '/final_log_alpha']), rtol=1e-5)
+
+
+def test_adam_state_travels_between_the_fused_and_the_torch_layout():
+    """Checkpoints carry the Adam moments in torch.optim's per-parameter layout whichever update produced them: a fused agent's
+    checkpoint resumes in an agent that steps torch.optim (and in the reference's SACAgent, sac_utils.py:85-108), and torch-only
+    checkpoints — the reference's own training checkpoints — resume in the fused update (scattered into the flat m / v / steps)."""
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    low, high = -torch.ones(2, device=dev), torch.ones(2, device=dev)
+    kw = dict(hidden_dim=64, activation='relu', use_entropy_tuning=True, actor_lr=1e-3, critic_lr=2e-3, entropy_lr=1e-3)
+    torch.manual_seed(4)
+    fused = SACAgent(6, 2, low, high, SACConfig(**kw), dev)
+    buf = DeviceReplay(4096, 6, 2, dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)                     # noqa: E731
+    buf.push(r(4096, 6), torch.tanh(r(4096, 2)), r(4096), r(4096, 6), (torch.rand(4096, device=dev, generator=g) > 0.05).float())
+    fused.update_from_buffer(buf, 256, 5)
+    torch.cuda.synchronize()
+    sd_f = fused.state_dict()
+    assert set(sd_f['flat_adam']) == {'counter'} and len(sd_f['actor_opt']['state']) == 8 and len(sd_f['critic_opt']['state']) == 12
+    # (1) -> an agent that steps torch.optim: per-parameter moments == the flat ones, step counts carried
+    eager = SACAgent(6, 2, low, high, SACConfig(**kw, extra={'cuda_graphs': False}), dev)
+    eager.load_state_dict(sd_f)
+    fl = fused._flat
+    for opt_f, opt_e in ((fused.actor_opt, eager.actor_opt), (fused.critic_opt, eager.critic_opt), (fused.alpha_opt, eager.alpha_opt)):
+        for pf, pe in zip(opt_f.param_groups[0]['params'], opt_e.param_groups[0]['params']):
+            o, k = fused._flat_offset(pf), pf.numel()
+            assert torch.equal(opt_e.state[pe]['exp_avg'].reshape(-1), fl['m'][o:o + k])
+            assert torch.equal(opt_e.state[pe]['exp_avg_sq'].reshape(-1), fl['v'][o:o + k])
+            assert float(opt_e.state[pe]['step']) == 5.0
+            assert torch.equal(pe.data, pf.data)
+    # (2) torch-only checkpoint (what the reference / a non-fused agent saves) -> the fused update's flat buffers
+    sd_e = eager.state_dict()
+    assert 'flat_adam' not in sd_e
+    again = SACAgent(6, 2, low, high, SACConfig(**kw), dev)
+    again.load_state_dict(sd_e)
+    assert again.use_fused and again._flat['steps'].tolist() == [5.0, 5.0, 5.0]
+    n = fl['n']
+    assert torch.equal(again._flat['m'][:n + 1], fl['m'][:n + 1]) and torch.equal(again._flat['v'][:n + 1], fl['v'][:n + 1])
+    assert torch.equal(again._flat['p'], fl['p']) and torch.equal(again._flat['targ'], fl['targ'])
+    # ... and it continues exactly where the first agent continues (same sampling counter once that is carried too)
+    again._flat['counter'].copy_(fl['counter'])
+    fused.update_from_buffer(buf, 256, 3); again.update_from_buffer(buf, 256, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(again._flat['p'], fused._flat['p'])

@@ -7,13 +7,15 @@ import pytest
 import torch
 
 from safe_control_gym_amd.ppo import episode_metrics
+from tests.devices import DEVICES
 
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'metrics.npz'))
 
 
+@pytest.mark.parametrize('device', DEVICES)
 @pytest.mark.parametrize('case', ['one', 'three', 'many'])
-def test_episode_metrics_reproduce_metric_extractor(case):
-    tot = torch.as_tensor(G[f'{case}/totals'])
+def test_episode_metrics_reproduce_metric_extractor(case, device):
+    tot = torch.as_tensor(G[f'{case}/totals'], device=device)
     got = episode_metrics(tot[:, 0], tot[:, 1], tot[:, 2], tot[:, 3])
     for k, ref in zip(G['keys'], G[f'{case}/metrics']):
         np.testing.assert_allclose(got[str(k)], ref, rtol=1e-12, atol=1e-14, err_msg=str(k))

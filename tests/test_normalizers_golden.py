@@ -9,14 +9,18 @@ import numpy as np
 import pytest
 
 torch = pytest.importorskip('torch')
+
+from tests.devices import DEVICES  # noqa: E402
 G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'normalizers.npz'))
 TOL = dict(rtol=1e-12, atol=1e-12)
 
 
-def _run(mod, as_in, as_np):
+def _run(mod, as_in, as_np, device='cpu'):
     D = G['obs'].shape[2]
-    o = mod.MeanStdNormalizer(shape=(D,), clip=2.5) if mod.__name__.startswith('oracle') else mod.MeanStdNormalizer((D,), clip=2.5)
-    r = mod.RewardStdNormalizer(gamma=0.97, clip=3.0)
+    if mod.__name__.startswith('oracle'):
+        o, r = mod.MeanStdNormalizer(shape=(D,), clip=2.5), mod.RewardStdNormalizer(gamma=0.97, clip=3.0)
+    else:
+        o, r = mod.MeanStdNormalizer((D,), device, clip=2.5), mod.RewardStdNormalizer(0.97, device, clip=3.0)
     for t in range(G['obs'].shape[0]):
         if t == 30:
             o.set_read_only(); r.set_read_only()
@@ -30,9 +34,10 @@ def _run(mod, as_in, as_np):
     return o
 
 
-def test_device_normalizers_reproduce_the_reference():
+@pytest.mark.parametrize('device', DEVICES)
+def test_device_normalizers_reproduce_the_reference(device):
     from safe_control_gym_amd import normalization as dev
-    o = _run(dev, torch.as_tensor, lambda t: t.numpy() if torch.is_tensor(t) else np.asarray(t))
+    o = _run(dev, lambda a: torch.as_tensor(a, device=device), lambda t: t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t), device)
     sd = o.state_dict()
     np.testing.assert_allclose(sd['mean'], G['sd_mean'], **TOL)
     np.testing.assert_allclose(sd['var'], G['sd_var'], **TOL)

@@ -5,11 +5,13 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from safe_control_gym_amd import parallel
+from tests.devices import DEVICES
 from safe_control_gym_amd.ppo import (MLPActorCritic, PPOAgent, PPOConfig, normal_entropy, normal_log_prob,
                                       policy_loss_terms, value_loss_term)
 
@@ -258,14 +260,16 @@ def test_normaliser_statistics_are_global_across_ranks(tmp_path):
     torch.testing.assert_close(got['count'], nz.rms.count, rtol=0, atol=0)
 
 
-def test_ppo_collector_reproduces_the_reference_rollout_buffer():
+@pytest.mark.parametrize('device', DEVICES)
+def test_ppo_collector_reproduces_the_reference_rollout_buffer(device):
     """ppo.PPO's collector against the REFERENCE's own `PPO.train_step` (controllers/ppo/ppo.py:259-303; tests/golden/
     make_ppo_collector.py): the recorded transitions of 4 envs x 30 steps (8 time-limit truncations, 12 terminations) are replayed
     (tests/replay_env.py) with the actions the reference sampled, from the reference's initial weights, and the rollout must equal the
     PPOBuffer the reference hands to PPOAgent.update — obs, act, mask, v, logp, terminal_v = the critic's value of the TERMINAL
     observation where truncated (0 elsewhere), reward with gamma * terminal_v folded in, returns, batch-normalised advantages.
-    CPU: the eager collector; returns / advantages through the oracle's statement of compute_returns_and_advantages in place of the
-    scg_gae kernel (which tests/test_gpu_gae.py holds to that same statement)."""
+    cpu: the eager collector; returns / advantages through the oracle's statement of compute_returns_and_advantages in place of the
+    scg_gae kernel (which tests/test_gpu_gae.py holds to that same statement).  cuda: device tensors end to end and the scg_gae
+    KERNEL itself produces the returns / advantages that are compared with the reference's buffer."""
     import os
 
     import numpy as np
@@ -275,7 +279,7 @@ def test_ppo_collector_reproduces_the_reference_rollout_buffer():
     from tests.replay_env import ReplayVecEnv, forced_step, spec_for
     G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ppo_collector.npz'))
     tr = {k: G[f'transitions/{k}'] for k in ('act', 'next_obs', 'rew', 'done', 'trunc', 'term_obs')}
-    env = ReplayVecEnv(spec_for(dict(episode_len_sec=0.2, randomized_init=True, done_on_out_of_bound=True)), 'cpu', G['obs0'],
+    env = ReplayVecEnv(spec_for(dict(episode_len_sec=0.2, randomized_init=True, done_on_out_of_bound=True)), device, G['obs0'],
                        tr['next_obs'], tr['rew'], tr['done'], tr['trunc'], tr['term_obs'])
     gam, lam = (float(x) for x in G['gamma_lambda'])
     cfg = PPOConfig(hidden_dim=16, activation='tanh', use_gae=True, gamma=gam, gae_lambda=lam, rollout_batch_size=4, rollout_steps=30,
@@ -283,7 +287,7 @@ def test_ppo_collector_reproduces_the_reference_rollout_buffer():
     ppo = PPO(env, cfg, seed=0)
     assert not ppo._fused_rollout and not ppo._graph_rollout
     ppo.agent.ac.load_state_dict({k[5:]: torch.as_tensor(G[k]) for k in G.files if k.startswith('init/')})
-    acts = torch.as_tensor(tr['act'], dtype=torch.float32)
+    acts = torch.as_tensor(tr['act'], dtype=torch.float32, device=device)
     ppo.agent.ac.step = forced_step(ppo.agent.ac, ppo.obs, acts)
 
     def cpu_gae(rew, v, mask, terminal_v, last_v, gamma, lam_, use_gae, out=None):
@@ -292,12 +296,14 @@ def test_ppo_collector_reproduces_the_reference_rollout_buffer():
                                                   terminal_v.double().numpy()[..., None], last_v.double().numpy()[..., None], gamma, use_gae, lam_)
         rew.copy_(torch.as_tensor(r[..., 0] + gamma * terminal_v.double().numpy(), dtype=rew.dtype))      # in place, like the kernel / ppo_utils.py:389
         return torch.as_tensor(ret[..., 0], dtype=rew.dtype), torch.as_tensor(adv[..., 0], dtype=rew.dtype)
-    ppo._gae = cpu_gae
+    if device == 'cpu':
+        ppo._gae = cpu_gae
     ppo.collect()
     ret, adv, mom = ppo._returns_body(dense=False)
     assert ppo.total_steps == int(G['total_steps'])
     torch.testing.assert_close(env.seen_act, acts, rtol=0, atol=0)
-    B = {k: torch.as_tensor(G[f'buffer/{k}'], dtype=torch.float32) for k in ('obs', 'act', 'rew', 'mask', 'v', 'logp', 'terminal_v', 'ret', 'adv')}
+    B = {k: torch.as_tensor(G[f'buffer/{k}'], dtype=torch.float32, device=device)
+         for k in ('obs', 'act', 'rew', 'mask', 'v', 'logp', 'terminal_v', 'ret', 'adv')}
     torch.testing.assert_close(ppo.obs[:ppo.T], B['obs'], rtol=0, atol=1e-6)
     torch.testing.assert_close(ppo.act, B['act'], rtol=0, atol=1e-6)
     torch.testing.assert_close(1.0 - ppo.done.float(), B['mask'][..., 0], rtol=0, atol=0)

@@ -1,9 +1,11 @@
 """CPU tests of the SAC learner pieces against direct statements of sac_utils.py."""
 import math
 
+import pytest
 import torch
 
 from safe_control_gym_amd.sac import DeviceReplay, MLPActorCritic, SACAgent, SACConfig
+from tests.devices import DEVICES
 
 
 def test_tanh_gaussian_logprob_matches_change_of_variables():
@@ -158,25 +160,34 @@ def test_data_parallel_sac_update_matches_single_process(tmp_path):
     torch.testing.assert_close(got[0], ref, rtol=1e-4, atol=1e-5)
 
 
-def test_sac_collector_reproduces_the_reference_buffer():
+@pytest.mark.parametrize('device', DEVICES)
+@pytest.mark.parametrize('norm', [False, True], ids=['plain', 'normalised'])
+def test_sac_collector_reproduces_the_reference_buffer(device, norm):
     """sac.SAC.train_step against the REFERENCE's own `SAC.train_step` (controllers/sac/sac.py:269-335; tests/golden/
     make_sac_collector.py): the recorded transitions of 4 envs x 40 vector steps are replayed (tests/replay_env.py) with the actions the
     reference fed, and the replay ring must hold what the reference's SACBuffer holds — obs, act, rew and the TRUE next_obs / mask of the
     time-limit fix-up (12 truncated episodes store their terminal observation with mask 1, 8 terminated ones the post-reset observation
-    with mask 0), in ring order after the wrap (160 pushes into 120 slots)."""
+    with mask 0), in ring order after the wrap (160 pushes into 120 slots).
+    normalised: the reference ran with `norm_obs: True, norm_reward: True` (sac.py:75-81) — the ring holds NORMALISED observations /
+    rewards (statistics updated by next_obs, then the reward's running returns with upstream's index-array reset, then the truncated
+    envs' terminal observations), and the normalisers' final mean / var / count / running returns equal the reference's.
+    cuda: the same on device tensors (the replay ring, the normalisers' float64 statistics and the masked update live in HBM)."""
     import os
 
     import numpy as np
     from safe_control_gym_amd.sac import SAC
     from tests.replay_env import ReplayVecEnv, spec_for
-    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sac_collector.npz'))
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sac_collector_norm.npz' if norm else 'sac_collector.npz'))
     tr = {k: G[f'transitions/{k}'] for k in ('act', 'next_obs', 'rew', 'done', 'trunc', 'term_obs')}
-    env = ReplayVecEnv(spec_for(dict(episode_len_sec=0.2, randomized_init=True, done_on_out_of_bound=True)), 'cpu', G['obs0'],
+    env = ReplayVecEnv(spec_for(dict(episode_len_sec=0.2, randomized_init=True, done_on_out_of_bound=True)), device, G['obs0'],
                        tr['next_obs'], tr['rew'], tr['done'], tr['trunc'], tr['term_obs'])
+    extra = {'cuda_graphs': False}
+    if norm:
+        extra.update(norm_obs=True, norm_reward=True, clip_obs=4.0, clip_reward=2.0)
     cfg = SACConfig(hidden_dim=16, activation='relu', rollout_batch_size=4, warm_up_steps=0, train_interval=10 ** 9, max_buffer_size=120,
-                    extra={'cuda_graphs': False})
+                    extra=extra)
     sac = SAC(env, cfg, seed=0)
-    acts = torch.as_tensor(tr['act'], dtype=torch.float32)
+    acts = torch.as_tensor(tr['act'], dtype=torch.float32, device=device)
     sac.agent.ac.act = lambda obs, deterministic=False: acts[env.t % env.T]      # the actions the reference fed (warm-up draws + its samples)
     for _ in range(acts.shape[0]):
         res = sac.train_step()
@@ -184,7 +195,18 @@ def test_sac_collector_reproduces_the_reference_buffer():
     assert sac.total_steps == int(G['total_steps']) and [sac.buffer.pos, sac.buffer.size] == G['buffer/pos_size'].tolist()
     torch.testing.assert_close(env.seen_act, acts, rtol=0, atol=0)
     for k in ('obs', 'act', 'rew', 'next_obs', 'mask'):
-        got = getattr(sac.buffer, k).numpy().reshape(G[f'buffer/{k}'].shape)
+        got = getattr(sac.buffer, k).cpu().numpy().reshape(G[f'buffer/{k}'].shape)
         np.testing.assert_allclose(got, G[f'buffer/{k}'], rtol=0, atol=1e-6, err_msg=k)
     m = G['buffer/mask'].reshape(-1)
     assert (m == 0).sum() > 0 and (tr['trunc'].sum() > 0)                       # the fixture holds both kinds of episode end
+    if norm:
+        o, r = sac.obs_normalizer, sac.reward_normalizer
+        kw = dict(rtol=5e-6, atol=1e-7)             # (the collector's observations / rewards are float32; the reference's were float64)
+        np.testing.assert_allclose(o.rms.mean.cpu().numpy(), G['norm/obs_mean'], **kw)
+        np.testing.assert_allclose(o.rms.var.cpu().numpy(), G['norm/obs_var'], **kw)
+        np.testing.assert_allclose(float(o.rms.count), float(G['norm/obs_count']), rtol=1e-12)
+        np.testing.assert_allclose(float(r.rms.var), float(G['norm/rew_var']), **kw)
+        np.testing.assert_allclose(float(r.rms.count), float(G['norm/rew_count']), rtol=1e-12)
+        np.testing.assert_allclose(r.ret.cpu().numpy(), G['norm/ret'], **kw)
+        np.testing.assert_allclose(sac.obs.cpu().numpy(), G['final_obs'], rtol=0, atol=1e-6)
+        assert np.abs(G['buffer/obs']).max() <= 4.0 + 1e-6 and np.abs(G['buffer/rew']).max() <= 2.0 + 1e-6
