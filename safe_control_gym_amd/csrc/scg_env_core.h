@@ -203,35 +203,49 @@ __device__ __forceinline__ void small_sinc_cos(T a2, T& sinc, T& ca) {
 // The host rejects configurations whose arrays exceed the 32-bit offsets (validate() in scg_kernels.hip).
 typedef unsigned int u32x2 __attribute__((vector_size(8)));
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
+// Cache policy of the simulator's buffer STORES (gfx942 / gfx950 `aux`: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).
+// SCG_ST_AUX = 17 (sc0 | sc1): write-through at system scope.  Each of the 8 XCDs has its own L2, so a kernel's dirty lines
+// have to leave for the memory side (Infinity Cache / HBM) before the next kernel — on another XCD — may read them: with the
+// default write-back policy that happens as ONE flush at the end of the kernel, behind the last store (65 536 envs,
+// Quadrotor2D: 11.5 MB, ~0.9 us of a 5.2 us launch with nothing left to overlap it); written through, every store starts its
+// trip when it is issued — the constraint rows at ~55 % of the wave's lifetime, the observation at ~65 % — under the remaining
+// arithmetic.  Measured (tools/sessions/s81.sh, same box, alternating runs): Quadrotor2D-track 5.24 -> 4.40 us per launch,
+// Quadrotor3D-track 9.85 -> 8.56 us.  Visibility is only ever EARLIER than with the default policy; values are untouched.
+#ifndef SCG_ST_AUX
+#define SCG_ST_AUX 17
+#endif
+#ifndef SCG_LD_AUX
+#define SCG_LD_AUX 0
+#endif
 __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, float) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v, s, SCG_LD_AUX));
 }
 __device__ __forceinline__ int32_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, int32_t) {
-    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0);
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, v, s, SCG_LD_AUX);
 }
 __device__ __forceinline__ uint32_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint32_t) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0);
+    return __builtin_amdgcn_raw_buffer_load_b32(r, v, s, SCG_LD_AUX);
 }
 __device__ __forceinline__ uint8_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint8_t) {
-    return __builtin_amdgcn_raw_buffer_load_b8(r, v, s, 0);
+    return __builtin_amdgcn_raw_buffer_load_b8(r, v, s, SCG_LD_AUX);
 }
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, double) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, v, s, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, v, s, SCG_LD_AUX));
 }
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, float x) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), r, v, s, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), r, v, s, SCG_ST_AUX);
 }
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, int32_t x) {
-    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)x, r, v, s, 0);
+    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)x, r, v, s, SCG_ST_AUX);
 }
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint32_t x) {
-    __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, SCG_ST_AUX);
 }
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint8_t x) {
-    __builtin_amdgcn_raw_buffer_store_b8(x, r, v, s, 0);
+    __builtin_amdgcn_raw_buffer_store_b8(x, r, v, s, SCG_ST_AUX);
 }
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, double x) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, v, s, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, v, s, SCG_ST_AUX);
 }
 
 // 16-byte store.  The uniform array offset goes through the VECTOR offset here (one v_add per row, the chunk constants
@@ -242,7 +256,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uin
 // s4 offen` + `v_mov_b32 v42, s6` tore 16-64 doubles out of 1.5 M on a cold first launch
 // (tests/test_gpu_parity_scale.py; tools/hazard_lint.py proves the pattern absent from every built library).
 __device__ __forceinline__ void buf_st128(u32x4 d, __amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t array_off, uint32_t k) {
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, lane_off + array_off + k, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, lane_off + array_off + k, 0, SCG_ST_AUX);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -280,7 +294,7 @@ struct Slot {
 #pragma unroll
             for (int j = 0; j < per; ++j) p.e[j] = x[c * per + j];
             if constexpr (W == 16) buf_st128(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * W));
-            else if constexpr (W == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p), r, off, soff + (uint32_t)(c * W), 0);
+            else if constexpr (W == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p), r, off, soff + (uint32_t)(c * W), SCG_ST_AUX);
             else buf_st(r, off, soff + (uint32_t)(c * W), p.e[0]);
         }
     }
@@ -301,8 +315,8 @@ struct Slot {
 #pragma unroll
         for (int c = 0; c < bytes / W; ++c) {
             Pack<per> p;
-            if constexpr (W == 16) p = __builtin_bit_cast(Pack<per>, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff + (uint32_t)(c * W), 0));
-            else if constexpr (W == 8) p = __builtin_bit_cast(Pack<per>, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff + (uint32_t)(c * W), 0));
+            if constexpr (W == 16) p = __builtin_bit_cast(Pack<per>, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff + (uint32_t)(c * W), SCG_LD_AUX));
+            else if constexpr (W == 8) p = __builtin_bit_cast(Pack<per>, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff + (uint32_t)(c * W), SCG_LD_AUX));
             else p.e[0] = buf_ld(r, off, soff + (uint32_t)(c * W), U());
 #pragma unroll
             for (int j = 0; j < per; ++j) x[c * per + j] = p.e[j];
