@@ -38,7 +38,12 @@ ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'qua
 KERNEL_NAME = {'quadrotor_2D_track': 'step_kernel<QUAD_2D,float>', 'cartpole_stab': 'step_kernel<CARTPOLE,float>',
                'quadrotor_3D_track': 'step_kernel<QUAD_3D,float>', 'quadrotor_3D_track_disturbed': 'step_kernel<QUAD_3D,float,DIST>'}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-TRAFFIC_FILES = ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json')
+# HBM traffic / executed-instruction counts come from committed rocprofv3 --pmc passes (tools/profile_round4.sh ->
+# tools/profile_post.py).  They describe ONE build of the kernels: the file carries the hash of the kernel sources it was measured
+# on, and a line printed from other sources drops the number (traffic: null, with the reason) instead of quoting a stale one.
+TRAFFIC_FILE = 'r04_hbm_traffic.json'
+SEQ_K, SEQ_K_ALL = 32, 8        # control steps per launch of the two scg_step_sequence workloads (sequence_leg, tools/seq_profile.py)
+SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
 
 
 def parse():
@@ -134,18 +139,46 @@ def cpu_baseline(task, cfg, env_id, budget_s, n_envs):
                       f'i7-1068NG7): 381-464 env-steps/s'}
 
 
+_PMC_CACHE = {}
+
+
+def pmc_entry(key):
+    """Entry `key` of profiles/r04_hbm_traffic.json if that file was measured on THESE kernel sources, else (None, why)."""
+    if 'file' not in _PMC_CACHE:
+        try:
+            with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
+                _PMC_CACHE['file'] = json.load(f)
+        except (OSError, ValueError):
+            _PMC_CACHE['file'] = None
+    d = _PMC_CACHE['file']
+    if d is None:
+        return None, f'profiles/{TRAFFIC_FILE} not present'
+    from safe_control_gym_amd import _lib
+    have, want = d.get('_meta', {}).get('source_hash'), f'0x{_lib.source_hash():016x}'
+    if have != want:
+        return None, f'profiles/{TRAFFIC_FILE} was measured on kernel sources {have}, this tree is {want}: dropped'
+    e = d.get(key)
+    return (e, f'profiles/{TRAFFIC_FILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, per launch; kernel sources {want})') if e \
+        else (None, f'profiles/{TRAFFIC_FILE} has no entry {key}')
+
+
 def traffic_of(task, dtype, n):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this very command (separate FETCH_SIZE / WRITE_SIZE
-    passes, gfx950 x2 fetch correction — tools/profile_round.sh, tools/profile_post.py)."""
-    for name in TRAFFIC_FILES:
-        try:
-            with open(os.path.join(ROOT, 'profiles', name)) as f:
-                t = json.load(f).get(f'{task}/{dtype}/{n}', {}).get('traffic_bytes_per_launch')
-            if t:
-                return t, f'profiles/{name} (rocprofv3 --pmc, bytes per launch)'
-        except OSError:
-            pass
-    return None, None
+    passes, gfx950 x2 fetch correction — tools/profile_round4.sh, tools/profile_post.py)."""
+    e, src = pmc_entry(f'{task}/{dtype}/{n}')
+    return (e['traffic_bytes_per_launch'] if e else None), src
+
+
+def valu_issue_of(task, dtype, n, period_us):
+    """Fraction of the launch period the busiest SIMD spends ISSUING vector instructions: executed VALU instructions per wave
+    (SQ_INSTS_VALU / SQ_WAVES of the same PMC passes) x waves per SIMD x 4 clocks (a wave64 instruction occupies the SIMD's 16
+    lanes for 4 cycles) / 2.4 GHz.  The bound that matters where the kernel sits on the f32 ridge (CartPole: 50 engine substeps)."""
+    e, _ = pmc_entry(f'{task}/{dtype}/{n}')
+    if not e or not e.get('valu_instructions_per_wave'):
+        return None
+    waves_per_simd = -(-(n // 64) // 1024)              # 256 CUs x 4 SIMDs
+    issue_us = e['valu_instructions_per_wave'] * waves_per_simd * 4 / (SHADER_CLOCK_GHZ * 1e3)
+    return {'valu_instructions_per_wave': e['valu_instructions_per_wave'], 'issue_us': issue_us, 'frac': issue_us / period_us}
 
 
 class StepBench:
@@ -217,7 +250,8 @@ def roofline_of(task, dtype_name, n, period_us):
     traffic, src = traffic_of(task, dtype_name, n)
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic, 'traffic_source': src,
-            'kernel': KERNEL_NAME.get(task, 'step_kernel'), 'avg_launch_us': period_us, 'algorithmic_bytes_per_env_step': algo}
+            'kernel': KERNEL_NAME.get(task, 'step_kernel'), 'avg_launch_us': period_us, 'algorithmic_bytes_per_env_step': algo,
+            'valu_issue': valu_issue_of(task, dtype_name, n, period_us)}
 
 
 def secondary_env_kernels(torch, n):
@@ -230,7 +264,7 @@ def secondary_env_kernels(torch, n):
             us = b.kernel_period_us(3000)
             r = roofline_of(task, 'f32', n, us)
             e = {'avg_launch_us': us, 'env_steps_per_s': n / (us * 1e-6), 'frac': r['frac'], 'algorithmic_bytes_per_env_step': r['algorithmic_bytes_per_env_step'],
-                 'traffic': r['traffic'], 'kernel_build': 'config-specialised' if b.env.specialized else 'generic', 'finite_outputs': b.sane()}
+                 'traffic': r['traffic'], 'valu_issue': r['valu_issue'], 'kernel_build': 'config-specialised' if b.env.specialized else 'generic', 'finite_outputs': b.sane()}
             if task == 'cartpole_stab':         # BASELINE config #2: in-kernel random actions, K steps per launch
                 K = 1000
                 b.env.rollout_random(K)
@@ -274,7 +308,7 @@ def gae_leg(torch):
     return out
 
 
-def sequence_leg(torch, n, K=32, task='quadrotor_2D_track', K_all=8):
+def sequence_leg(torch, n, K=SEQ_K, task='quadrotor_2D_track', K_all=SEQ_K_ALL):
     """The same control steps with K of them per launch (scg_step_sequence): caller-supplied action sequences resident in
     HBM, per-step outputs written to [K]-stacked arrays, state in registers between steps.  Two output sets: what a PPO-style
     collector keeps (obs, reward, done, flags; terminal observation where done) and every output of scg_step (+ mse,
@@ -315,6 +349,11 @@ def sequence_leg(torch, n, K=32, task='quadrotor_2D_track', K_all=8):
                     'frac': rate * bytes_es / 1e9 / HBM_PEAK_GBS,
                     'frac_on_per_step_bytes': rate * ALGO_BYTES_PER_ENV_STEP.get(task, 0) / 1e9 / HBM_PEAK_GBS,
                     'finite_outputs': bool(torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all())}
+        pm, src = pmc_entry(f'sequence_{tag.split("_")[0]}/f32/{n}')           # step_sequence_kernel under rocprofv3 (tools/seq_profile.py)
+        res[tag]['traffic'] = pm['traffic_bytes_per_launch'] if pm else None
+        res[tag]['traffic_bytes_per_env_step'] = pm['traffic_bytes_per_launch'] / (n * K) if pm else None
+        res[tag]['rocprof_avg_launch_us'] = pm.get('rocprof_avg_launch_us') if pm else None
+        res[tag]['traffic_source'] = src
         del out
     env.close()
     res['note'] = ('parity: tests/test_gpu_sequence.py (bit-identical to K x scg_step); the headline above stays one launch per control '
@@ -343,8 +382,12 @@ def fused_rollout_leg(torch, n, T=32):
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / reps
     env.close()
+    pm, src = pmc_entry(f'rollout_policy/f32/{n}')             # rollout_policy_kernel under rocprofv3 (tools/seq_profile.py)
     return {'envs': n, 'rollout_steps': T, 'ms_per_rollout': 1e3 * el, 'env_steps_per_s': n * T / el,
-            'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments'}
+            'what': 'scg_rollout_policy (actor in the loop) + two batched critic passes + scg_gae + advantage moments',
+            'rollout_policy_kernel': {'traffic': pm['traffic_bytes_per_launch'] if pm else None,
+                                      'traffic_bytes_per_env_step': pm['traffic_bytes_per_launch'] / (n * T) if pm else None,
+                                      'rocprof_avg_launch_us': pm.get('rocprof_avg_launch_us') if pm else None, 'traffic_source': src}}
 
 
 # Evaluation protocol of the learning legs (round 3).  The deterministic policy is scored on `EVAL_ENVS` DISTINCT episodes, one per
@@ -387,7 +430,7 @@ def shipped_ppo_score(torch, eval_env, tag='quadrotor_2D_track', hidden=128, act
 
 
 def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=None, lr=2e-3, target_kl=0.03, epochs=None, rollout_steps=32,
-            target=None):
+            target=None, mb_per_epoch=None):
     """PPO wall-clock until the deterministic-policy evaluation reaches the reference reward on BASELINE config #3's batch
     (65 536 envs per GPU): fused rollout, fused MFMA update; every iteration's weights are evaluated on a second stream
     (EVAL_ENVS distinct randomised-init episodes, fused deterministic rollout) while training goes on.  Target = the shipped
@@ -424,7 +467,8 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
         eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=seed * 111, return_numpy=False, policy=pol, **ev_cfg)
         pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=target_kl,
                          entropy_coef=0.01, opt_epochs=epochs, mini_batch_size=minibatch, actor_lr=lr, critic_lr=lr,
-                         rollout_batch_size=envs, rollout_steps=rollout_steps)
+                         rollout_batch_size=envs, rollout_steps=rollout_steps,
+                         extra={'minibatches_per_epoch': mb_per_epoch} if mb_per_epoch else {})
         ppo = PPO(env, pcfg, seed=seed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -467,7 +511,9 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
             'last_eval_return': final, 'reached': len(ok1), 'reached_two_consecutive': len(ok2),
             'median_first_hit_s': statistics.median(ok1) if ok1 else None, 'median_two_consecutive_s': statistics.median(ok2) if ok2 else None,
             'median_s': statistics.median(ok2) if ok2 else None, 'budget_s_per_seed': budget_s,
-            'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {envs * rollout_steps // minibatch} minibatches of {minibatch}, lr {lr:g}, '
+            'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {min(envs * rollout_steps // minibatch, mb_per_epoch or 10 ** 9)} minibatches of {minibatch}'
+                     + (f' (PARTIAL epochs: {mb_per_epoch} of the {envs * rollout_steps // minibatch} minibatches of each shuffled epoch)' if mb_per_epoch else '')
+                     + f', lr {lr:g}, '
                      f'target_kl {target_kl:g}, GAE 0.95, gamma 0.99, ent 0.01',
             'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA); every iteration\'s weights evaluated by the fused '
                     'deterministic rollout on a second stream'}
@@ -705,6 +751,7 @@ def main():
             out['f64'] = {'avg_launch_us': us, 'ms_per_step': us * 1e-3, 'env_steps_per_s': N / (us * 1e-6),
                           'note': 'same workload on the float64 kernels (the reference computes in float64); bytes per env-step double, '
                                   'algorithmic 2 x 187 - 10 = 364 B', 'frac': (364 * N / (us * 1e-6)) / 1e9 / HBM_PEAK_GBS,
+                          'traffic': traffic_of(args.task, 'f64', N)[0], 'traffic_source': traffic_of(args.task, 'f64', N)[1],
                           'finite_outputs': fb.sane()}
             fb.env.close()
         except Exception as exc:                                    # noqa: BLE001

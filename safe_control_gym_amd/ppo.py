@@ -280,6 +280,13 @@ class PPOAgent:
         assert mb >= 32 and mb % 32 == 0, 'update() routes other minibatch sizes to the PyTorch path'     # 32-sample tiles
         n_mb = M // mb
         assert n_mb != 0, 'num_mini_batch is 0'
+        # extra['minibatches_per_epoch']: a PARTIAL epoch — the first k minibatches of the epoch's permutation (a uniform subsample of
+        # the rollout; upstream always walks the whole permutation, ppo_utils.py:358-371).  With 65 536 envs x 32 steps an iteration
+        # holds 2 M samples: the number of optimiser steps per iteration, not the number of samples seen, is what the KL-limited
+        # policy iteration needs, and the learner is the whole cost of the iteration (bench.py's PPO leg says which it uses).
+        cap = cfg.extra.get('minibatches_per_epoch')
+        if cap:
+            n_mb = max(1, min(n_mb, int(cap)))
         for k, v in data.items():
             assert v.dtype == torch.float32 and v.is_contiguous(), k
         if self._fused is None or self._fused['key'] != (M, mb):

@@ -21,10 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(script_args, extra_env, timeout=600):
+def _torchrun(script_args, extra_env, timeout=600, nproc=2):
     env = dict(os.environ, **extra_env)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port())] + script_args
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
@@ -130,6 +130,42 @@ def test_train_sac_two_ranks_stay_in_lock_step(tmp_path):
     torch.testing.assert_close(a['params'], b['params'], rtol=0, atol=0)
     torch.testing.assert_close(a['init_params'], b['init_params'], rtol=0, atol=0)
     assert (a['params'] - a['init_params']).abs().max() > 1e-4
+
+
+def test_bench_eight_ranks_on_one_gpu_headline_and_ppo_leg():
+    """The driver's 8-GPU command line (python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8) with EIGHT ranks
+    sharing this box's one GPU over gloo: launcher / port / barrier plumbing, eight env shards, the PPO leg's per-minibatch gradient
+    all-reduce, asynchronous evaluation per rank and rank 0's stop-flag broadcast, one JSON line from rank 0.  (No scaling number is
+    meaningful here — eight processes time-slice one device; `rccl_ranks: 0` says so in the line.)"""
+    out = _torchrun(['bench.py', '--gpus', '8', '--steps', '200', '--warmup', '50', '--envs', '16384', '--ppo-seeds', '1', '--ppo-seconds', '4',
+                     '--ppo-envs', '4096', '--sac-seeds', '0'], {'SCG_BENCH_BACKEND': 'gloo', 'SCG_BENCH_PPO_GLOO': '1'}, timeout=900, nproc=8)
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 8 and r['config']['parallelism'] == 'env-shard x8' and r['config']['rccl_ranks'] == 0 and 'watchdog' not in r
+    assert r['config']['finite_outputs'] is True and r['config']['envs_per_gpu'] == 16384
+    assert abs(r['value'] - 8 * 16384 * r['steps'] / (r['ms_per_step'] * 1e-3 * r['steps'])) <= 1e-6 * r['value']
+    p = r['ppo']
+    assert 'error' not in p, p
+    assert p['n_gpus'] == 8 and p['envs_per_gpu'] == 4096 and p['iterations'][0] >= 2 and p['best_eval_return'][0] > 0
+
+
+def test_train_ppo_eight_ranks_stay_in_lock_step(tmp_path):
+    """examples/train_ppo.py on eight ranks (BASELINE config #4's shape, one GPU shared, gloo): bit-identical weights on all eight
+    ranks after three iterations of reduced gradients, eight disjoint env_id_offset streams (pairwise different first observations)."""
+    base = str(tmp_path / 'final')
+    _torchrun(['examples/train_ppo.py', '--envs', '512', '--minibatch', '16384', '--rollout-steps', '32', '--max-env-steps',
+               str(3 * 8 * 512 * 32), '--max-seconds', '1e9', '--target-return', '1e9', '--eval-envs', '64', '--quiet',
+               '--save-final', base], {'SCG_DIST_BACKEND': 'gloo'}, timeout=900, nproc=8)
+    rs = [torch.load(f'{base}.rank{r}.pt') for r in range(8)]
+    assert len({r['iterations'] for r in rs}) == 1 and rs[0]['iterations'] >= 2
+    assert [r['env_id_offset'] for r in rs] == [512 * k for k in range(8)]
+    for k in range(1, 8):
+        torch.testing.assert_close(rs[k]['params'], rs[0]['params'], rtol=0, atol=0)
+        torch.testing.assert_close(rs[k]['init_params'], rs[0]['init_params'], rtol=0, atol=0)
+        for j in range(k):
+            assert not torch.equal(rs[k]['first_obs'], rs[j]['first_obs'])
+    assert torch.isfinite(rs[0]['params']).all() and (rs[0]['params'] - rs[0]['init_params']).abs().max() > 1e-4
 
 
 def _sac_dp_worker(rank, world, port, out_dir):

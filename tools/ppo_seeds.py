@@ -22,12 +22,13 @@ def main():
     ap.add_argument('--target-kl', type=float, default=0.03)
     ap.add_argument('--epochs', type=int, default=None)
     ap.add_argument('--rollout-steps', type=int, default=32)
+    ap.add_argument('--mb-per-epoch', type=int, default=None, help='partial epochs: optimiser steps per epoch (PPOConfig.extra minibatches_per_epoch)')
     a = ap.parse_args()
     import torch
     import bench
     torch.cuda.set_device(0)
     res = bench.ppo_leg(torch, None, 1, 0, a.seeds, a.budget, envs=a.envs, minibatch=a.minibatch, lr=a.lr, target_kl=a.target_kl,
-                        epochs=a.epochs, rollout_steps=a.rollout_steps)
+                        epochs=a.epochs, rollout_steps=a.rollout_steps, mb_per_epoch=a.mb_per_epoch)
     print(json.dumps(res))
 
 

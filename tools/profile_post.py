@@ -1,12 +1,43 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof (tools/profile_round.sh) into the committed profiles/<tag>_* artefacts."""
-import csv, glob, json, os, sys
+"""Condense gpurun_out/prof (tools/profile_round4.sh) into the committed profiles/<tag>_* artefacts.
+
+    python tools/profile_post.py r04
+
+* <tag>_kernel_stats_<workload>_<N>.csv   rocprofv3 --kernel-trace --stats summary rows of the workload's kernels
+* <tag>_hbm_traffic.json                  per workload: FETCH_SIZE x 2 + WRITE_SIZE per launch (separate --pmc passes, gfx950 x2 fetch
+                                          correction of MI355X_MICROARCH.md), executed VALU instructions per wave (SQ_INSTS_VALU / SQ_WAVES),
+                                          the rocprof average launch duration; `_meta.source_hash` = the kernel sources it was measured on
+                                          (bench.py drops the numbers when the tree's hash differs)
+Directory names written by the round-4 script: kt_<workload>_<dtype>_<N>, pmc_<COUNTERS>_<workload>_<dtype>_<N> (counters joined by '+');
+round-2/3 layouts (kt_<task>_<N>) are still understood."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
 DST = os.path.join(ROOT, 'profiles')
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+# workload -> substring of the kernel it is about
+KERNEL_OF = {'sequence_all': 'step_sequence_kernel', 'sequence_collector': 'step_sequence_kernel', 'rollout_policy': 'rollout_policy_kernel'}
+
+
+def kernel_of(workload):
+    return KERNEL_OF.get(workload, 'step_kernel')
+
+
+def second_half_mean(rows, counter, kname):
+    v = [float(r['Counter_Value']) for r in rows if kname in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    v = v[len(v) // 2:]
+    return (sum(v) / len(v), len(v)) if v else None
+
+
 traffic = {}
-for extra in ('ppo_iteration', 'ppo_iteration_65536', 'sac_iteration', 'sequence'):
+for extra in ('ppo_iteration', 'ppo_iteration_65536', 'sac_iteration'):
     stats = glob.glob(f'{SRC}/{extra}/**/*kernel_stats.csv', recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
@@ -17,52 +48,51 @@ for extra in ('ppo_iteration', 'ppo_iteration_65536', 'sac_iteration', 'sequence
 for d in sorted(glob.glob(f'{SRC}/kt_*')):
     if not os.path.isdir(d):
         continue
-    name = os.path.basename(d)[3:]
-    task, N = name.rsplit('_', 1)
-    N = int(N)
+    m = re.match(r'kt_(.+?)_(f32|f64)_(\d+)$', os.path.basename(d)) or re.match(r'kt_(.+)()_(\d+)$', os.path.basename(d))
+    work, dt, N = m.group(1), m.group(2) or 'f32', int(m.group(3))
+    kname = kernel_of(work)
+    entry = {'envs': N, 'kernel': kname}
     stats = glob.glob(f'{d}/**/*kernel_stats.csv', recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        keep = [r for r in rows if 'step_kernel' in r['Name'] or float(r['Percentage']) > 0.5]
-        with open(f'{DST}/{TAG}_kernel_stats_{task}_{N}.csv', 'w', newline='') as f:
+        keep = [r for r in rows if kname in r['Name'] or float(r['Percentage']) > 0.5]
+        suffix = '' if dt == 'f32' else f'_{dt}'
+        with open(f'{DST}/{TAG}_kernel_stats_{work}{suffix}_{N}.csv', 'w', newline='') as f:
             w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
         for r in keep:
-            if 'step_kernel' in r['Name']:
-                print(task, N, 'step_kernel: calls', r['Calls'], 'avg ns', r['AverageNs'], 'pct', r['Percentage'])
+            if kname in r['Name']:
+                entry['rocprof_avg_launch_us'] = float(r['AverageNs']) * 1e-3
+                entry['rocprof_calls'] = int(r['Calls'])
+                print(work, dt, N, kname, 'calls', r['Calls'], 'avg ns', r['AverageNs'], 'pct', r['Percentage'])
+                break
     vals = {}
-    for C in ('FETCH_SIZE', 'WRITE_SIZE'):
-        files = glob.glob(f'{SRC}/pmc_{C}_{task}_{N}/**/*counter_collection.csv', recursive=True)
-        if not files: continue
-        v = [float(r['Counter_Value']) for r in csv.DictReader(open(files[0])) if 'step_kernel' in r['Kernel_Name'] and r['Counter_Name'] == C]
-        v = v[len(v) // 2:]
-        if v:
-            vals[C] = (sum(v) / len(v), len(v))
-    if len(vals) == 2:
+    for f in glob.glob(f'{SRC}/pmc_*_{work}_{dt}_{N}/**/*counter_collection.csv', recursive=True) + \
+            (glob.glob(f'{SRC}/pmc_*_{work}_{N}/**/*counter_collection.csv', recursive=True) if dt == 'f32' else []):
+        rows = list(csv.DictReader(open(f)))
+        for C in {r['Counter_Name'] for r in rows}:
+            got = second_half_mean(rows, C, kname)
+            if got:
+                vals[C] = got
+    if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
         fetch = vals['FETCH_SIZE'][0] * 1024 * 2          # KB -> B, gfx950 x2 correction (MI355X_MICROARCH.md)
         write = vals['WRITE_SIZE'][0] * 1024
-        traffic[f'{task}/f32/{N}'] = {
-            'envs': N, 'FETCH_SIZE_KB_per_launch': vals['FETCH_SIZE'][0], 'WRITE_SIZE_KB_per_launch': vals['WRITE_SIZE'][0],
-            'dispatches_averaged': [vals['FETCH_SIZE'][1], vals['WRITE_SIZE'][1]],
-            'fetch_bytes_corrected_x2': fetch, 'write_bytes': write, 'traffic_bytes_per_launch': fetch + write,
-            'traffic_bytes_per_env_step': (fetch + write) / N,
-            'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (TCC slot limit); FETCH_SIZE doubled per '
-                    'MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)'}
-        print(task, N, 'traffic B/env-step', (fetch + write) / N)
+        entry.update({'FETCH_SIZE_KB_per_launch': vals['FETCH_SIZE'][0], 'WRITE_SIZE_KB_per_launch': vals['WRITE_SIZE'][0],
+                      'dispatches_averaged': [vals['FETCH_SIZE'][1], vals['WRITE_SIZE'][1]],
+                      'fetch_bytes_corrected_x2': fetch, 'write_bytes': write, 'traffic_bytes_per_launch': fetch + write,
+                      'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (TCC slot limit); FETCH_SIZE doubled per '
+                              'MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)'})
+        if kname == 'step_kernel':
+            entry['traffic_bytes_per_env_step'] = (fetch + write) / N
+        print(work, dt, N, 'traffic B/launch', fetch + write, 'per env', (fetch + write) / N)
+    if 'SQ_INSTS_VALU' in vals and 'SQ_WAVES' in vals and vals['SQ_WAVES'][0] > 0:
+        entry['valu_instructions_per_wave'] = vals['SQ_INSTS_VALU'][0] / vals['SQ_WAVES'][0]
+        entry['waves_per_launch'] = vals['SQ_WAVES'][0]
+        print(work, dt, N, 'VALU / wave', entry['valu_instructions_per_wave'])
+    if len(entry) > 2:
+        traffic[f'{work}/{dt}/{N}'] = entry
 if traffic:
+    from safe_control_gym_amd import _lib
+    traffic['_meta'] = {'source_hash': f'0x{_lib.source_hash():016x}', 'tag': TAG,
+                        'how': 'tools/profile_round4.sh on one MI355X (gpurun), condensed by tools/profile_post.py; the hash is of the kernel '
+                               'sources in the tree when this file was written — run the two back to back'}
     json.dump(traffic, open(f'{DST}/{TAG}_hbm_traffic.json', 'w'), indent=1)
-# diagnostic counter passes (4 M envs)
-diag = {}
-for d in sorted(glob.glob(f'{SRC}/diag*')):
-    if not os.path.isdir(d):
-        continue
-    for f in glob.glob(f'{d}/**/*counter_collection.csv', recursive=True):
-        acc = {}
-        for r in csv.DictReader(open(f)):
-            if 'step_kernel' in r['Kernel_Name']:
-                acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-        for k, v in acc.items():
-            v = v[len(v) // 2:]
-            diag[k] = sum(v) / len(v)
-if diag:
-    json.dump(diag, open(f'{DST}/{TAG}_pmc_4m_envs.json', 'w'), indent=1)
-    print(json.dumps(diag, indent=1))
