@@ -430,7 +430,7 @@ def shipped_ppo_score(torch, eval_env, tag='quadrotor_2D_track', hidden=128, act
 
 
 def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=None, lr=2e-3, target_kl=0.03, epochs=None, rollout_steps=32,
-            target=None, mb_per_epoch=None):
+            target=None, mb_per_epoch='auto'):
     """PPO wall-clock until the deterministic-policy evaluation reaches the reference reward on BASELINE config #3's batch
     (65 536 envs per GPU): fused rollout, fused MFMA update; every iteration's weights are evaluated on a second stream
     (EVAL_ENVS distinct randomised-init episodes, fused deterministic rollout) while training goes on.  Target = the shipped
@@ -444,8 +444,15 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
     # re-tuned for the batch (probes: tools/sessions/s43.sh, profiles/r03_ppo_probes_65536.txt): at 65 536 envs
     # 2 epochs x 32 minibatches of 127 x 512 rows reach the target in 1.4 s median where 4 x 64 of 127 x 256 need 2.2-2.3 s
     # (16 384 envs, tools/sessions/s54.sh: 2 epochs x 32 minibatches of 127 x 128 rows 0.62 s median of 4 seeds, 4 x 16 of 127 x 256 0.75 s)
+    # round 4 (tools/sessions/s83.sh, 3 seeds each, s to two consecutive evaluations >= target): what the KL-limited policy iteration
+    # needs per iteration is a number of optimiser STEPS (~64), not a number of samples seen — at 65 536 envs x 32 steps = 2 M
+    # samples, 2 PARTIAL epochs of 32 minibatches of 16 256 (a uniform half of the rollout; PPOConfig.extra minibatches_per_epoch)
+    # reach the target in 0.71 s median (0.60-0.77) where 2 full epochs of 32 x 65 024 need 1.30 s; the full-epoch figure stays in
+    # the line (`full_epochs`).  Also probed: 1 x 64 of 16 256: 0.98 s; 2 x 16 of 32 512: 0.89; 2 x 32 of 32 512: 0.97; 2 x 16 of 65 024: 0.95.
+    if mb_per_epoch == 'auto':
+        mb_per_epoch = 32 if (envs >= 65536 and minibatch is None) else None
     if minibatch is None:
-        minibatch = 65024 if envs >= 65536 else 16256
+        minibatch = 16256
     if epochs is None:
         epochs = 2
     env_id, cfg = load_task('quadrotor_2D_track')
@@ -775,6 +782,9 @@ def main():
             res = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds, envs=args.ppo_envs)
             if world == 1 and args.ppo_envs != 16384:           # the small-batch point (round 2's leg) under the same protocol and target
                 res['envs_16384'] = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds, envs=16384, target=res['target_return'])
+            if world == 1 and args.ppo_envs >= 65536:           # the same batch with FULL epochs (round 3's configuration), same protocol and target
+                res['full_epochs'] = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds, envs=args.ppo_envs, minibatch=65024,
+                                             mb_per_epoch=None, target=res['target_return'])
         except Exception as exc:                                    # noqa: BLE001
             import traceback
             res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}

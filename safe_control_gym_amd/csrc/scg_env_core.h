@@ -214,6 +214,9 @@ typedef unsigned int u32x4 __attribute__((vector_size(16)));
 #ifndef SCG_ST_AUX
 #define SCG_ST_AUX 17
 #endif
+#ifndef SCG_SEQ_ST_AUX
+#define SCG_SEQ_ST_AUX 0        // the K-steps-per-launch kernels (scg_step_sequence, scg_rollout_policy, scg_rollout_random): write-back
+#endif
 #ifndef SCG_LD_AUX
 #define SCG_LD_AUX 0
 #endif
@@ -232,20 +235,25 @@ __device__ __forceinline__ uint8_t buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, 
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, double) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, v, s, SCG_LD_AUX));
 }
+template <int AUX = SCG_ST_AUX>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, float x) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), r, v, s, SCG_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x), r, v, s, AUX);
 }
+template <int AUX = SCG_ST_AUX>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, int32_t x) {
-    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)x, r, v, s, SCG_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)x, r, v, s, AUX);
 }
+template <int AUX = SCG_ST_AUX>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint32_t x) {
-    __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, SCG_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, AUX);
 }
+template <int AUX = SCG_ST_AUX>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, uint8_t x) {
-    __builtin_amdgcn_raw_buffer_store_b8(x, r, v, s, SCG_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b8(x, r, v, s, AUX);
 }
+template <int AUX = SCG_ST_AUX>
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uint32_t s, double x) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, v, s, SCG_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), r, v, s, AUX);
 }
 
 // 16-byte store.  The uniform array offset goes through the VECTOR offset here (one v_add per row, the chunk constants
@@ -255,8 +263,9 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t v, uin
 // soffset field", GCNHazardRecognizer) — which does not hold on MI355X: `buffer_store_dwordx4 v[42:45], v27, s[40:43],
 // s4 offen` + `v_mov_b32 v42, s6` tore 16-64 doubles out of 1.5 M on a cold first launch
 // (tests/test_gpu_parity_scale.py; tools/hazard_lint.py proves the pattern absent from every built library).
+template <int AUX = SCG_ST_AUX>
 __device__ __forceinline__ void buf_st128(u32x4 d, __amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t array_off, uint32_t k) {
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, lane_off + array_off + k, 0, SCG_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, lane_off + array_off + k, 0, AUX);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
@@ -264,17 +273,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
 }
 
-template <typename V>
+// AUX: the cache policy of this slot's STORES (SCG_ST_AUX: write-through, for the one-launch-per-control-step kernels whose
+// stores would otherwise leave in one end-of-kernel flush; SCG_SEQ_ST_AUX: write-back, for the K-steps-per-launch kernels, whose
+// hundreds of megabytes of stacked outputs stream out under the following control steps anyway and are faster through the L2).
+template <typename V, int AUX = SCG_ST_AUX>
 struct Slot {
     using U = typename std::remove_const<V>::type;
+    template <int A2> __device__ __forceinline__ Slot<V, A2> with() const { return Slot<V, A2>{r, soff, off}; }
     __amdgpu_buffer_rsrc_t r;
     uint32_t soff;  // uniform byte offset of the array inside the resource; SCG_NO_OFF = array not present
     uint32_t off;   // per-lane byte offset
     __device__ __forceinline__ explicit operator bool() const { return soff != SCG_NO_OFF; }
     __device__ __forceinline__ U load(size_t k = 0) const { return buf_ld(r, off, soff + (uint32_t)(k * sizeof(V)), U()); }
-    __device__ __forceinline__ void store(U x, size_t k = 0) const { buf_st(r, off, soff + (uint32_t)(k * sizeof(V)), x); }
+    __device__ __forceinline__ void store(U x, size_t k = 0) const { buf_st<AUX>(r, off, soff + (uint32_t)(k * sizeof(V)), x); }
     // element index only known per lane / from LDS (not provably uniform): folded into the lane offset
-    __device__ __forceinline__ void store_at(U x, uint32_t k) const { buf_st(r, off + k * (uint32_t)sizeof(V), soff, x); }
+    __device__ __forceinline__ void store_at(U x, uint32_t k) const { buf_st<AUX>(r, off + k * (uint32_t)sizeof(V), soff, x); }
 
     // N consecutive elements of this lane (an AoS row whose lane offset was built with elems_per_lane = N, base
     // 16-byte aligned): moved in the widest pieces the row pitch allows (16, 8 or 4 bytes).
@@ -293,9 +306,9 @@ struct Slot {
             Pack<per> p;
 #pragma unroll
             for (int j = 0; j < per; ++j) p.e[j] = x[c * per + j];
-            if constexpr (W == 16) buf_st128(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * W));
-            else if constexpr (W == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p), r, off, soff + (uint32_t)(c * W), SCG_ST_AUX);
-            else buf_st(r, off, soff + (uint32_t)(c * W), p.e[0]);
+            if constexpr (W == 16) buf_st128<AUX>(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * W));
+            else if constexpr (W == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p), r, off, soff + (uint32_t)(c * W), AUX);
+            else buf_st<AUX>(r, off, soff + (uint32_t)(c * W), p.e[0]);
         }
     }
     // chunk c (M elements = 16 bytes) of this lane's row
@@ -305,7 +318,7 @@ struct Slot {
         Pack<M> p;
 #pragma unroll
         for (int j = 0; j < M; ++j) p.e[j] = x[j];
-        buf_st128(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * 16));
+        buf_st128<AUX>(__builtin_bit_cast(u32x4, p), r, off, soff, (uint32_t)(c * 16));
     }
     template <int N>
     __device__ __forceinline__ void load_row(U* x) const {
@@ -606,10 +619,15 @@ __device__ __forceinline__ T planar_pitch(T th) {
 
 // ------------------------------------------------------------------ the environment
 // DIST: any passive disturbance or adversary configured (host-selected kernel variant).
-template <int SYS, typename T, bool DIST>
+// STAUX: cache policy of every store this code issues (its own workspace arrays and the slots it is handed), see Slot.
+template <int SYS, typename T, bool DIST, int STAUX = SCG_ST_AUX>
 struct EnvOps {
     using D = Dims<SYS>;
     using E = Env<SYS, T>;
+    template <typename V>
+    __device__ static __forceinline__ Slot<V, STAUX> ws_slot(__amdgpu_buffer_rsrc_t r, uint32_t soff, int lane_index) {
+        return slot_in<V>(r, soff, lane_index).template with<STAUX>();
+    }
     // speculative reset draws inside the integrator (PreDraw): specialised float builds whose reset is exactly the compact
     // initial-state draw (-DSCG_NO_PREDRAW switches it off: A/B measurements)
 #if defined(SCG_SPEC) && !defined(SCG_NO_PREDRAW)
@@ -655,7 +673,7 @@ struct EnvOps {
         const size_t N = (size_t)P.i.num_envs;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
 #pragma unroll
-        for (int k = 0; k < D::NS; ++k) slot_in<T>(ws, P.i.state_off, i).store(e.s[k], k * N);
+        for (int k = 0; k < D::NS; ++k) ws_slot<T>(ws, P.i.state_off, i).store(e.s[k], k * N);
     }
     __device__ static __forceinline__ void store(const PV<T>& P, int i, const E& e, bool params_dirty, bool with_state = true) {
         const size_t N = (size_t)P.i.num_envs;
@@ -663,10 +681,10 @@ struct EnvOps {
         if (with_state) store_state(P, i, e);
         if (P.c.per_env_params && params_dirty) {
 #pragma unroll
-            for (int k = 0; k < D::NP; ++k) slot_in<T>(ws, P.i.param_off, i).store(e.par[k], k * N);
+            for (int k = 0; k < D::NP; ++k) ws_slot<T>(ws, P.i.param_off, i).store(e.par[k], k * N);
         }
-        slot_in<int32_t>(ws, P.i.step_off, i).store(e.step);
-        slot_in<uint32_t>(ws, P.i.episode_off, i).store(e.episode);
+        ws_slot<int32_t>(ws, P.i.step_off, i).store(e.step);
+        ws_slot<uint32_t>(ws, P.i.episode_off, i).store(e.episode);
     }
 
     // env.state (the vector the reference exposes), from the raw simulator state.
@@ -719,7 +737,7 @@ SCG_DIST_UNROLL
                     if (d.offset_slot >= 0) {
                         const int j = 4 * ch + k;
                         U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_DISTURB, (uint32_t)(j >> 1)));
-                        slot_in<int32_t>(make_rsrc(P.i.ws), P.i.dist_off, i).store(
+                        ws_slot<int32_t>(make_rsrc(P.i.ws), P.i.dist_off, i).store(
                             (int32_t)int_below((j & 1) ? w.z : w.x, (uint32_t)d.max_step), (size_t)d.offset_slot * P.i.num_envs);
                     }
                 }
@@ -833,7 +851,9 @@ SCG_DIST_UNROLL
         return 2 * D::NX;
     }
     // Row -> this env's slot of an [N][obs_dim] array (per-lane, strided by the row pitch).
-    __device__ static __forceinline__ void store_obs_row(const PV<T>& P, const T* row, int n, Slot<T> dst) {
+    template <int SLOT_AUX>
+    __device__ static __forceinline__ void store_obs_row(const PV<T>& P, const T* row, int n, Slot<T, SLOT_AUX> dst_in) {
+        const Slot<T, STAUX> dst = dst_in.template with<STAUX>();
         if (n == P.c.nobs && n == 2 * D::NX) dst.template store_row<2 * D::NX>(row);
         else if (n == P.c.nobs && n == D::NX) dst.template store_row<D::NX>(row);
         else {
@@ -842,10 +862,12 @@ SCG_DIST_UNROLL
         }
     }
 
+    template <int SLOT_AUX>
     __device__ static __forceinline__ void write_obs(const PV<T>& P, const GoalTab<T>& goal_tab, const T* st,
                                                      const E& e, RngKey key, int next_index, uint32_t rng_step,
-                                                     int32_t ctrl_step, int env_index, Slot<T> dst,
+                                                     int32_t ctrl_step, int env_index, Slot<T, SLOT_AUX> dst_in,
                                                      const T* ext_pre = nullptr) {
+        const Slot<T, STAUX> dst = dst_in.template with<STAUX>();
         if (obs_is_row(P)) {
             T row[2 * D::NX];
             const int n = obs_row(P, goal_tab, st, e, key, next_index, rng_step, ctrl_step, env_index, ext_pre, row);
@@ -880,8 +902,10 @@ SCG_DIST_UNROLL
     // Constraint rows (constraints.py:97-109); returns "any violated".  only_state: reset-time subset (written
     // densely at rows 0..n_state-1).  c_out: this env's column of the SoA [rows][N] output (row stride `stride`
     // elements: every store of a wave is one contiguous 256-byte segment), or absent.
+    template <int SLOT_AUX>
     __device__ static __forceinline__ bool constraints(const PV<T>& P, const T* st, const T* act,
-                                                       Slot<T> c_out, size_t stride, bool only_state) {
+                                                       Slot<T, SLOT_AUX> c_in, size_t stride, bool only_state) {
+        const Slot<T, STAUX> c_out = c_in.template with<STAUX>();
         bool viol = false;
         // (1) box rows: flat, unrolled so the row loads are all in flight together; the constrained
         //     variable is picked from registers with a select chain (no dependent memory round trips)
@@ -1070,9 +1094,10 @@ SCG_BOX_UNROLL
 
     // One control step, no auto-reset.  `act_in` = raw controller action; `adv` = adversary action or null.
     // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
+    template <int SLOT_AUX>
     __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,
-                                                      T* st, T* noisy_out, Slot<T> c_out, size_t c_stride,
+                                                      T* st, T* noisy_out, Slot<T, SLOT_AUX> c_out, size_t c_stride,
                                                       const T* ref_pre = nullptr, const T* ext_pre = nullptr,
                                                       const T* ext_reset = nullptr) {
         const int32_t c0 = e.step;      // ctrl_step_counter before the increment
@@ -1685,7 +1710,7 @@ SCG_BOX_UNROLL
             }
             if (!tracking) {
                 // stale `self.out_of_bounds` on goal_reached steps (see oracle/envs.py::_stale_oob)
-                const Slot<uint8_t> attr = slot_in<uint8_t>(make_rsrc(P.i.ws), P.i.oob_off, env_index);
+                const Slot<uint8_t, STAUX> attr = ws_slot<uint8_t>(make_rsrc(P.i.ws), P.i.oob_off, env_index);
                 const bool prev = attr.load() != 0;
                 oob = goal ? prev : oob;
                 attr.store(oob ? 1 : 0);

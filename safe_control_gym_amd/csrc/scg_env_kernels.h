@@ -190,8 +190,8 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(const CfgParams<T>* __rest
 // 64 partial cache lines per instruction, which the write path handles at a fraction of the speed of full lines
 // (profiles/r01_latency_budget.md §3).  The wave's rows form one contiguous 64*RB block, so the rows are transposed through
 // LDS (wave-private region, no workgroup barrier) and piece p of the block is written by lane p % 64.
-template <typename T, int NROW>
-__device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T* row, unsigned char* lds_wave, int lane) {
+template <typename T, int NROW, int AUX>
+__device__ __forceinline__ void store_rows_coalesced(const Slot<T, AUX>& dst, const T* row, unsigned char* lds_wave, int lane) {
     constexpr int RB = NROW * (int)sizeof(T);
     static_assert(RB % 16 == 0, "row pitch must be a multiple of 16 bytes");
     constexpr int per = 16 / (int)sizeof(T);
@@ -200,7 +200,7 @@ __device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T
         Piece p;
 #pragma unroll
         for (int j = 0; j < per; ++j) p.e[j] = row[j];
-        buf_st128(__builtin_bit_cast(u32x4, p), dst.r, dst.off, dst.soff, 0u);
+        buf_st128<AUX>(__builtin_bit_cast(u32x4, p), dst.r, dst.off, dst.soff, 0u);
         return;
     }
 #pragma unroll
@@ -217,7 +217,7 @@ __device__ __forceinline__ void store_rows_coalesced(const Slot<T>& dst, const T
 #pragma unroll
     for (int c = 0; c < RB / 16; ++c) {
         const Piece p = *reinterpret_cast<const Piece*>(lds_wave + (c * 64 + lane) * 16);
-        buf_st128(__builtin_bit_cast(u32x4, p), dst.r, block_off + (uint32_t)(lane * 16), dst.soff, (uint32_t)(c * 1024));
+        buf_st128<AUX>(__builtin_bit_cast(u32x4, p), dst.r, block_off + (uint32_t)(lane * 16), dst.soff, (uint32_t)(c * 1024));
     }
 }
 
@@ -408,12 +408,18 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     SCG_TL(7);
 }
 
+// Output slots of the K-steps-per-launch kernels: write-back stores (SCG_SEQ_ST_AUX, see Slot in scg_env_core.h).
+template <typename V>
+__device__ __forceinline__ Slot<V, SCG_SEQ_ST_AUX> seq_slot(V* base, int lane_index, int elems_per_lane = 1) {
+    return slot(base, lane_index, elems_per_lane).template with<SCG_SEQ_ST_AUX>();
+}
+
 template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                                int k_steps, T* __restrict__ reward_sum,
                                                                int32_t* __restrict__ done_count,
                                                                int32_t* __restrict__ violation_count, T* __restrict__ last_obs) {
-    using Ops = EnvOps<SYS, T, DIST>;
+    using Ops = EnvOps<SYS, T, DIST, SCG_SEQ_ST_AUX>;
     using D = Dims<SYS>;
     const int i = I.env_first + blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < I.env_end;
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
         T act[D::NU], noisy[D::NU];
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) act[j] = (T)-1 + (T)2 * u01<T>(u4_get(w, j));
-        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, slot((T*)nullptr, 0), 0);
+        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, seq_slot((T*)nullptr, 0), 0);
         rsum += r.reward;
         viols += (r.flags & FLAG_VIOLATION) ? 1 : 0;
         if (r.done) {
@@ -459,14 +465,14 @@ __global__ __launch_bounds__(BLOCK) void rollout_random_kernel(const CfgParams<T
             }
         }
     }
-    if (reward_sum) slot(reward_sum, i).store(rsum);
-    if (done_count) slot(done_count, i).store(dones);
-    if (violation_count) slot(violation_count, i).store(viols);
+    if (reward_sum) seq_slot(reward_sum, i).store(rsum);
+    if (done_count) seq_slot(done_count, i).store(dones);
+    if (violation_count) seq_slot(violation_count, i).store(viols);
     if (last_obs) {
         const bool fresh = e.step == 0;
         const int32_t c0 = e.step - 1;
         Ops::write_obs(P, goal, st, e, key, fresh ? 1 : c0 + 2, fresh ? 0u : (uint32_t)(c0 + 1), fresh ? 0 : c0, i,
-                       slot(last_obs, i, P.c.nobs));
+                       seq_slot(last_obs, i, P.c.nobs));
     }
     Ops::store(P, i, e, dirty);
 }
@@ -496,7 +502,7 @@ struct SeqArgs {
 template <int SYS, typename T, bool DIST>
 __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                               const SeqArgs<T> A) {
-    using Ops = EnvOps<SYS, T, DIST>;
+    using Ops = EnvOps<SYS, T, DIST, SCG_SEQ_ST_AUX>;
     using D = Dims<SYS>;
     const int i = I.env_first + blockIdx.x * blockDim.x + threadIdx.x;
     const int N = I.num_envs;
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
     const int nobs = P.c.nobs;
     const int rows = P.c.n_con_rows;
     T ep[4] = {(T)0, (T)0, (T)0, (T)0};
-    if (A.ep_stats) slot(A.ep_stats, i, 4).template load_row<4>(ep);
+    if (A.ep_stats) seq_slot(A.ep_stats, i, 4).template load_row<4>(ep);
     int ad = 0;
     if constexpr (DIST) {
         if (A.adv && P.c.adversary_channel >= 0) ad = P.c.adversary_channel == SCG_CH_ACTION ? D::NU : D::DYN;
@@ -554,14 +560,14 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
         const size_t tn = (size_t)t * N;
         const int32_t c0 = e.step;
         T noisy[D::NU];
-        const Slot<T> cv = A.c_values ? slot(A.c_values + (size_t)t * rows * N, i) : slot((T*)nullptr, 0);
+        const Slot<T, SCG_SEQ_ST_AUX> cv = A.c_values ? seq_slot(A.c_values + (size_t)t * rows * N, i) : seq_slot((T*)nullptr, 0);
         typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, cv, (size_t)N);
-        slot(A.reward + tn, i).store(r.reward);
-        slot(A.done + tn, i).store((uint8_t)(r.done ? 1 : 0));
-        slot(A.flags + tn, i).store((uint8_t)r.flags);
-        if (A.mse) slot(A.mse + tn, i).store(r.mse);
+        seq_slot(A.reward + tn, i).store(r.reward);
+        seq_slot(A.done + tn, i).store((uint8_t)(r.done ? 1 : 0));
+        seq_slot(A.flags + tn, i).store((uint8_t)r.flags);
+        if (A.mse) seq_slot(A.mse + tn, i).store(r.mse);
         if (A.noisy_action) {
-            const Slot<T> na = slot(A.noisy_action + tn * D::NU, i);
+            const Slot<T, SCG_SEQ_ST_AUX> na = seq_slot(A.noisy_action + tn * D::NU, i);
 #pragma unroll
             for (int j = 0; j < D::NU; ++j) na.store(noisy[j], (size_t)j * N);
         }
@@ -570,15 +576,15 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
         ep[2] += (r.flags & FLAG_VIOLATION) ? (T)1 : (T)0;
         ep[3] += r.mse;
         if (r.done) {
-            if (A.fin_stats) slot(A.fin_stats + tn * 4, i, 4).template store_row<4>(ep);
+            if (A.fin_stats) seq_slot(A.fin_stats + tn * 4, i, 4).template store_row<4>(ep);
             ep[0] = ep[1] = ep[2] = ep[3] = (T)0;
         }
         const bool do_reset = r.done && P.c.auto_reset;
-        const Slot<T> o_dst = slot(A.obs + tn * nobs, i, nobs);
+        const Slot<T, SCG_SEQ_ST_AUX> o_dst = seq_slot(A.obs + tn * nobs, i, nobs);
         if (Ops::obs_is_row(P)) {
             T row[2 * D::NX];
             int nrow = Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, nullptr, row);
-            if (r.done && A.terminal_obs) Ops::store_obs_row(P, row, nrow, slot(A.terminal_obs + tn * nobs, i, nobs));
+            if (r.done && A.terminal_obs) Ops::store_obs_row(P, row, nrow, seq_slot(A.terminal_obs + tn * nobs, i, nobs));
             if (do_reset) {
                 dirty = true;
                 Ops::reset(P, i, e, key, st);
@@ -600,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
 #endif
         } else {
             if (r.done && A.terminal_obs)
-                Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, slot(A.terminal_obs + tn * nobs, i, nobs), nullptr);
+                Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, seq_slot(A.terminal_obs + tn * nobs, i, nobs), nullptr);
             if (do_reset) {
                 dirty = true;
                 Ops::reset(P, i, e, key, st);
@@ -610,12 +616,12 @@ __global__ __launch_bounds__(BLOCK) void step_sequence_kernel(const CfgParams<T>
             }
         }
         if (A.state) {
-            const Slot<T> so = slot(A.state + tn * D::NX, i);
+            const Slot<T, SCG_SEQ_ST_AUX> so = seq_slot(A.state + tn * D::NX, i);
 #pragma unroll
             for (int k = 0; k < D::NX; ++k) so.store(st[k], (size_t)k * N);
         }
     }
-    if (A.ep_stats) slot(A.ep_stats, i, 4).template store_row<4>(ep);
+    if (A.ep_stats) seq_slot(A.ep_stats, i, 4).template store_row<4>(ep);
     Ops::store(P, i, e, dirty);
 }
 
@@ -648,7 +654,7 @@ constexpr uint32_t RNG_CH_POLICY = 5;
 template <int SYS, bool DIST, int EPW>
 __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<float> I, const PolicyArgs A) {
     using T = float;
-    using Ops = EnvOps<SYS, T, DIST>;
+    using Ops = EnvOps<SYS, T, DIST, SCG_SEQ_ST_AUX>;
     using D = Dims<SYS>;
     constexpr CfgParams<T> kcfg = scg_make_spec_cfg<T>();
     constexpr int NIN = kcfg.nobs, NU = D::NU, HID = SCG_POLICY_H, ACT = SCG_POLICY_ACT;
@@ -677,8 +683,8 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
     Ops::load_params(P, i, e);
     const RngKey key{I.key0, I.key1};
     float ep[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (A.ep_stats) slot(A.ep_stats, i, 4).template load_row<4>(ep);
-    if (A.episode_acc) slot(A.episode_acc, i, 8).template load_row<8>(acc);
+    if (A.ep_stats) seq_slot(A.ep_stats, i, 4).template load_row<4>(ep);
+    if (A.episode_acc) seq_slot(A.episode_acc, i, 8).template load_row<8>(acc);
     float logstd[NU], sigma[NU], logp_const = 0.0f;
 #pragma unroll
     for (int a = 0; a < NU; ++a) {
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
     for (int t = 0; t <= A.k_steps; ++t) {
         // ---- rollout row obs[t]
         {
-            const Slot<T> dst = slot(A.obs + (size_t)t * N * NIN, i, NIN);
+            const Slot<T, SCG_SEQ_ST_AUX> dst = seq_slot(A.obs + (size_t)t * N * NIN, i, NIN);
             if constexpr ((NIN * (int)sizeof(T)) % 16 == 0) {              // 16-byte rows leave through the LDS transpose (as in step_kernel)
                 if (full_wave) store_rows_coalesced<T, NIN>(dst, row, s_wave, lane);
                 else if (live) dst.template store_row<NIN>(row);
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
         // ---- the control step (identical code to scg_step's kernel)
         const int32_t c0 = e.step;
         T noisy[NU];
-        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, slot((T*)nullptr, 0), 0);
+        typename Ops::StepResult r = Ops::step(P, goal, e, act, nullptr, key, i, st, noisy, seq_slot((T*)nullptr, 0), 0);
         const size_t tn = (size_t)t * N + i;
         if (live) {
 #pragma unroll
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
         ep[0] += r.reward; ep[1] += 1.0f; ep[2] += (r.flags & FLAG_VIOLATION) ? 1.0f : 0.0f; ep[3] += r.mse;
         Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, nullptr, row);
         if (r.done) {
-            if (A.terminal_obs && live) slot(A.terminal_obs + (size_t)t * N * NIN, i, NIN).template store_row<NIN>(row);
+            if (A.terminal_obs && live) seq_slot(A.terminal_obs + (size_t)t * N * NIN, i, NIN).template store_row<NIN>(row);
             if (A.max_episodes <= 0 || acc[0] < (float)A.max_episodes) {
                 acc[0] += 1.0f; acc[1] += ep[0]; acc[2] += ep[1]; acc[3] += ep[2]; acc[4] += ep[3];
             }
@@ -787,8 +793,8 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
         }
     }
     if (live) {
-        if (A.ep_stats) slot(A.ep_stats, i, 4).template store_row<4>(ep);
-        if (A.episode_acc) slot(A.episode_acc, i, 8).template store_row<8>(acc);
+        if (A.ep_stats) seq_slot(A.ep_stats, i, 4).template store_row<4>(ep);
+        if (A.episode_acc) seq_slot(A.episode_acc, i, 8).template store_row<8>(acc);
         Ops::store(P, i, e, dirty);
     }
 }

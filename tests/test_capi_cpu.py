@@ -197,3 +197,27 @@ def test_staged_reference_python_stays_out_of_history_and_out_of_the_product():
                 assert 'oracle/_ref' not in src and 'reference_root' not in src and 'ref_stubs' not in src, os.path.join(d, f)
     bench = open(os.path.join(ROOT, 'bench.py')).read()
     assert 'ref_stubs' not in bench and 'reference_root' not in bench and '/root/reference' not in bench
+
+
+def test_bench_quotes_pmc_numbers_only_for_the_kernel_sources_they_were_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic / valu_issue come from a committed rocprofv3 --pmc file that names the hash of the kernel sources it
+    was measured on; with other sources in the tree the line must carry null + the reason, never the stale number."""
+    import json
+    import bench
+    from safe_control_gym_amd import _lib
+    good = {'_meta': {'source_hash': f'0x{_lib.source_hash():016x}'},
+            'quadrotor_2D_track/f32/65536': {'traffic_bytes_per_launch': 14.5e6, 'valu_instructions_per_wave': 900.0}}
+    os.makedirs(tmp_path / 'profiles')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    for meta_hash, expect in ((good['_meta']['source_hash'], 14.5e6), ('0x0123456789abcdef', None)):
+        good['_meta']['source_hash'] = meta_hash
+        (tmp_path / 'profiles' / bench.TRAFFIC_FILE).write_text(json.dumps(good))
+        bench._PMC_CACHE.clear()
+        r = bench.roofline_of('quadrotor_2D_track', 'f32', 65536, 4.2)
+        assert r['traffic'] == expect
+        if expect is None:
+            assert 'dropped' in r['traffic_source'] and r['valu_issue'] is None
+        else:
+            assert r['valu_issue']['frac'] == pytest.approx(900.0 * 4 / 2.4e3 / 4.2)
+        assert r['frac'] == pytest.approx(187 * 65536 / 4.2e-6 / 8e12)
+    bench._PMC_CACHE.clear()

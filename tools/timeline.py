@@ -27,9 +27,11 @@ if sys.argv[1] == 'hash':
     print(H)
 elif sys.argv[1] == 'build':
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
+    from safe_control_gym_amd import _lib as L          # the shipped build's flags: source-hash stamp (checked at load) and scheduler strategy
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=on', '-std=c++17', '-fPIC', '-shared', '-w', '-DSCG_SPEC',
-                           '-DSCG_EXP_TIMELINE'] + sys.argv[2:] + ['-include', f'{SPEC}/scg_spec_{H}.h', '-o', VARIANT,
-                           f'{ROOT}/safe_control_gym_amd/csrc/scg_kernels.hip'])
+                           '-DSCG_EXP_TIMELINE', f'-DSCG_SRC_HASH=0x{L.source_hash():016x}ULL', '-mllvm', '-amdgpu-sched-strategy=max-ilp']
+                          + sys.argv[2:] + ['-include', f'{SPEC}/scg_spec_{H}.h', '-o', VARIANT,
+                                            f'{ROOT}/safe_control_gym_amd/csrc/scg_kernels.hip'])
 else:
     import shutil, numpy as np, torch
     real = f'{SPEC}/libscg_spec_{H}.so'
