@@ -406,6 +406,28 @@ EVAL_INIT_RAND_Q3 = {k: {'distrib': 'uniform', 'low': lo, 'high': hi} for k, (lo
     'init_p': (-0.01, 0.01), 'init_q': (-0.01, 0.01), 'init_r': (-0.01, 0.01)}.items()}
 
 
+# BASELINE config #5 names "parameter + dynamics disturbances".  Upstream's parameter table (quadrotor.py:47-68) holds RANGES
+# (M 0.022 .. 0.032 around 0.027) but benchmark_env.py:237-268 ADDS the draw to the nominal value: the mass doubles and nothing flies
+# it.  Flyable statement of the same mechanism (additive draws, `respect_randomization_info`): deltas the normalised action space can
+# still hover — thrust authority is +-10 % of the nominal hover thrust (norm_act_scale 0.1), so |dM| / M <= 7.4 %.
+FLYABLE_PARAM_RAND_Q3 = {'M': {'distrib': 'uniform', 'low': -0.002, 'high': 0.002}, 'Ixx': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6},
+                         'Iyy': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}, 'Izz': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}}
+
+
+def sac_task_config(param_rand):
+    """(env_id, training config, evaluation config) of the SAC leg; param_rand: None (inertial randomisation off) or an additive table."""
+    from safe_control_gym_amd.registration import load_task
+    env_id, cfg = load_task('quadrotor_3D_track_disturbed')
+    cfg['randomized_inertial_prop'] = False
+    ev = eval_task_config(cfg, EVAL_INIT_RAND_Q3)
+    if param_rand:
+        from safe_control_gym_amd.env_config import QUAD_BASE_INIT_RAND     # (what the training env draws when the YAML tables are ignored, as upstream)
+        cfg = dict(cfg, randomized_inertial_prop=True, respect_randomization_info=True, inertial_prop_randomization_info=param_rand,
+                   init_state_randomization_info=dict(QUAD_BASE_INIT_RAND))
+        ev = dict(ev, randomized_inertial_prop=True, inertial_prop_randomization_info=param_rand)
+    return env_id, cfg, ev
+
+
 def eval_task_config(cfg, table):
     """Task config of the evaluation env: same task, initial states drawn per episode from `table` (additive, like upstream)."""
     return dict(cfg, randomized_init=True, respect_randomization_info=True, init_state_randomization_info=table)
@@ -527,7 +549,7 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
 
 
 def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, lr=1e-3, warm_up_steps=65536, eval_every=50,
-            buffer=4_000_000, world=1, rank=0):
+            buffer=4_000_000, world=1, rank=0, param_rand=None):
     """SAC wall-clock-to-reward on BASELINE config #5's env (Quadrotor3D figure-8 tracking, white-noise dynamics disturbance,
     constraint evaluation; `randomized_inertial_prop` OFF — upstream's additive draw doubles the mass and nothing can fly it,
     DESIGN §7), sac.py:162-335 semantics on the HIP engine.  Target = the score of the reference's SHIPPED SAC model
@@ -551,9 +573,8 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
         def act(self, obs):
             return self.ac.act(obs, deterministic=True)
 
-    env_id, cfg = load_task('quadrotor_3D_track_disturbed')
-    cfg['randomized_inertial_prop'] = False
-    eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=4242, return_numpy=False, **eval_task_config(cfg, EVAL_INIT_RAND_Q3))
+    env_id, cfg, ev_cfg = sac_task_config(param_rand)
+    eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=4242, return_numpy=False, **ev_cfg)
     spec = eval_env.spec
     low = torch.as_tensor(spec.action_space.low, dtype=torch.float32, device=eval_env.device)
     high = torch.as_tensor(spec.action_space.high, dtype=torch.float32, device=eval_env.device)
@@ -602,7 +623,9 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
         env.close()
     eval_env.close()
     ok1, ok2 = [t for t in first if t is not None], [t for t in both if t is not None]
-    return {'task': 'quadrotor_3D_track_disturbed (randomized_inertial_prop off)', 'target_return': target,
+    return {'task': 'quadrotor_3D_track_disturbed ' + ('(randomized_inertial_prop ON: additive draws per episode, training AND evaluation envs, '
+                    f'{ {k: (v["low"], v["high"]) for k, v in param_rand.items()} })' if param_rand else '(randomized_inertial_prop off)'),
+            'target_return': target,
             'target_source': 'shipped sac_model_quadrotor_3D_track.pt under this protocol',
             'shipped_model_eval': {'returns': [e['ep_return'] for e in evs], 'mean_length': sum(e['ep_length'] for e in evs) / len(evs)},
             'eval_protocol': f'{EVAL_ENVS} distinct randomised-init episodes per evaluation (x, y, z +-0.5, angles +-0.1, rates +-0.01), '
@@ -793,6 +816,8 @@ def main():
     if full and args.sac_seeds > 0 and (world == 1 or backend == 'nccl' or os.environ.get('SCG_BENCH_SAC_GLOO')):
         try:
             res = sac_leg(torch, args.sac_seeds, args.sac_seconds, world=world, rank=rank)
+            if world == 1:          # config #5 WITH parameter disturbances (flyable additive deltas), target re-measured under them
+                res['param_randomised'] = sac_leg(torch, args.sac_seeds, args.sac_seconds, param_rand=FLYABLE_PARAM_RAND_Q3)
         except Exception as exc:                                    # noqa: BLE001
             import traceback
             res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}

@@ -41,7 +41,9 @@ def source_hash():
 
 
 def lib_path(obs_dim, hidden, act_dim, activation):
-    return os.path.join(L.SPEC_DIR, f'libscg_learn_{obs_dim}_{hidden}_{act_dim}_{activation}.so')
+    """$SCG_LEARN_TAG selects a tagged variant library (built with $SCG_LEARN_FLAGS next to the shipped one: same-box A/B runs)."""
+    tag = os.environ.get('SCG_LEARN_TAG', '')
+    return os.path.join(L.SPEC_DIR, f'libscg_learn_{obs_dim}_{hidden}_{act_dim}_{activation}{"_" + tag if tag else ""}.so')
 
 
 def build(obs_dim, hidden, act_dim, activation, force=False):

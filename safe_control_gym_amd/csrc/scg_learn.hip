@@ -35,6 +35,9 @@
 
 using namespace scg;
 
+#ifndef SCG_L_PART_AUX
+#define SCG_L_PART_AUX 17       // cache policy of the partial-gradient stores: sc0 | sc1 = write-through (0 = write-back, for A/B)
+#endif
 constexpr int NIN = SCG_L_NIN, HID = SCG_L_H, NU = SCG_L_NU, ACT = SCG_L_ACT;
 constexpr int NT = HID / 32;
 constexpr int XS_WORDS = (NIN + 2) * 32;                // a wave's sample cache: [input | ones | zeros][32 samples]
@@ -509,9 +512,19 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         __syncthreads();
     }
     SCG_L_STAMP(4);
-    float* const P = A.partials + ((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE;
-    for (int k = tid; k < G::END; k += blockDim.x) P[k] = gl[k];
-    for (int k = tid; k < HID * HID; k += blockDim.x) P[G::END + k] = stg[k];
+    // The workgroup's partial vector (74 KB for H = 128; 254 workgroups: 19 MB per call) leaves as 16-byte stores WRITTEN THROUGH
+    // (sc0 sc1, SCG_L_PART_AUX): the reduction kernel that follows reads it from other XCDs, so it has to reach the memory side
+    // before this kernel may retire — written back, that is one flush behind the LAST workgroup's last store; written through,
+    // the partials of workgroups that finish early (the tile counts differ by one between waves) are out already.
+    static_assert(G::END % 4 == 0 && PARTIAL_STRIDE % 4 == 0 && (HID * HID) % 4 == 0, "16-byte partial stores");
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)A.partials, 0, 0xffffffff, 0x00020000);
+    const uint32_t pbase = (uint32_t)(((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE * sizeof(float));
+    typedef unsigned int u32x4 __attribute__((vector_size(16)));
+    for (int k = 4 * tid; k < G::END; k += 4 * blockDim.x)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(gl + k)), pr, pbase + 4u * (uint32_t)k, 0, SCG_L_PART_AUX);
+    for (int k = 4 * tid; k < HID * HID; k += 4 * blockDim.x)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(stg + k)), pr, pbase + 4u * (uint32_t)(G::END + k), 0,
+                                               SCG_L_PART_AUX);
     SCG_L_STAMP(5);
 }
 

@@ -16,7 +16,7 @@
 //   q_kernel<0>          target networks at (next_obs, a')
 //   q_kernel<2>          d[mean (q_y - target)^2]/d(q_y), y = 1, 2
 //   reduce_kernel        sum of the partials + Adam: critics, soft update of their target copies        (:163-168)
-//   (step counters, loss statistics: the last workgroup of the critics' reduce_kernel; finish_kernel on the data-parallel path)
+//   finish_kernel        step counters, loss statistics
 // (Data-parallel callers run the phases separately — include/scg_sac.h — with reduce_kernel writing the gradient only and
 //  adam_kernel stepping after the all-reduce.)
 // Gradient reduction: every WORKGROUP owns one partial gradient vector in global memory (a workgroup usually owns one tile: plain
@@ -687,26 +687,6 @@ __device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay) {
     return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
 }
 
-struct FinishArgs {
-    float* steps; uint32_t* counter; float* stats; float* stats_acc; const float* actor_stat; const float* q_stat;
-    const float* log_alpha_before; int alpha_on; float target_entropy;
-};
-// step counters + loss statistics of one gradient step (one thread)
-__device__ __forceinline__ void finish_step(const FinishArgs& F) {
-    F.steps[0] += 1.0f; F.steps[1] += 1.0f;
-    if (F.alpha_on) F.steps[2] += 1.0f;
-    *F.counter += 1u;
-    const float pl = F.actor_stat[0], ml = F.actor_stat[1];
-    const float cl = F.q_stat[0] + F.q_stat[2];
-    const float el = F.alpha_on ? -(*F.log_alpha_before) * (ml + F.target_entropy) : 0.0f;
-    F.stats[0] = pl; F.stats[1] = cl; F.stats[2] = el; F.stats[3] = ml;
-    if (F.stats_acc) { F.stats_acc[0] += pl; F.stats_acc[1] += cl; F.stats_acc[2] += el; F.stats_acc[3] += ml; }
-}
-__global__ void finish_kernel(const FinishArgs F) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    finish_step(F);
-}
-
 struct ReduceArgs {
     const float* partials; int n_part; scg_mlp_layout lay[2]; float* grad;
     float* stat_out;            // [2 * gridDim.y]: STAT + 0, STAT + 1 of each network
@@ -717,15 +697,8 @@ struct ReduceArgs {
     // gradient through memory go away.  Data-parallel callers leave p null, all-reduce grad and run adam_kernel.
     float* p; float* m; float* v; float lr; const float* steps; int step_slot; float* target; float tau;
     int alpha_on; float lr_alpha;
-    // done_role 2 (the critics' launch of the single-GPU path): the LAST workgroup to finish — every other one has read its
-    // step count and published its sums by then (fence + one atomic per workgroup) — also does the step's bookkeeping
-    // (finish_step), which therefore needs no launch of its own.  done_role 1 (the actor's launch of the same step, earlier on
-    // the stream): zeroes that workgroup counter (the workspace is the caller's, uninitialised memory).
-    uint32_t* done; int done_role; FinishArgs fin;
 };
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float t);
-template <int NIN, int NOUT>
-__device__ __forceinline__ void reduce_element(const ReduceArgs& R, int net, int k, float s);
 template <int NIN, int NOUT>
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     __shared__ float part[4][64];
@@ -740,23 +713,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     }
     part[grp][kl] = s;
     __syncthreads();
-    if (grp == 0 && k < words) reduce_element<NIN, NOUT>(R, net, k, (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]));
-    if (R.done_role == 1) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *R.done = 0u;
-    } else if (R.done_role == 2) {
-        __threadfence();                                    // this thread's sums / parameter writes / reads of steps: done and visible
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t total = gridDim.x * gridDim.y;
-            if (atomicAdd(R.done, 1u) == total - 1u) {
-                __threadfence();
-                finish_step(R.fin);
-            }
-        }
-    }
-}
-template <int NIN, int NOUT>
-__device__ __forceinline__ void reduce_element(const ReduceArgs& R, int net, int k, float s) {
+    if (grp != 0 || k >= words) return;
+    s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
     const int d = dest_of<NIN, NOUT>(k, R.lay[net]);
     if (d >= 0) {
         R.grad[d] = s;
@@ -803,9 +761,29 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs A) {
     if (A.target && i < A.n_polyak) A.target[i] = (1.0f - A.tau) * A.target[i] + A.tau * A.p[i];
 }
 
+struct FinishArgs {
+    float* steps; uint32_t* counter; float* stats; float* stats_acc; const float* actor_stat; const float* q_stat;
+    const float* log_alpha_before; int alpha_on; float target_entropy;
+};
+// (Kept as its own one-thread launch.  Folding it into the critics' reduce_kernel as "the last workgroup to finish does the
+//  bookkeeping" — a device-scope fence + one atomic per workgroup — was measured in round 4 (tools/sessions/s84.sh,
+//  profiles/r04_kernel_stats_sac_iteration.csv): reduce_kernel<28, 1> 7.7 -> 64.8 us.  On this chip a device-scope release is
+//  a write-back of the XCD's L2 (the 8 L2s are not coherent with each other), and 640 workgroups each paid one.)
+__global__ void finish_kernel(const FinishArgs F) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    F.steps[0] += 1.0f; F.steps[1] += 1.0f;
+    if (F.alpha_on) F.steps[2] += 1.0f;
+    *F.counter += 1u;
+    const float pl = F.actor_stat[0], ml = F.actor_stat[1];
+    const float cl = F.q_stat[0] + F.q_stat[2];
+    const float el = F.alpha_on ? -(*F.log_alpha_before) * (ml + F.target_entropy) : 0.0f;
+    F.stats[0] = pl; F.stats[1] = cl; F.stats[2] = el; F.stats[3] = ml;
+    if (F.stats_acc) { F.stats_acc[0] += pl; F.stats_acc[1] += cl; F.stats_acc[2] += el; F.stats_acc[3] += ml; }
+}
+
 // ------------------------------------------------------------------ host side
 struct Ws {      // workspace carve-up (floats)
-    size_t idx, eps, a_pi, logp, eps2, a_next, logp_next, qpi, dqda, qt, stat, la_before, done, partials, total;
+    size_t idx, eps, a_pi, logp, eps2, a_next, logp_next, qpi, dqda, qt, stat, la_before, partials, total;
 };
 static Ws carve(int B, int n_part) {
     Ws w; size_t o = 0;
@@ -813,7 +791,7 @@ static Ws carve(int B, int n_part) {
     w.idx = take(B); w.eps = take((size_t)B * NU); w.a_pi = take((size_t)B * NU); w.logp = take(B);
     w.eps2 = take((size_t)B * NU); w.a_next = take((size_t)B * NU); w.logp_next = take(B);
     w.qpi = take(2 * (size_t)B); w.dqda = take(2 * (size_t)B * NU); w.qt = take(2 * (size_t)B);
-    w.stat = take(8); w.la_before = take(1); w.done = take(1);
+    w.stat = take(8); w.la_before = take(1);
     w.partials = take(2 * (size_t)n_part * PSTRIDE);
     w.total = o;
     return w;
@@ -874,7 +852,6 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     // by one, an all-reduce of d_grad between them) get the gradient only and step in adam_kernel
     const bool fuse = phases == SCG_SAC_ALL;
     auto optimiser = [&](ReduceArgs& R, float lr, int step_slot) {
-        R.done = reinterpret_cast<uint32_t*>(W + w.done); R.done_role = 0; R.fin = FinishArgs{};
         if (!fuse) { R.p = nullptr; R.m = R.v = R.target = nullptr; R.steps = nullptr; R.lr = R.tau = R.lr_alpha = 0.0f; R.step_slot = 0; R.alpha_on = 0; return; }
         R.p = a->d_params; R.m = a->d_m; R.v = a->d_v; R.lr = lr; R.steps = a->d_steps; R.step_slot = step_slot;
         R.target = a->d_target; R.tau = a->tau; R.alpha_on = a->use_entropy_tuning; R.lr_alpha = a->entropy_lr;
@@ -893,7 +870,6 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->actor; R.lay[1] = a->actor; R.grad = a->d_grad; R.stat_out = stat;
         R.alpha_slot = a->n_params; R.target_entropy = a->target_entropy;
         optimiser(R, a->actor_lr, 0);
-        if (fuse) R.done_role = 1;
         reduce_kernel<NOBS, NA><<<dim3((Part<NOBS, NA>::END + 63) / 64, 1), dim3(256), 0, st>>>(R);
     }
     }
@@ -916,10 +892,6 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->q1; R.lay[1] = a->q2; R.grad = a->d_grad; R.stat_out = stat + 2;
         R.alpha_slot = -1; R.target_entropy = 0.0f;
         optimiser(R, a->critic_lr, 1);
-        if (fuse) {          // 9. step counters, loss statistics: by the last workgroup of this launch
-            R.done_role = 2;
-            R.fin = FinishArgs{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
-        }
         reduce_kernel<NQ, 1><<<dim3((Part<NQ, 1>::END + 63) / 64, 2), dim3(256), 0, st>>>(R);
     }
     }
@@ -930,8 +902,8 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
                    0, a->n_params, 0.0f, 0.0f, stat, a->d_target, a->n_params, a->tau};
         adam_kernel<<<dim3((a->n_params + 255) / 256), dim3(256), 0, st>>>(A);
     }
-    // 9. step counters, loss statistics (data-parallel path: its own launch after the caller's all-reduce and the Adam kernel)
-    if (!fuse) {
+    // 9. step counters, loss statistics
+    {
         FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
         finish_kernel<<<dim3(1), dim3(64), 0, st>>>(F);
     }

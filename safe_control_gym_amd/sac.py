@@ -177,7 +177,7 @@ class SACAgent:
         self.use_graphs = (torch.device(device).type == 'cuda' and bool(cfg.extra.get('cuda_graphs', True))
                            and parallel.world_size() == 1)
         # Fused gradient step (csrc/scg_sac.hip, include/scg_sac.h): the whole SACAgent.update — sampling, the five network
-        # passes on the matrix cores, both Adam steps, temperature, Polyak — as 8 launches on flat parameter vectors instead
+        # passes on the matrix cores, both Adam steps, temperature, Polyak — as 9 launches on flat parameter vectors instead
         # of ~100 PyTorch kernels.  Chosen here, visibly: single-rank GPU runs of shapes the library serves.
         from safe_control_gym_amd import _sac
         self.obs_dim, self.act_dim = obs_dim, act_dim
@@ -297,7 +297,7 @@ class SACAgent:
             st = (F['acc'] / n_updates).tolist()
             return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
         g = F['graphs'].get(n_updates)
-        if g is None:                               # n_updates steps as one HIP graph (8 launches each: host-launch bound otherwise)
+        if g is None:                               # n_updates steps as one HIP graph (9 launches each: host-launch bound otherwise)
             with torch.cuda.device(dev):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
