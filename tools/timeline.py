@@ -6,6 +6,9 @@
 """
 import ctypes as C, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1 and sys.argv[1] == 'run':
+    import torch        # BEFORE anything that may load a HIP library: torch's bundled runtime must initialise first (s84 / s85: the run
+    torch.cuda.init()   # died in hipSetDevice with "no ROCm-capable device is detected" when _lib was imported ahead of torch)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPEC = os.path.join(ROOT, 'safe_control_gym_amd', 'spec')
 
