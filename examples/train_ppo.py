@@ -24,6 +24,9 @@ def main():
     ap.add_argument('--rollout-steps', type=int, default=32)
     ap.add_argument('--epochs', type=int, default=4)
     ap.add_argument('--minibatch', type=int, default=32512, help='127 x 256: the gradient kernel then fills 254 of the 256 CUs exactly')
+    ap.add_argument('--mb-per-epoch', type=int, default=None,
+                    help='PARTIAL epochs: walk only this many minibatches of each shuffled epoch (PPOConfig.extra minibatches_per_epoch); '
+                         'bench.py uses 2 x 32 x 16 256 at 65 536 envs')
     ap.add_argument('--lr', type=float, default=2e-3)
     ap.add_argument('--critic-lr', type=float, default=None)
     ap.add_argument('--hidden', type=int, default=128)
@@ -69,7 +72,8 @@ def main():
                      target_kl=args.target_kl, entropy_coef=args.entropy, opt_epochs=args.epochs,
                      mini_batch_size=args.minibatch, actor_lr=args.lr, critic_lr=args.critic_lr or args.lr,
                      rollout_batch_size=args.envs, rollout_steps=args.rollout_steps, max_env_steps=int(args.max_env_steps),
-                     extra={'cuda_graphs': not args.no_graphs, 'fused_update': not args.no_fused})
+                     extra={'cuda_graphs': not args.no_graphs, 'fused_update': not args.no_fused,
+                            **({'minibatches_per_epoch': args.mb_per_epoch} if args.mb_per_epoch else {})})
     ppo = PPO(env, pcfg, seed=args.seed)
     init_params = torch.cat([p.detach().reshape(-1) for p in ppo.agent.ac.parameters()]).cpu()
     torch.cuda.synchronize()
