@@ -273,6 +273,11 @@ class PPOAgent:
             float(cfg.actor_lr), float(cfg.critic_lr), fl['steps'].data_ptr(), float(cfg.target_kl),
             F['stats_acc'].data_ptr(), F['stats'].data_ptr(), F['adam_sync'].data_ptr(), st))
 
+    def _capped(self, n_mb):
+        """Minibatches walked per epoch: all of the shuffled epoch, or the first extra['minibatches_per_epoch'] of them (every update path)."""
+        cap = self.cfg.extra.get('minibatches_per_epoch')
+        return max(1, min(n_mb, int(cap))) if cap else n_mb
+
     def _update_fused(self, data, generator=None):
         cfg = self.cfg
         M = data['obs'].shape[0]
@@ -284,9 +289,7 @@ class PPOAgent:
         # the rollout; upstream always walks the whole permutation, ppo_utils.py:358-371).  With 65 536 envs x 32 steps an iteration
         # holds 2 M samples: the number of optimiser steps per iteration, not the number of samples seen, is what the KL-limited
         # policy iteration needs, and the learner is the whole cost of the iteration (bench.py's PPO leg says which it uses).
-        cap = cfg.extra.get('minibatches_per_epoch')
-        if cap:
-            n_mb = max(1, min(n_mb, int(cap)))
+        n_mb = self._capped(n_mb)
         for k, v in data.items():
             assert v.dtype == torch.float32 and v.is_contiguous(), k
         if self._fused is None or self._fused['key'] != (M, mb):
@@ -386,6 +389,7 @@ class PPOAgent:
         M = data['obs'].shape[0]
         mb = min(cfg.mini_batch_size, M)
         n_mb = M // mb
+        n_mb = self._capped(n_mb)
         assert n_mb != 0, 'num_mini_batch is 0'
         if self._g is None or self._g['key'] != (M, mb):
             # static copies of the per-iteration inputs (the rollout tensors keep their addresses already)
@@ -452,6 +456,7 @@ class PPOAgent:
         M = data['obs'].shape[0]
         mb = min(cfg.mini_batch_size, M)
         n_mb = M // mb
+        n_mb = self._capped(n_mb)
         assert n_mb != 0, 'num_mini_batch is 0'
         if self._bucket is None:
             params = list(self.ac.actor.parameters()) + list(self.ac.critic.parameters())

@@ -139,12 +139,16 @@ def test_gated_adam_kernel_equals_the_graphed_torch_adam():
     assert F['stats_acc'][4].item() == ref['steps'][0]
 
 
-def test_fused_update_matches_the_torch_update_statistically():
+@pytest.mark.parametrize('cap', [None, 3], ids=['full_epochs', 'partial_epochs'])
+def test_fused_update_matches_the_torch_update_statistically(cap):
     """A whole PPOAgent.update through the fused kernels vs the graphed PyTorch path from identical parameters, data and
-    minibatch permutations: same number of gated actor steps, parameters equal to float32 accumulation-order noise."""
+    minibatch permutations: same number of gated actor steps, parameters equal to float32 accumulation-order noise.
+    partial_epochs: extra['minibatches_per_epoch'] = 3 of the 8 minibatches of each shuffled epoch, on both paths."""
     data = None
     res, params = {}, {}
     for mode, extra in (('fused', {}), ('torch', {'fused_update': False})):
+        if cap:
+            extra = dict(extra, minibatches_per_epoch=cap)
         ag = _agent(12, 128, 2, 'tanh', **extra)
         assert ag.use_fused == (mode == 'fused')
         if data is None:
@@ -154,6 +158,7 @@ def test_fused_update_matches_the_torch_update_statistically():
         torch.cuda.synchronize()
         params[mode] = ag._flat['p'].clone()
     assert res['fused']['actor_steps'] == res['torch']['actor_steps'] and res['fused']['minibatches'] == res['torch']['minibatches']
+    assert res['fused']['minibatches'] == 2 * (cap or 8)
     for k in ('policy_loss', 'value_loss', 'entropy_loss', 'approx_kl'):
         assert abs(res['fused'][k] - res['torch'][k]) < 1e-4 + 1e-3 * abs(res['torch'][k]), (k, res)
     torch.testing.assert_close(params['fused'], params['torch'], rtol=0, atol=2e-4)

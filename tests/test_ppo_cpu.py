@@ -317,3 +317,18 @@ def test_ppo_collector_reproduces_the_reference_rollout_buffer(device):
     from safe_control_gym_amd.rarl import _normalised
     torch.testing.assert_close(_normalised(adv, mom), B['adv'][..., 0], rtol=1e-4, atol=1e-4)
     assert B['terminal_v'].abs().max() > 0 and (B['mask'] == 0).sum() == 20
+
+
+def test_partial_epochs_walk_only_the_first_k_minibatches_of_each_epoch():
+    """PPOConfig.extra['minibatches_per_epoch'] (bench.py's 65 536-env configuration): every epoch is still a fresh permutation of the
+    whole rollout, the update walks its first k minibatches — k optimiser steps per epoch, on every update path (the eager one here)."""
+    torch.manual_seed(0)
+    cfg = PPOConfig(hidden_dim=16, opt_epochs=3, mini_batch_size=64, target_kl=0.0, extra={'minibatches_per_epoch': 2})
+    ag = PPOAgent(12, 2, cfg, 'cpu')
+    full = PPOAgent(12, 2, PPOConfig(hidden_dim=16, opt_epochs=3, mini_batch_size=64, target_kl=0.0), 'cpu')
+    full.ac.load_state_dict(ag.ac.state_dict())
+    data = _data(512)
+    perms = [torch.randperm(512, generator=torch.Generator().manual_seed(k)).numpy() for k in range(3)]
+    res = ag.update(data, perms=perms)
+    assert res['minibatches'] == 3 * 2 and res['actor_steps'] == 6
+    assert full.update(data, perms=perms)['minibatches'] == 3 * 8
