@@ -106,7 +106,9 @@ class SACConfig:
 
 
 class DeviceReplay:
-    """SACBuffer (sac_utils.py:301-413) as device tensors; a push appends a whole vectorised step."""
+    """SACBuffer (sac_utils.py:301-413) as device tensors; a push appends a whole vectorised step.  The write position lives on the
+    device as well (`pos_t`), so a push is a fixed sequence of static-shape device operations — capturable in a HIP graph together with
+    the policy forward and the env step (SAC._collect_graph); `pos` / `size` are the host's mirror of it, advanced arithmetically."""
 
     def __init__(self, capacity, obs_dim, act_dim, device):
         f = dict(device=device, dtype=torch.float32)
@@ -117,20 +119,35 @@ class DeviceReplay:
         self.rew = torch.zeros(self.capacity, 1, **f)
         self.mask = torch.ones(self.capacity, 1, **f)
         self.pos, self.size = 0, 0
+        self.pos_t = torch.zeros((), dtype=torch.int64, device=device)          # `pos` on the device
         self.size_t = torch.zeros((), device=device)         # `size` as a device scalar: sampling inside a captured graph
         self.size_i32 = torch.zeros(1, dtype=torch.int32, device=device)       # (the fused update samples in its own kernel)
+        self._ar = None
 
-    def push(self, obs, act, rew, next_obs, mask):
+    def push_device(self, obs, act, rew, next_obs, mask):
+        """The device side of a push: rows pos .. pos + n - 1 (mod capacity) of the ring, then pos / size advance — no host value."""
         n = obs.shape[0]
         if n > self.capacity:
             raise ValueError('replay capacity smaller than one vectorised step')
-        idx = (torch.arange(n, device=obs.device) + self.pos) % self.capacity
-        self.obs[idx], self.act[idx], self.next_obs[idx] = obs, act, next_obs
-        self.rew[idx, 0], self.mask[idx, 0] = rew, mask
+        if self._ar is None or self._ar.shape[0] != n:
+            self._ar = torch.arange(n, device=self.obs.device)
+        idx = (self._ar + self.pos_t) % self.capacity
+        self.obs.index_copy_(0, idx, obs)
+        self.act.index_copy_(0, idx, act)
+        self.next_obs.index_copy_(0, idx, next_obs)
+        self.rew.index_copy_(0, idx, rew.reshape(n, 1))
+        self.mask.index_copy_(0, idx, mask.reshape(n, 1))
+        self.pos_t.add_(n).remainder_(self.capacity)
+        self.size_t.add_(float(n)).clamp_(max=float(self.capacity))
+        self.size_i32.add_(n).clamp_(max=self.capacity)
+
+    def advance_host(self, n):
         self.pos = (self.pos + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
-        self.size_t.fill_(float(self.size))
-        self.size_i32.fill_(self.size)
+
+    def push(self, obs, act, rew, next_obs, mask):
+        self.push_device(obs, act, rew, next_obs, mask)
+        self.advance_host(obs.shape[0])
 
     def state_dict(self):
         """SACBuffer.state_dict (sac_utils.py:330-338): the filled part of the ring + the write position."""
@@ -145,6 +162,7 @@ class DeviceReplay:
         for k in ('obs', 'act', 'rew', 'next_obs', 'mask'):
             getattr(self, k)[:n].copy_(sd[k].to(self.obs.device))
         self.pos, self.size = int(sd['pos']) % self.capacity, n
+        self.pos_t.fill_(self.pos)
         self.size_t.fill_(float(n))
         self.size_i32.fill_(n)
 
@@ -490,6 +508,8 @@ class SAC:
         self.reward_normalizer = (RewardStdNormalizer(cfg.gamma, self.device, clip=x.get('clip_reward', 10.0)) if x.get('norm_reward')
                                   else BaseNormalizer())
         self._normalise = bool(x.get('norm_obs') or x.get('norm_reward'))
+        if x.get('norm_reward'):        # eager: graphs captured later (and checkpoint loads, in place) share this storage
+            self.reward_normalizer.ret = torch.zeros(env.num_envs, dtype=torch.float64, device=self.device)
         spec = env.spec
         self.N, self.obs_dim, self.act_dim = env.num_envs, spec.obs_dim, spec.nu
         rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
@@ -498,21 +518,25 @@ class SAC:
         self.high = torch.as_tensor(spec.action_space.high, dtype=torch.float32, device=self.device)
         self.agent = SACAgent(self.obs_dim, self.act_dim, self.low, self.high, cfg, self.device)
         self.buffer = DeviceReplay(cfg.max_buffer_size, self.obs_dim, self.act_dim, self.device)
-        self.obs = self.obs_normalizer(env.reset_tensors()).clone()         # sac.py:103-104
+        self.obs = self.obs_normalizer(env.reset_tensors()).clone()         # sac.py:103-104; persistent storage (captured graphs alias it)
         self.total_steps = 0
         self._since_update = 0
+        self._graph_collect = self.device.type == 'cuda' and bool(cfg.extra.get('cuda_graphs', True))
+        self._collect_graphs = {}
 
-    def train_step(self):
-        cfg, env = self.cfg, self.env
-        t0 = time.perf_counter()
-        if self.total_steps < cfg.warm_up_steps:       # action_space.sample() per env (sac.py:276-277)
+    # ---- one vectorised env step into the replay ring (sac.py:273-311)
+    @torch.no_grad()
+    def _collect_body(self, warm):
+        """Static-shape device operations only: action (uniform during warm-up, else a sample of the policy), env step kernel,
+        time-limit fix-up, normalisers, ring push, the next observation into the persistent `self.obs`."""
+        env = self.env
+        if warm:                                        # action_space.sample() per env (sac.py:276-277)
             act = self.low + (self.high - self.low) * torch.rand(self.N, self.act_dim, device=self.device)
         else:
             act = self.agent.ac.act(self.obs)
         out = env.step_tensors(act)
         done = out.done.bool()
         trunc = (out.flags & 1).bool() & done
-        # time truncation is not termination: the stored next state is the terminal observation, mask 1 (sac.py:287-305)
         if self._normalise:
             # sac.py:281-297, in upstream's order: next_obs, then the reward (running returns, its index-array reset), then the
             # terminal observations of the TRUNCATED envs only — each call updates the running statistics
@@ -522,10 +546,41 @@ class SAC:
             term_n = self.obs_normalizer(out.terminal_obs, mask=trunc)
         else:
             obs_n, rew, term_n = out.obs, out.reward, out.terminal_obs
+        # time truncation is not termination: the stored next state is the terminal observation, mask 1 (sac.py:287-305)
         next_obs = torch.where(trunc[:, None], term_n, obs_n)
         mask = torch.where(trunc, torch.ones_like(out.reward), 1.0 - done.to(torch.float32))
-        self.buffer.push(self.obs, act, rew, next_obs, mask)
-        self.obs = obs_n.clone()
+        self.buffer.push_device(self.obs, act, rew, next_obs, mask)
+        self.obs.copy_(obs_n)
+
+    def _collect(self, warm):
+        """Eager, or (GPU, cfg.extra['cuda_graphs'] not off) ONE HIP-graph replay per vector step: the eager collector is ~45 small
+        launches per step — policy MLP, sampling, env kernel, fix-up, five ring writes — i.e. host-launch bound (0.7 ms of a 2.7 ms
+        vector step at 2048 envs x 16 gradient steps).  One graph per phase (warm-up / policy), captured after two eager steps of
+        that phase and re-captured after env.seed() (the Philox key is a kernel argument)."""
+        if not self._graph_collect:
+            self._collect_body(warm)
+            return
+        key = (bool(warm), getattr(self.env, 'seed_epoch', 0), id(self.buffer))
+        st = self._collect_graphs.get(key)
+        if st is None:
+            st = self._collect_graphs[key] = {'eager': 0, 'g': None}
+        if st['g'] is None:
+            if st['eager'] < 2:
+                st['eager'] += 1
+                self._collect_body(warm)
+                return
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._collect_body(warm)
+            st['g'] = g
+        st['g'].replay()
+
+    def train_step(self):
+        cfg = self.cfg
+        t0 = time.perf_counter()
+        self._collect(self.total_steps < cfg.warm_up_steps)
+        self.buffer.advance_host(self.N)
         world = parallel.world_size()
         self.total_steps += self.N * world
         self._since_update += self.N * world
@@ -569,12 +624,17 @@ class SAC:
                 if f'{name}_normalizer_count' in state:
                     nz.rms.count.fill_(state[f'{name}_normalizer_count'])
         if 'reward_normalizer_ret' in state and hasattr(self.reward_normalizer, 'rms'):
-            self.reward_normalizer.ret = state['reward_normalizer_ret'].to(self.device)
+            ret = state['reward_normalizer_ret'].to(self.device)
+            if self.reward_normalizer.ret is not None and self.reward_normalizer.ret.shape == ret.shape:
+                self.reward_normalizer.ret.copy_(ret)               # in place: the collector's graphs alias this tensor
+            else:
+                self.reward_normalizer.ret = ret
+                self._collect_graphs = {}
         if training and 'total_steps' in state:
             self.total_steps = int(state['total_steps'])
             self._since_update = int(state.get('since_update', 0))
             if 'obs' in state:
-                self.obs = state['obs'].to(self.device).clone()
+                self.obs.copy_(state['obs'].to(self.device))              # in place: the collector's graphs alias this tensor
             if 'env_random_state' in state:
                 self.env.set_env_random_state(state['env_random_state'])
             rs = state.get('random_state')

@@ -402,3 +402,44 @@ def test_async_evaluator_matches_blocking_evaluation_and_overlaps_training():
     assert aev.launch(tag=3) and aev.poll(wait=True)['ep_return'] == pytest.approx(ref2['ep_return'], rel=1e-6)
     for e in (env, ev_env, ev_env2):
         e.close()
+
+
+@pytest.mark.parametrize('norm', [False, True], ids=['plain', 'normalised'])
+def test_sac_graph_collector_equals_the_eager_collector(norm):
+    """SAC.train_step's collector as ONE HIP-graph replay per vector step (policy / uniform action, env step kernel, time-limit fix-up,
+    normalisers, device-side ring push) against the same body run eagerly: warm-up and policy phases (two eager steps, then capture +
+    replays, per phase), short episodes so that truncations and auto-resets occur, a ring that wraps.  Same seeds -> same Philox
+    draws on both sides (torch's graph-safe generator): ring contents, write position, current observation and the normalisers'
+    statistics must agree."""
+    from safe_control_gym_amd.sac import SAC, SACConfig
+    N = 256
+
+    def run(graphs):
+        env = _env('quadrotor_2D_track', N, episode_len_sec=0.12)               # 6-step episodes
+        extra = {'cuda_graphs': graphs}
+        if norm:
+            extra.update(norm_obs=True, norm_reward=True, clip_obs=5.0)
+        cfg = SACConfig(hidden_dim=32, activation='relu', warm_up_steps=5 * N, train_interval=10 ** 9, train_batch_size=64,
+                        max_buffer_size=9 * N, extra=extra)
+        torch.manual_seed(123)
+        sac = SAC(env, cfg, seed=7)
+        assert sac._graph_collect == graphs
+        for _ in range(12):                                                     # 5 warm-up + 7 policy steps; 12 N pushes into 9 N slots
+            assert 'updates' not in sac.train_step()
+        torch.cuda.synchronize()
+        b = sac.buffer
+        st = {k: getattr(b, k).clone() for k in ('obs', 'act', 'rew', 'next_obs', 'mask')}
+        st.update(obs_now=sac.obs.clone(), pos=b.pos, size=b.size, pos_t=int(b.pos_t), size_i32=int(b.size_i32), total=sac.total_steps,
+                  graphs=sorted(k[0] for k, v in sac._collect_graphs.items() if v['g'] is not None))
+        if norm:
+            st.update(mean=sac.obs_normalizer.rms.mean.clone(), var=sac.obs_normalizer.rms.var.clone(), ret=sac.reward_normalizer.ret.clone(),
+                      rvar=sac.reward_normalizer.rms.var.clone())
+        env.close()
+        return st
+    g, e = run(True), run(False)
+    assert g['graphs'] == [False, True] and e['graphs'] == []                   # both phases were captured / none was
+    assert (g['pos'], g['size'], g['pos_t'], g['size_i32'], g['total']) == (e['pos'], e['size'], e['pos_t'], e['size_i32'], e['total']) \
+        == (3 * N, 9 * N, 3 * N, 9 * N, 12 * N)
+    assert (g['mask'] == 0).sum() > 0 and (g['mask'] == 1).sum() > 0
+    for k in ('obs', 'act', 'rew', 'next_obs', 'mask', 'obs_now') + (('mean', 'var', 'ret', 'rvar') if norm else ()):
+        torch.testing.assert_close(g[k], e[k], rtol=1e-5, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
