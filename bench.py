@@ -590,7 +590,7 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
         scfg = SACConfig(hidden_dim=128, activation='relu', train_batch_size=batch, actor_lr=lr, critic_lr=lr, warm_up_steps=warm_up_steps * world,
                          train_interval=envs * world, max_buffer_size=buffer, extra={'updates_per_step': updates_per_step})
         sac = SAC(env, scfg, seed=seed)
-        det = Det(sac.agent.ac)
+        det = sac.agent.deterministic_policy()          # (fused agents: the library's batched actor, one launch per evaluation step)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         t_first, t_both, best, it, streak, n_grad = None, None, -1e30, 0, 0, 0

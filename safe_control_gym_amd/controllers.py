@@ -239,7 +239,7 @@ class SAC(HipController):
         self.env = self._vec(n, self.seed)
         self.eval_env = None
         self.impl = sac.SAC(self.env, scfg, seed=self.seed)
-        self._det = _Deterministic(self.impl.agent.ac)      # one object: evaluate() caches its captured graph per policy object
+        self._det = self.impl.agent.deterministic_policy()  # one object: evaluate() caches its captured graph per policy object
 
     def _act_module(self):
         return self._det

@@ -204,6 +204,10 @@ class SACAgent:
                           and _sac.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._flat = self._flatten(low, high) if self.use_fused else None
         self._fused = None
+        if self.use_fused:          # one-time kernel attributes NOW (not a stream operation: must not fall into a later graph capture)
+            with torch.cuda.device(self.log_alpha.device):
+                D = _sac.lib(obs_dim, cfg.hidden_dim, act_dim, cfg.activation)
+                _sac.check(D, D.scg_sac_prepare())
         kw = {'capturable': True} if self.use_graphs else {}
         self.actor_opt = torch.optim.Adam(self.ac.actor.parameters(), cfg.actor_lr, **kw)
         self.critic_opt = torch.optim.Adam(list(self.ac.q1.parameters()) + list(self.ac.q2.parameters()), cfg.critic_lr, **kw)
@@ -364,6 +368,42 @@ class SACAgent:
                 fl['v'][o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
                 n_steps = float(st['step'])
             fl['steps'][which] = n_steps
+
+    # ---- deterministic actions for evaluation
+    @torch.no_grad()
+    def act_deterministic(self, obs):
+        """`ac.act(obs, deterministic=True)` (sac_utils.py:209-215: tanh of the mean, rescaled to the action space).  On the fused path ONE
+        launch of the library's batched actor on the flat parameter vector (scg_sac_act, exact-f32 MFMA) instead of ~9 PyTorch kernels:
+        the evaluation loop is 250 sequential (policy, env step) pairs on a 256-env batch, i.e. launch-bound."""
+        if not self.use_fused or obs.dtype != torch.float32 or obs.dim() != 2:
+            return self.ac.act(obs, deterministic=True)
+        import ctypes as C
+        from safe_control_gym_amd import _sac
+        fl = self._flat
+        D = _sac.lib(self.obs_dim, self.cfg.hidden_dim, self.act_dim, self.cfg.activation)
+        if '_act_bounds' not in fl:
+            fl['_act_bounds'] = ((C.c_float * 4)(*(fl['low'] + [0.0] * (4 - self.act_dim))), (C.c_float * 4)(*(fl['high'] + [0.0] * (4 - self.act_dim))))
+        lo, hi = fl['_act_bounds']
+        x = obs.contiguous()
+        out = torch.empty(x.shape[0], self.act_dim, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _sac.check(D, D.scg_sac_act(fl['p'].data_ptr(), C.byref(fl['actor']), lo, hi, x.data_ptr(), x.shape[0], out.data_ptr(),
+                                        C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return out
+
+    def deterministic_policy(self):
+        """An object with `.act(obs)` for ppo.evaluate / the controllers (one per agent: evaluate caches its captured graph per policy object)."""
+        if getattr(self, '_det_policy', None) is None:
+            agent = self
+
+            class _Det:
+                ac = agent.ac
+
+                @staticmethod
+                def act(obs):
+                    return agent.act_deterministic(obs)
+            self._det_policy = _Det()
+        return self._det_policy
 
     # same keys as the reference's SACAgent (sac_utils.py:85-108), so its checkpoints load directly; the action bounds are
     # buffers here (not in upstream's state dict), hence strict=False

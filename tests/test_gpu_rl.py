@@ -443,3 +443,38 @@ def test_sac_graph_collector_equals_the_eager_collector(norm):
     assert (g['mask'] == 0).sum() > 0 and (g['mask'] == 1).sum() > 0
     for k in ('obs', 'act', 'rew', 'next_obs', 'mask', 'obs_now') + (('mean', 'var', 'ret', 'rvar') if norm else ()):
         torch.testing.assert_close(g[k], e[k], rtol=1e-5, atol=1e-5, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_sac_evaluation_with_the_fused_deterministic_actor_equals_the_torch_policy():
+    """ppo.evaluate driven by SACAgent.deterministic_policy() (scg_sac_act: one launch per evaluation step on the flat parameters)
+    against the same evaluation with the torch modules: same episodes, returns to float32 noise; and the packed accumulators of
+    evaluate() still expose per-env totals (controllers.run reads them)."""
+    from safe_control_gym_amd.ppo import evaluate
+    from safe_control_gym_amd.sac import SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    e1 = _env('quadrotor_3D_track', 64, randomized_init=False)
+    e2 = _env('quadrotor_3D_track', 64, randomized_init=False)
+    spec = e1.spec
+    low = torch.as_tensor(spec.action_space.low, dtype=torch.float32, device=dev)
+    high = torch.as_tensor(spec.action_space.high, dtype=torch.float32, device=dev)
+    torch.manual_seed(2)
+    ag = SACAgent(spec.obs_dim, spec.nu, low, high, SACConfig(hidden_dim=128, activation='relu'), dev)
+    assert ag.use_fused
+    obs = torch.randn(300, spec.obs_dim, device=dev)
+    torch.testing.assert_close(ag.act_deterministic(obs), ag.ac.act(obs, deterministic=True), rtol=1e-4, atol=1e-5)
+
+    class Torch:
+        ac = ag.ac
+
+        @staticmethod
+        def act(o):
+            return ag.ac.act(o, deterministic=True)
+    a = evaluate(ag.deterministic_policy(), e1)
+    b = evaluate(Torch(), e2)
+    assert a['episodes'] == b['episodes'] == 64
+    for k in ('ep_return', 'ep_length', 'ep_mse', 'ep_constraint_violation'):
+        assert a[k] == pytest.approx(b[k], rel=5e-3, abs=5e-3), (k, a[k], b[k])         # (a termination one step apart in one env of 64)
+    acc = e1._eval_cache['acc']
+    assert acc['ret'].shape == (64,) and float(acc['count'].sum()) == 64 and float(acc['length'].min()) >= 1
+    assert ag.deterministic_policy() is ag.deterministic_policy()
+    e1.close(); e2.close()
