@@ -491,13 +491,23 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
             parallel.broadcast_(t, 0)
             target = float(t.item())
     first, both, its, best_all, final = [], [], [], [], []
-    for seed in range(1, seeds + 1):
-        env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
-        eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=seed * 111, return_numpy=False, policy=pol, **ev_cfg)
-        pcfg = PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=target_kl,
+
+    def config():
+        return PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=target_kl,
                          entropy_coef=0.01, opt_epochs=epochs, mini_batch_size=minibatch, actor_lr=lr, critic_lr=lr,
                          rollout_batch_size=envs, rollout_steps=rollout_steps,
                          extra={'minibatches_per_epoch': mb_per_epoch} if mb_per_epoch else {})
+    # One untimed iteration on a scratch instance (seed 0) before the first clock starts: the process's one-time costs — loading the
+    # learner / rollout code objects, kernel attributes, first launches — were 0.45 s of the first seed's first iteration
+    # (tools/ppo_iter_times.py: 455 ms, then 6.4 ms per iteration; the second seed's first iteration: 6.4 ms) and are not training.
+    w_env = HipVecEnv(env_id, envs, seed=0, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
+    PPO(w_env, config(), seed=0).train_step()
+    torch.cuda.synchronize()
+    w_env.close()
+    for seed in range(1, seeds + 1):
+        env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
+        eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=seed * 111, return_numpy=False, policy=pol, **ev_cfg)
+        pcfg = config()
         ppo = PPO(env, pcfg, seed=seed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -545,7 +555,9 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
                      + f', lr {lr:g}, '
                      f'target_kl {target_kl:g}, GAE 0.95, gamma 0.99, ent 0.01',
             'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA); every iteration\'s weights evaluated by the fused '
-                    'deterministic rollout on a second stream'}
+                    'deterministic rollout on a second stream',
+            'untimed_warmup': 'one train_step of a scratch instance (seed 0) before the first clock: code-object loads and first launches, '
+                              '0.45 s once per process'}
 
 
 def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, lr=1e-3, warm_up_steps=65536, eval_every=50,
@@ -585,6 +597,17 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
     evs = [evaluate(det0, eval_env) for _ in range(4)]
     target = sum(e['ep_return'] for e in evs) / len(evs)
     first, both, best_all, steps_all, grads_all, rate = [], [], [], [], [], []
+    # untimed: a scratch instance (seed 0) takes a few vector steps, gradient steps and one evaluation-sized policy call, so that the
+    # process's one-time costs (code-object loads, kernel attributes, first launches) are not inside the first seed's clock
+    w_env = HipVecEnv(env_id, envs, seed=0, env_id_offset=rank * envs, return_numpy=False, **cfg)
+    w = SAC(w_env, SACConfig(hidden_dim=128, activation='relu', train_batch_size=batch, actor_lr=lr, critic_lr=lr, warm_up_steps=envs * world,
+                             train_interval=envs * world, max_buffer_size=8 * envs, extra={'updates_per_step': updates_per_step}), seed=0)
+    for _ in range(6):
+        w.train_step()
+    w.agent.deterministic_policy().act(w.obs)
+    torch.cuda.synchronize()
+    w_env.close()
+    del w
     for seed in range(1, seeds + 1):
         env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, **cfg)
         scfg = SACConfig(hidden_dim=128, activation='relu', train_batch_size=batch, actor_lr=lr, critic_lr=lr, warm_up_steps=warm_up_steps * world,

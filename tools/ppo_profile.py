@@ -13,6 +13,7 @@ def main():
     ap.add_argument('--epochs', type=int, default=4)
     ap.add_argument('--minibatch', type=int, default=65536)
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--mb-per-epoch', type=int, default=None, help='partial epochs (PPOConfig.extra minibatches_per_epoch)')
     ap.add_argument('--no-fused', action='store_true')
     ap.add_argument('--fused-rollout', action='store_true')
     args = ap.parse_args()
@@ -27,7 +28,8 @@ def main():
     eval_env = HipVecEnv(env_id, 256, seed=222, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
     pcfg = PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, target_kl=0.03, opt_epochs=args.epochs,
                      mini_batch_size=args.minibatch, actor_lr=2e-3, critic_lr=2e-3, rollout_batch_size=args.envs,
-                     rollout_steps=args.rollout_steps, extra={'fused_update': not args.no_fused, 'fused_rollout': args.fused_rollout})
+                     rollout_steps=args.rollout_steps, extra={'fused_update': not args.no_fused, 'fused_rollout': args.fused_rollout,
+                            **({'minibatches_per_epoch': args.mb_per_epoch} if args.mb_per_epoch else {})})
     ppo = PPO(env, pcfg, seed=2)
     tot = {'collect': 0.0, 'update': 0.0, 'eval': 0.0}
     for it in range(args.iters + 3):

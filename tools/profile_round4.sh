@@ -5,10 +5,11 @@
 #       --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE, --pmc SQ_INSTS_VALU SQ_WAVES
 #   K-steps-per-launch kernels (tools/seq_profile.py): step_sequence_kernel K = 8 all outputs / K = 32 collector outputs, and
 #       rollout_policy_kernel (PPO's fused collector): the same four passes
-#   learner iterations (PPO 16 384 / 65 536 envs, SAC): kernel trace only
+#   learner iterations (PPO 16 384 / 65 536 envs, SAC): kernel trace only   (SCG_PROFILE_LEARNERS_ONLY=1: only these; SCG_PROFILE_ENV_ONLY=1: skip them)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 B="--no-cpu-baseline --no-secondary --ppo-seeds 0 --sac-seeds 0"
+if [ -z "$SCG_PROFILE_LEARNERS_ONLY" ]; then
 for spec in quadrotor_2D_track:65536:f32 cartpole_stab:65536:f32 quadrotor_3D_track:65536:f32 quadrotor_3D_track_disturbed:65536:f32 quadrotor_2D_track:65536:f64; do
   IFS=: read T N DT <<< "$spec"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_${T}_${DT}_$N -o p -- \
@@ -26,11 +27,12 @@ for M in sequence_all sequence_collector rollout_policy; do
         python tools/seq_profile.py --mode $M --reps 30 > $OUT/pmc_${C}_$M.log 2>&1 < /dev/null
   done
 done
+fi
 if [ -z "$SCG_PROFILE_ENV_ONLY" ]; then
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ppo_iteration -o p -- \
-    python tools/ppo_profile.py --fused-rollout --iters 30 --minibatch 16256 > $OUT/ppo_iteration.log 2>&1 < /dev/null
+    python tools/ppo_profile.py --fused-rollout --iters 30 --epochs 2 --minibatch 16256 > $OUT/ppo_iteration.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ppo_iteration_65536 -o p -- \
-    python tools/ppo_profile.py --fused-rollout --envs 65536 --iters 12 --minibatch 65024 > $OUT/ppo_iteration_65536.log 2>&1 < /dev/null
+    python tools/ppo_profile.py --fused-rollout --envs 65536 --iters 20 --epochs 2 --minibatch 16256 --mb-per-epoch 32 > $OUT/ppo_iteration_65536.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sac_iteration -o p -- \
     python tools/sac_time_to_reward.py --budget 12 --eval-every 100000 > $OUT/sac_iteration.log 2>&1 < /dev/null
 fi
