@@ -80,6 +80,15 @@ int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, 
                    float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, uint32_t* d_block_counter,
                    void* stream);
 
+/* One optimiser step of PPOAgent.update (ppo_utils.py:113-146) on ONE GPU in two launches: the gradient kernel of scg_ppo_grad, then
+ * a kernel that sums the workgroups' partial gradients AND applies the two gated Adam steps of scg_adam_gated element by element (each
+ * parameter is summed and stepped by exactly one thread; d_grad / d_stats are filled as by scg_ppo_grad; d_params is updated in place).
+ * The step counts are double-buffered: read from d_steps_in [2], written to d_steps_out [2] (two different buffers — the caller
+ * alternates them) — which is what lets the kernel do without a device-scope fence.  Data-parallel callers, whose gradients are
+ * all-reduced between the two halves, keep scg_ppo_grad + scg_adam_gated. */
+int scg_ppo_step(const scg_ppo_grad_args* args, float* d_m, float* d_v, float lr_actor, float lr_critic, const float* d_steps_in,
+                 float* d_steps_out, float target_kl, float* d_stats_acc, void* stream);
+
 /* d_out[i] = pi(i) for i < count, pi a keyed pseudo-random permutation of [0, n) (count <= n): the shuffled row indices of
  * one epoch's minibatches (SubsetRandomSampler + BatchSampler(drop_last=True), ppo_utils.py:358-371), one launch. */
 int scg_random_permutation(int32_t* d_out, int n, int count, uint64_t key, void* stream);

@@ -81,6 +81,8 @@ def lib(obs_dim, hidden, act_dim, activation):
     D.scg_ppo_grad_workspace_bytes.argtypes = [C.c_int]
     D.scg_mlp_forward.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     D.scg_ppo_grad.argtypes = [C.POINTER(PpoGradArgs), C.c_void_p]
+    D.scg_ppo_step.argtypes = [C.POINTER(PpoGradArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                               C.c_void_p]
     D.scg_adam_gated.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     D.scg_random_permutation.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p]

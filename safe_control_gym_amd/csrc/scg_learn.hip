@@ -475,6 +475,17 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
         for (int m = 16; m >= 1; m >>= 1) { v0 += __shfl_xor(v0, m, 64); v1 += __shfl_xor(v1, m, 64); }
         if (lane == 0) { gl_add(glw + G::STAT + 0, v0); gl_add(glw + G::STAT + 1, v1); }
+        // entropy_loss = -sum_a (0.5 + 0.5 log(2 pi) + logstd_a) of the parameters THIS launch read: slot STAT + 2 of one partial vector
+        // (every other workgroup contributes 0), so that the reduction needs no look at the parameters — which the fused reduction + Adam
+        // kernel updates while it sums
+        if constexpr (ACTOR) {
+            if (lane == 0 && wave == 0 && blockIdx.x == 0) {
+                float ent = 0.0f;
+#pragma unroll
+                for (int a = 0; a < NOUT; ++a) ent -= 1.4189385332046727f + logstd[a];
+                gl_add(glw + G::STAT + 2, ent);
+            }
+        }
     }
     __syncthreads();                                                    // every wave is done with the weight image
     if constexpr (private_dw1()) {
@@ -589,9 +600,76 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
     } else if (d == -3 && net == 0) {                       // approx-KL: rides in the gradient buffer's last slot
         R.grad[R.n_params] = s;
         R.stats[3] = s;
-        float ent = 0.0f;                                   // entropy_loss = -sum_a (0.5 + 0.5 log(2 pi) + logstd_a)
-        for (int a = 0; a < NU; ++a) ent -= 1.4189385332046727f + R.params[R.logstd_off + a];
-        R.stats[2] = ent;
+    } else if (d == -4 && net == 0) {                       // entropy_loss (written by one workgroup of the gradient kernel)
+        R.stats[2] = s;
+    }
+}
+
+// Single-GPU optimiser step: the reduction above AND the two gated Adam steps of adam_gated_kernel in ONE launch — every parameter's
+// gradient is summed by exactly one thread, which steps that parameter at once (no trip of the gradient through memory, no second
+// launch, no device-scope fence: the step counts are double-buffered, read from `steps_in` by everybody, written to `steps_out` by
+// the one thread that owns the approx-KL word).  The gate needs the minibatch's approx-KL before the first actor element steps:
+// every block sums that ONE word of the workgroups' partials itself, all in the same fixed order, and the owner of the word
+// reports exactly that value.  Data-parallel callers keep scg_ppo_grad -> all-reduce -> scg_adam_gated.
+struct StepArgs {
+    ReduceArgs R;
+    float* p; float* m; float* v; float lr_actor, lr_critic;
+    const float* steps_in; float* steps_out; float target_kl; float* stats_acc;
+};
+__global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const StepArgs S) {
+    __shared__ float part[4][64];
+    __shared__ float klw[4];
+    const ReduceArgs& R = S.R;
+    const int net = blockIdx.y;
+    const int kl_ = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl_;
+    const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
+    {
+        constexpr int KW = GradLds<NU>::STAT + 1;           // the actor's approx-KL word
+        float v = 0.0f;
+        for (int g = threadIdx.x; g < R.n_wg; g += 256) v += R.partials[((size_t)g * 2 + 0) * PARTIAL_STRIDE + KW];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (kl_ == 0) klw[grp] = v;
+    }
+    float s = 0.0f;
+    if (k < words) {
+#pragma unroll 8
+        for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
+    }
+    part[grp][kl_] = s;
+    __syncthreads();
+    if (grp != 0 || k >= words) return;
+    s = (part[0][kl_] + part[1][kl_]) + (part[2][kl_] + part[3][kl_]);
+    const float kl = (klw[0] + klw[1]) + (klw[2] + klw[3]);
+    const bool gate = S.target_kl <= 0.0f || kl <= 1.5f * S.target_kl;
+    const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
+    if (d >= 0) {
+        if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
+        R.grad[d] = s;
+        const bool critic = net == 1;
+        if (critic || gate) {
+            const float t = S.steps_in[critic ? 1 : 0] + 1.0f;
+            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+            const float m = b1 * S.m[d] + (1.0f - b1) * s;
+            const float v = b2 * S.v[d] + (1.0f - b2) * s * s;
+            S.m[d] = m; S.v[d] = v;
+            const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+            const float lr = critic ? S.lr_critic : S.lr_actor;
+            S.p[d] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
+        }
+    } else if (d == -2) {                                   // loss sum
+        R.stats[net == 0 ? 0 : 1] = s;
+        if (S.stats_acc) S.stats_acc[net == 0 ? 0 : 1] += s;
+    } else if (d == -3 && net == 0) {                       // approx-KL (+ the step's bookkeeping: this thread is unique in the launch)
+        R.grad[R.n_params] = kl;
+        R.stats[3] = kl;
+        S.steps_out[0] = S.steps_in[0] + (gate ? 1.0f : 0.0f);
+        S.steps_out[1] = S.steps_in[1] + 1.0f;
+        if (S.stats_acc) { S.stats_acc[3] += kl; S.stats_acc[4] += gate ? 1.0f : 0.0f; }
+    } else if (d == -4 && net == 0) {                       // entropy_loss
+        R.stats[2] = s;
+        if (S.stats_acc) S.stats_acc[2] += s;
     }
 }
 
@@ -736,6 +814,35 @@ extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
     R.partials = G.partials; R.n_wg = a->n_workgroups; R.actor = a->actor; R.critic = a->critic; R.logstd_off = a->logstd_off;
     R.n_params = a->n_params; R.entropy_coef = a->entropy_coef; R.params = a->d_params; R.grad = a->d_grad; R.stats = a->d_stats;
     ppo_reduce_kernel<<<dim3((PARTIAL_STRIDE + 63) / 64, 2), dim3(256), 0, st>>>(R);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int scg_ppo_step(const scg_ppo_grad_args* a, float* d_m, float* d_v, float lr_actor, float lr_critic, const float* d_steps_in,
+                            float* d_steps_out, float target_kl, float* d_stats_acc, void* stream) {
+    if (!a || !a->d_params || !a->d_obs || !a->d_act || !a->d_logp_old || !a->d_adv || !a->d_ret || !a->d_v_old || !a->d_idx ||
+        !a->d_workspace || !a->d_grad || !a->d_stats || !d_m || !d_v || !d_steps_in || !d_steps_out || d_steps_in == d_steps_out)
+        return fail(-1, "scg_ppo_step: NULL argument (or steps_in == steps_out: the step counts are double-buffered)");
+    if (a->batch <= 0 || a->batch % 32 != 0) return fail(-1, "scg_ppo_step: the minibatch size must be a positive multiple of 32");
+    if (a->n_workgroups <= 0) return fail(-1, "scg_ppo_step: n_workgroups must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    GradArgs G;
+    G.params = a->d_params; G.actor = a->actor; G.critic = a->critic; G.logstd_off = a->logstd_off;
+    G.obs = a->d_obs; G.act = a->d_act; G.logp_old = a->d_logp_old; G.adv = a->d_adv; G.ret = a->d_ret; G.v_old = a->d_v_old;
+    G.idx = a->d_idx; G.batch = a->batch; G.clip_param = a->clip_param; G.use_clipped_value = a->use_clipped_value;
+    G.partials = (float*)a->d_workspace;
+    const size_t bytes = grad_lds_words() * sizeof(float);
+    static scg::PerDeviceOnce set_g;
+    int dev;
+    if (set_g.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_g.commit(dev); }
+    ppo_grad_kernel<<<dim3(a->n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
+    HIP_TRY(hipGetLastError());
+    StepArgs S;
+    S.R.partials = G.partials; S.R.n_wg = a->n_workgroups; S.R.actor = a->actor; S.R.critic = a->critic; S.R.logstd_off = a->logstd_off;
+    S.R.n_params = a->n_params; S.R.entropy_coef = a->entropy_coef; S.R.params = a->d_params; S.R.grad = a->d_grad; S.R.stats = a->d_stats;
+    S.p = const_cast<float*>(a->d_params); S.m = d_m; S.v = d_v; S.lr_actor = lr_actor; S.lr_critic = lr_critic;
+    S.steps_in = d_steps_in; S.steps_out = d_steps_out; S.target_kl = target_kl; S.stats_acc = d_stats_acc;
+    ppo_reduce_adam_kernel<<<dim3((PARTIAL_STRIDE + 63) / 64, 2), dim3(256), 0, st>>>(S);
     HIP_TRY(hipGetLastError());
     return 0;
 }

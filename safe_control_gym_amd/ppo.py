@@ -190,6 +190,7 @@ class PPOAgent:
         self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
                           and _learn.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._fused = None
+        self._fused_step_ok = bool(cfg.extra.get('fused_step', True))      # (False: scg_ppo_grad + scg_adam_gated also on one rank — A/B, tests)
 
     # ---- graphed update -------------------------------------------------------------------------------------
     def _flatten(self):
@@ -273,6 +274,23 @@ class PPOAgent:
             float(cfg.actor_lr), float(cfg.critic_lr), fl['steps'].data_ptr(), float(cfg.target_kl),
             F['stats_acc'].data_ptr(), F['stats'].data_ptr(), F['adam_sync'].data_ptr(), st))
 
+    def _fused_step(self, F):
+        """One optimiser step on ONE rank in two launches (scg_ppo_step): gradient kernel, then reduction + gated Adam in one kernel.
+        The step counts are double-buffered — bank 0 is `_flat['steps']` (what checkpoints and the other update paths read), bank 1 a
+        scratch pair; `_update_fused` leaves the current counts in bank 0."""
+        from safe_control_gym_amd import _learn
+        fl, cfg, C = self._flat, self.cfg, F['C']
+        if 'steps_b' not in fl:
+            fl['steps_b'] = torch.zeros(2, device=self.device)
+            fl['bank'] = 0
+        banks = (fl['steps'], fl['steps_b'])
+        src, dst = banks[fl['bank']], banks[1 - fl['bank']]
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _learn.check(F['lib'], F['lib'].scg_ppo_step(C.byref(F['args']), fl['m'].data_ptr(), fl['v'].data_ptr(), float(cfg.actor_lr),
+                                                     float(cfg.critic_lr), src.data_ptr(), dst.data_ptr(), float(cfg.target_kl),
+                                                     F['stats_acc'].data_ptr(), st))
+        fl['bank'] = 1 - fl['bank']
+
     def _capped(self, n_mb):
         """Minibatches walked per epoch: all of the shuffled epoch, or the first extra['minibatches_per_epoch'] of them (every update path)."""
         cap = self.cfg.extra.get('minibatches_per_epoch')
@@ -318,12 +336,18 @@ class PPOAgent:
                     perm = perm.view(n_mb, mb)
                 for j in range(n_mb):
                     F['args'].d_idx = perm[j].data_ptr()
+                    if world == 1 and self._fused_step_ok:
+                        self._fused_step(F)                         # gradient kernel + (reduction and gated Adam in one launch)
+                        continue
                     self._fused_grad(F)
                     if world > 1:                                   # gradients of both networks + approx_kl, one collective
                         parallel.all_reduce_sum_(self._flat['g'])
                         self._flat['g'].div_(world)
                     self._fused_adam(F)
                 F['keep'] = perm                                    # (the index rows must outlive the queued launches)
+            if self._flat.get('bank'):                              # an odd number of fused steps: the counts are in the scratch bank
+                self._flat['steps'].copy_(self._flat['steps_b'])
+                self._flat['bank'] = 0
         st = (F['stats_acc'] / (cfg.opt_epochs * n_mb)).tolist()
         return {'policy_loss': st[0], 'value_loss': st[1], 'entropy_loss': st[2], 'approx_kl': st[3],
                 'actor_steps': int(round(st[4] * cfg.opt_epochs * n_mb)), 'minibatches': cfg.opt_epochs * n_mb}

@@ -18,7 +18,7 @@ for seed in (1, 2):
     env = HipVecEnv(env_id, 65536, seed=seed, return_numpy=False, policy=(128, 'tanh'), **cfg)
     ppo = PPO(env, PPOConfig(hidden_dim=128, activation='tanh', gamma=0.99, use_gae=True, gae_lambda=0.95, target_kl=0.03, entropy_coef=0.01,
                              opt_epochs=2, mini_batch_size=16256, actor_lr=2e-3, critic_lr=2e-3, rollout_batch_size=65536, rollout_steps=32,
-                             extra={'minibatches_per_epoch': 32}), seed=seed)
+                             extra={'minibatches_per_epoch': 32, 'fused_step': '--no-fused-step' not in sys.argv}), seed=seed)
     torch.cuda.synchronize()
     ts = []
     for it in range(40):
@@ -26,6 +26,6 @@ for seed in (1, 2):
         ppo.train_step()
         torch.cuda.synchronize()
         ts.append(1e3 * (time.perf_counter() - t0))
-    print(f'seed {seed}: first iterations ms', [round(t, 2) for t in ts[:6]], 'steady state ms (mean of 20..39)', round(sum(ts[20:]) / 20, 3),
+    print('fused_step' if ppo.agent._fused_step_ok else 'grad + adam', f'seed {seed}: first iterations ms', [round(t, 2) for t in ts[:6]], 'steady state ms (mean of 20..39)', round(sum(ts[20:]) / 20, 3),
           'start-up excess ms', round(sum(ts[:6]) - 6 * sum(ts[20:]) / 20, 1))
     env.close()
