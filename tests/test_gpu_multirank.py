@@ -233,3 +233,31 @@ def test_fused_sac_step_two_ranks_equal_one_process_on_the_joint_batch(tmp_path)
     assert (one._flat['targ'].cpu() - a['targ']).abs().max() <= 1e-4
     init_flat_moved = (p2[:-1] - one._flat['p'].cpu()[:-1]).abs().max() < 1.0 and (a['params'] - b['params']).abs().max() == 0
     assert init_flat_moved
+
+
+def test_rccl_backend_initialises_and_carries_the_collectives_with_one_rank():
+    """What a single GPU can show of the `nccl` (= RCCL) branch that the driver's N > 1 runs take: the backend initialises on this box
+    (librccl loads, the dmabuf IPC mode is accepted), and the three collectives the learning legs use — all-reduce (gradients), broadcast
+    (parameters, stop flag), barrier — run on device tensors through `parallel.py`'s own helpers.  One rank: no peer traffic, but every
+    call goes through RCCL's code path instead of the gloo staging the other tests of this file use."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from safe_control_gym_amd import parallel
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+assert dist.get_backend() == 'nccl' and not parallel._through_host(torch.zeros(1, device='cuda'))
+g = torch.arange(36742, dtype=torch.float32, device='cuda')            # the PPO pair's flat gradient + approx-KL slot
+dist.all_reduce(g); parallel.broadcast_(g, 0); dist.barrier(); torch.cuda.synchronize()
+assert float(g[-1]) == 36741.0
+m = torch.nn.Linear(4, 3).cuda(); parallel.broadcast_parameters([m])
+b = parallel.FlatBucket(list(m.parameters()), n_scalars=1)
+for p in m.parameters(): p.grad = torch.ones_like(p)
+b.pack([torch.tensor(0.5, device='cuda')]); b.all_reduce_mean(); assert float(b.unpack()[0]) == 0.5
+dist.destroy_process_group()
+print('RCCL_ONE_RANK_OK')
+'''
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and 'RCCL_ONE_RANK_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
