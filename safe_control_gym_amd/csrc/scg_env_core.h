@@ -629,9 +629,14 @@ struct EnvOps {
         return slot_in<V>(r, soff, lane_index).template with<STAUX>();
     }
     // speculative reset draws inside the integrator (PreDraw): specialised float builds whose reset is exactly the compact
-    // initial-state draw (-DSCG_NO_PREDRAW switches it off: A/B measurements)
+    // initial-state draw (-DSCG_NO_PREDRAW switches it off: A/B measurements).  CartPole only since round 4: its 50-substep loop is a
+    // long dependent chain whose issue gaps the Philox rounds fill (5.81 us without, 5.50 with); the quadrotor loops got short
+    // (recurrence integrator) and the launches issue-bound (write-through stores), and there the 40-80 quarter-rate multiplies
+    // of the speculative rounds cost MORE than the divergent reset branch they save: Quadrotor2D 4.19 -> 4.02 us, Quadrotor3D
+    // 8.42 -> 8.26 us without them (same box, alternating, tools/sessions/s98; round 3, write-back stores: 0 / -0.5 %).
+    // Bit-identical either way: the speculative rounds produce rng_words()' words.
 #if defined(SCG_SPEC) && !defined(SCG_NO_PREDRAW)
-    static constexpr bool PRE = sizeof(T) == 4 && !DIST && (SYS == SCG_CARTPOLE || SYS == SCG_QUAD_2D || SYS == SCG_QUAD_3D) && scg_make_spec_cfg<T>().randomized_init != 0 &&
+    static constexpr bool PRE = sizeof(T) == 4 && !DIST && SYS == SCG_CARTPOLE && scg_make_spec_cfg<T>().randomized_init != 0 &&
                                 scg_make_spec_cfg<T>().init_compact != 0 && scg_make_spec_cfg<T>().per_env_params == 0 &&
                                 scg_make_spec_cfg<T>().auto_reset != 0 && scg_make_spec_cfg<T>().substeps % 10 == 0;
 #else
