@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 TASKS = ('quadrotor_2D_track', 'cartpole_stab', 'quadrotor_3D_track', 'quadrotor_3D_track_disturbed')
 
 
-def build(tag, src, flags, tasks):
+def build(tag, src, flags, tasks, sched=None):
     from safe_control_gym_amd import _lib
     from safe_control_gym_amd.env_config import EnvSpec
     from safe_control_gym_amd.registration import load_task
@@ -37,7 +37,7 @@ def build(tag, src, flags, tasks):
             f.write(text)
         out = so[:-3] + f'_{tag}.so'
         res = None
-        for sched in _lib.sched_flags(c):
+        for sched in ([[] if sched == 'default' else ['-mllvm', f'-amdgpu-sched-strategy={sched}']] if sched else _lib.sched_flags(c)):
             cmd = [_lib._hipcc(), '--offload-arch=gfx950', '-O3', '-ffp-contract=on', '-std=c++17', '-fPIC', '-shared', '-DSCG_SPEC', '-include', hdr,
                    f'-DSCG_SRC_HASH=0x{_lib.source_hash():016x}ULL', '-o', out] + flags.split() + sched + [os.path.join(src, s) for s in _lib.SOURCES]
             res = subprocess.run(cmd, capture_output=True, text=True)
@@ -107,13 +107,14 @@ def main():
     ap.add_argument('--src', default=None)
     ap.add_argument('--flags', default='')
     ap.add_argument('--tasks', default=TASKS[0])
+    ap.add_argument('--sched', default=None, help="build: machine-scheduler strategy of the variant instead of _lib.sched_flags' choice ('default' = LLVM's)")
     ap.add_argument('--rounds', type=int, default=2)
     ap.add_argument('--envs', default='65536', help='comma-separated env counts for the launch-period A/B')
     ap.add_argument('--no-gate', action='store_true', help='skip the one-step parity gate (e.g. on a second call for another env count)')
     a = ap.parse_args()
     tasks = TASKS if a.tasks == 'all' else tuple(a.tasks.split(','))
     if a.cmd == 'build':
-        build(a.tag, a.src, a.flags, tasks)
+        build(a.tag, a.src, a.flags, tasks, a.sched)
     elif a.cmd == 'run':
         run(a.tag, tasks, a.rounds, [int(e) for e in a.envs.split(',')], not a.no_gate)
     else:
