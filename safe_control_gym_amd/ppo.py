@@ -727,6 +727,10 @@ class PPO:
     def save(self, path, training=True):
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(self.checkpoint_state(training), path)
+
+    def checkpoint_state(self, training=True):
+        """The checkpoint dict (subclasses add their keys: Safe-Explorer's 'safety_layer')."""
         state = {'agent': self.agent.state_dict(), 'obs_normalizer': self.obs_normalizer.state_dict(),
                  'reward_normalizer': self.reward_normalizer.state_dict()}
         if getattr(self.reward_normalizer, 'ret', None) is not None:
@@ -739,7 +743,7 @@ class PPO:
                           'random_state': {'torch': torch.get_rng_state(),
                                            'torch_cuda': torch.cuda.get_rng_state(self.device) if self.device.type == 'cuda' else None},
                           'env_random_state': self.env.get_env_random_state()})
-        torch.save(state, path)
+        return state
 
     def load(self, path, training=True):
         state = torch.load(path, map_location='cpu', weights_only=False)

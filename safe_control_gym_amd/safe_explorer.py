@@ -197,13 +197,12 @@ class SafeExplorerPPO(PPO):
         return acc
 
     # ---- checkpoints with upstream's keys (safe_ppo.py:146-176): agent, safety_layer, normalisers
-    def save(self, path, training=True):
-        super().save(path, training)
-        state = torch.load(path, map_location='cpu', weights_only=False)
+    def checkpoint_state(self, training=True):
+        state = super().checkpoint_state(training)
         state['safety_layer'] = self.safety_layer.state_dict()
         if training:
             state['c'] = self.c.cpu()
-        torch.save(state, path)
+        return state
 
     def load(self, path, training=True):
         state = torch.load(path, map_location='cpu', weights_only=False)
