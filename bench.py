@@ -12,8 +12,12 @@ the K-step graph is replayed R times, each replay timed between barrier + synchr
 
 Secondary objects (rank 0, N = 1): `f64` (the float64 kernels of the same workload), `secondary` (the other BASELINE
 configs' env kernels: cartpole_stab incl. the fused random-action rollout of config #2, quadrotor_3D_track[_disturbed]),
-`gae` (scg_gae timing + its own roofline), `fused_rollout` (K steps per launch with the PPO actor in the loop), `ppo`
-(budgeted wall-clock-to-reward runs), `cpu_baseline`.
+`gae` (scg_gae timing + its own roofline), `sequence` (scg_step_sequence: K control steps per launch, the mode that carries >= 0.40 of the
+HBM roofline at this N), `fused_rollout` (K steps per launch with the PPO actor in the loop), `ppo` (budgeted wall-clock-to-reward runs at
+BASELINE config #3's batch: 2 partial epochs x 32 minibatches of 16 256 per iteration, with `ppo.full_epochs` and `ppo.envs_16384` beside
+it), `sac` (config #5's env; `sac.param_randomised` = with flyable parameter disturbances, target re-measured under them), `cpu_baseline`.
+`roofline.traffic`, `roofline.valu_issue`, `f64.traffic`, `sequence.*.traffic*` are quoted from profiles/r04_hbm_traffic.json (rocprofv3
+--pmc passes) only while that file names the hash of the kernel sources in this tree.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU with
 torch.distributed.run.  Rank 0 prints ONE JSON line.  Env shards are independent (rank r owns global env ids
