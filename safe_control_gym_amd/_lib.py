@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libscg_hip.so')
 SOURCES = ['scg_kernels.hip']
-HEADERS = ['scg_env_core.h', 'scg_env_kernels.h', 'scg_gae_kernels.h', 'scg_mlp.h', 'scg_params.h', 'scg_rng.h', 'scg_spec.h',
+HEADERS = ['scg_env_core.h', 'scg_env_kernels.h', 'scg_gae_kernels.h', 'scg_mlp.h', 'scg_once.h', 'scg_params.h', 'scg_rng.h', 'scg_spec.h',
            os.path.join('..', '..', 'include', 'scg_hip.h')]         # (scg_mlp.h: the policy-in-the-loop variants include it)
 SPEC_DIR = os.path.join(PKG_DIR, 'spec')
 

@@ -9,7 +9,7 @@ from safe_control_gym_amd import _lib as L
 from safe_control_gym_amd._learn import ACTS, MlpLayout
 
 SRC = os.path.join(L.CSRC_DIR, 'scg_sac.hip')
-DEPS = [SRC, os.path.join(L.CSRC_DIR, 'scg_mlp.h'), os.path.join(L.CSRC_DIR, 'scg_rng.h'),
+DEPS = [SRC, os.path.join(L.CSRC_DIR, 'scg_mlp.h'), os.path.join(L.CSRC_DIR, 'scg_once.h'), os.path.join(L.CSRC_DIR, 'scg_rng.h'),
         os.path.normpath(os.path.join(L.CSRC_DIR, '..', '..', 'include', 'scg_sac.h')),
         os.path.normpath(os.path.join(L.CSRC_DIR, '..', '..', 'include', 'scg_learn.h'))]
 

@@ -268,7 +268,12 @@ class SafeExplorerPPO(PPO):
         super()._build()
         self.safety_layer = self.impl.safety_layer
         self.num_constraints = self.impl.C
-        self._pretrain_steps = 0
+        self.impl.pretrain_steps = 0
+
+    # pre-training epochs done: lives on the implementation object so that it is saved / restored with its checkpoint
+    # (a resumed pre-training run continues at epoch k instead of repeating all `constraint_epochs`)
+    _pretrain_steps = property(lambda self: self.impl.pretrain_steps,
+                               lambda self, v: setattr(self.impl, 'pretrain_steps', int(v)))
 
     def _make_impl(self, pcfg):
         from safe_control_gym_amd import safe_explorer

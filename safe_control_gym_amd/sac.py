@@ -361,9 +361,11 @@ class SACAgent:
             n_steps = 0.0
             for p in opt.param_groups[0]['params']:
                 st = opt.state.get(p)
-                if not st:
-                    continue
                 o, k = self._flat_offset(p), p.numel()
+                if not st:                      # no state for this parameter (zero-step checkpoint): a load is a full overwrite
+                    fl['m'][o:o + k].zero_()
+                    fl['v'][o:o + k].zero_()
+                    continue
                 fl['m'][o:o + k].copy_(st['exp_avg'].reshape(-1))
                 fl['v'][o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
                 n_steps = float(st['step'])

@@ -202,6 +202,9 @@ class SafeExplorerPPO(PPO):
         state['safety_layer'] = self.safety_layer.state_dict()
         if training:
             state['c'] = self.c.cpu()
+            # upstream saves `total_steps`, which in the pre-training phase IS the epoch count (safe_ppo.py:146-160, :178-213);
+            # here total_steps counts env steps of the PPO phase, so the pre-training progress travels under its own key
+            state['pretrain_steps'] = int(getattr(self, 'pretrain_steps', 0))
         return state
 
     def load(self, path, training=True):
@@ -210,6 +213,8 @@ class SafeExplorerPPO(PPO):
         self.load_safety_layer(state)
         if training and 'c' in state:
             self.c = state['c'].to(self.device)
+        if training:
+            self.pretrain_steps = int(state.get('pretrain_steps', 0))
 
     def load_safety_layer(self, state_or_path):
         """The `pretrained` hand-over of the second phase (safe_ppo.py:96-100): only the safety layer of a checkpoint."""

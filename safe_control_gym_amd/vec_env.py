@@ -130,11 +130,14 @@ class StepTensors:
 class LazyInfoList(Sequence):
     """``info['n']``: behaves like the reference's tuple of per-env dicts
     (dummy_vec_env.py:41) but copies the columnar device arrays to the host only on first access.
-    It is a VIEW of the step's output buffers, which the next step() overwrites (all columns together, the step counter
-    included): read it — or index it once, which snapshots every column on the host — before stepping again."""
+    It is a VIEW of the step's output buffers, which the next step() overwrites (all columns together): read it — or index
+    it once, which snapshots every column on the host — before stepping again.  ``step_snapshot``: the ctrl_step_counter
+    of every env AT STEP TIME (benchmark_env.py:466); the NumPy-returning facade (which synchronises anyway) passes it, the
+    tensor-returning one reads the live counters at first access like every other column."""
 
-    def __init__(self, venv, out, is_reset):
+    def __init__(self, venv, out, is_reset, step_snapshot=None):
         self._venv, self._out, self._is_reset, self._host = venv, out, is_reset, None
+        self._step_snapshot = step_snapshot
 
     def __len__(self):
         return self._venv.num_envs
@@ -147,7 +150,7 @@ class LazyInfoList(Sequence):
             h.update(fin_return=fin[:, 0], fin_length=fin[:, 1], fin_violation=fin[:, 2], fin_mse=fin[:, 3])
             h['c_values'] = o.c_values.t().cpu().numpy() if o.c_values is not None else None
             if not self._is_reset:      # ctrl_step_counter of the running episodes (benchmark_env.py:466); a reset's is 0 by definition
-                h['step'] = self._venv.get_counters()[0]
+                h['step'] = self._step_snapshot if self._step_snapshot is not None else self._venv.get_counters()[0]
             self._host = h
         return self._host
 
@@ -441,10 +444,11 @@ class HipVecEnv(VecEnv):
     def step_wait(self):
         out = self.step_tensors(self._actions, self._adv)
         self._adv = None
-        info = {'n': LazyInfoList(self, out, is_reset=False)}
         if self.return_numpy:
+            info = {'n': LazyInfoList(self, out, is_reset=False, step_snapshot=self.get_counters()[0])}
             return (out.obs.cpu().numpy().astype(np.float64), out.reward.cpu().numpy().astype(np.float64),
                     out.done.cpu().numpy().astype(bool), info)
+        info = {'n': LazyInfoList(self, out, is_reset=False)}
         return out.obs, out.reward, out.done.bool(), info
 
     def _reset_info(self, host, i, with_constraints=False):
