@@ -313,6 +313,11 @@ int scg_set_state(scg_env* env, const double* h_state, int first_env, int n, voi
 int scg_get_state(scg_env* env, double* h_state, int first_env, int n, void* stream);
 int scg_set_params(scg_env* env, const double* h_params, int first_env, int n, void* stream);
 int scg_get_params(scg_env* env, double* h_params, int first_env, int n, void* stream);
+/* Tuning knob (no reference counterpart; results are identical either way).  Config-specialised libraries step shards of
+ * <= max_envs envs with TWO waves per 64 envs, each producing half of the step's outputs (the regime where a launch leaves SIMD
+ * wave slots empty: 65 536 envs = one wave per SIMD on MI355X); larger shards, and the generic library always, use one wave per 64
+ * envs.  Default: 98 304, or the environment variable SCG_SPLIT_MAX_ENVS at library load; 0 = never split. */
+int scg_set_split_max_envs(scg_env* env, int max_envs);
 /* BenchmarkEnv.seed (benchmark_env.py:193-214): new Philox key for subsequent draws. */
 int scg_set_seed(scg_env* env, uint64_t seed);
 /* ctrl_step_counter / episode index per env (benchmark_env.py:329-330). */

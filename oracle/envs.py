@@ -27,13 +27,13 @@ from oracle import bullet
 from oracle.constraints import create_constraint_list
 from oracle.disturbances import create_disturbance_list
 from oracle.rng import (CH_ACTION, CH_DYNAMICS, CH_OBSERVATION, CH_RESET, NumpyEnvRng, PhiloxEnvRng,
-                        make_tag)
+                        make_tag, u01_from_word)
 from oracle.trajectory import generate_trajectory, transform_trajectory
 
 CHANNEL_OF_MODE = {'action': CH_ACTION, 'dynamics': CH_DYNAMICS, 'observation': CH_OBSERVATION}
 # Philox reset-draw groups (must match scg_rng.h): item = group; j = INIT_STATE_LABELS index | inertial parameter
 # index | 4 * (channel - 1) + list index for disturbance offsets.  Variable j of a group whose randomised variables all
-# need ONE word (uniform / choice) uses word j % 4 of block j // 4 ("compact"); as soon as one of them is a normal draw
+# need ONE word (uniform / choice) uses the 21-bit field j % 6 of block j // 6 ("compact"); as soon as one of them is a normal draw
 # (two words) every variable of the group uses block j // 2 and the word pair (2*(j%2), 2*(j%2)+1); disturbance offsets
 # always use the pair layout.
 GROUP_INIT, GROUP_INERTIAL, GROUP_DISTURB = 0, 1, 2
@@ -77,11 +77,15 @@ class Draws:
         d_args = spec.pop('args', [])
         if self.rng.kind == 'numpy':
             return np.array([getattr(self.rng.gens[i], distrib)(*d_args, **spec) for i in idx], dtype=np.float64)
-        tag = make_tag(CH_RESET, group, j // 4 if compact else j // 2)
-        w0 = j % 4 if compact else 2 * (j % 2)
+        tag = make_tag(CH_RESET, group, j // 6 if compact else j // 2)
+        w0 = 2 * (j % 2)
+        if compact:
+            word = self.rng.compact_field(idx, self.env.episode, 0, tag, j % 6)
         if distrib == 'uniform':
             low = d_args[0] if len(d_args) > 0 else spec.get('low', 0.0)
             high = d_args[1] if len(d_args) > 1 else spec.get('high', 1.0)
+            if compact:
+                return low + (high - low) * u01_from_word(word)
             return low + (high - low) * self.rng.uniform01(idx, self.env.episode, 0, tag, word=w0)
         if distrib == 'normal':
             loc = d_args[0] if len(d_args) > 0 else spec.get('loc', 0.0)
@@ -89,6 +93,8 @@ class Draws:
             return loc + scale * self.rng.normal01_words(idx, self.env.episode, 0, tag, w0, w0 + 1)
         if distrib == 'choice':
             opts = np.asarray(d_args[0] if len(d_args) > 0 else spec['a'], dtype=np.float64)
+            if compact:
+                return opts[((word.astype(np.uint64) * np.uint64(len(opts))) >> np.uint64(32)).astype(np.int64)]
             return opts[self.rng.integer_below(idx, self.env.episode, 0, tag, len(opts), word=w0)]
         raise NotImplementedError(f'oracle/philox: distribution {distrib}')
 

@@ -125,13 +125,17 @@ static void reset_env(const oc_cfg* c, int i, double* s, int32_t* step, uint32_t
     double iv[OC_MAX_STATE];
     for (int k = 0; k < c->nx; ++k) iv[k] = c->init_state[k];
     if (c->randomized_init) {
-        /* uniform draws only: the compact layout of scg_rng.h (variable j = word j % 4 of block j / 4) */
-        for (int b = 0; b < (c->nx + 3) / 4; ++b) {
+        /* uniform draws only: the compact layout of scg_rng.h (variable j = 21-bit field j % 6 of block j / 6, left-aligned
+           in a word: fields 0-3 the top 21 bits of the four words, 4 and 5 their 11 / 10 low bits paired up) */
+        for (int b = 0; b < (c->nx + 5) / 6; ++b) {
             uint32_t ctr[4] = {(uint32_t)(c->env_id_offset + i), *episode, 0u, (0u << 16) | (0u << 8) | (uint32_t)b};
             philox(ctr, (uint32_t)(c->seed & 0xffffffffu), (uint32_t)(c->seed >> 32));
-            for (int k = 0; k < 4 && 4 * b + k < c->nx; ++k) {
-                const int j = 4 * b + k;
-                if (c->init_rand[j]) iv[j] += c->init_lo[j] + (c->init_hi[j] - c->init_lo[j]) * u01(ctr[k]);
+            for (int k = 0; k < 6 && 6 * b + k < c->nx; ++k) {
+                const int j = 6 * b + k;
+                uint32_t w;
+                if (k < 4) w = ctr[k] & 0xfffff800u;
+                else w = (ctr[k == 4 ? 0 : 2] << 21) | ((ctr[k == 4 ? 1 : 3] & 0x3ffu) << 11);
+                if (c->init_rand[j]) iv[j] += c->init_lo[j] + (c->init_hi[j] - c->init_lo[j]) * u01(w);
             }
         }
     }

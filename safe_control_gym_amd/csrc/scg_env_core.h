@@ -472,7 +472,7 @@ __device__ __forceinline__ float cos_2pi(float u) {
 
 // ------------------------------------------------------------------ random helpers
 // Reset-time draws: variable j of group g uses Philox block j/2 of item g, words 2*(j&1) and 2*(j&1)+1 — or, when no
-// variable of the group is a normal draw, word j%4 of block j/4 (scg_rng.h).
+// variable of the group is a normal draw, 21-bit field j%6 of block j/6 (scg_rng.h).
 template <typename T>
 __device__ __forceinline__ T rand_value(const HotRand<T>& r, const DevRand<T>& full, uint32_t w0, uint32_t w1) {
     if (r.kind == SCG_RAND_UNIFORM) return r.p0 + (r.p1 - r.p0) * u01<T>(w0);
@@ -642,7 +642,7 @@ struct EnvOps {
 #else
     static constexpr bool PRE = false;
 #endif
-    static constexpr int PRE_NB = (Dims<SYS>::NX + 3) / 4;
+    static constexpr int PRE_NB = (Dims<SYS>::NX + COMPACT_PER_BLOCK - 1) / COMPACT_PER_BLOCK;
 #ifdef SCG_SPEC
     static constexpr int PRE_U2 = scg_make_spec_cfg<T>().substeps > 0 ? scg_make_spec_cfg<T>().substeps : 1;   // the 2-D loop is fully unrolled
 #else
@@ -749,14 +749,15 @@ SCG_DIST_UNROLL
             }
         }
         if (P.c.per_env_params && P.c.param_compact) {
-            // one-word distributions only: four variables per Philox block (see scg_rng.h)
+            // one-word distributions only: six 21-bit variables per Philox block (see scg_rng.h)
+            constexpr int CPB = COMPACT_PER_BLOCK;
 #pragma unroll
-            for (int b = 0; b < (D::NP + 3) / 4; ++b) {
+            for (int b = 0; b < (D::NP + CPB - 1) / CPB; ++b) {
                 U4 w = rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_PARAM, (uint32_t)b));
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (4 * b + k < D::NP)
-                        e.par[4 * b + k] = P.c.base_param[4 * b + k] + rand_value(P.c.param_rand[4 * b + k], P.i.cold->param_rand[4 * b + k], u4_get(w, k), 0u);
+                for (int k = 0; k < CPB; ++k)
+                    if (CPB * b + k < D::NP)
+                        e.par[CPB * b + k] = P.c.base_param[CPB * b + k] + rand_value(P.c.param_rand[CPB * b + k], P.i.cold->param_rand[CPB * b + k], compact_word(w, k), 0u);
             }
         } else if (P.c.per_env_params) {
 #pragma unroll
@@ -770,14 +771,15 @@ SCG_DIST_UNROLL
 #pragma unroll
         for (int k = 0; k < D::NX; ++k) iv[k] = P.c.init_state[k];
         if (P.c.randomized_init && P.c.init_compact) {
+            constexpr int CPB = COMPACT_PER_BLOCK;
 #pragma unroll
-            for (int b = 0; b < (D::NX + 3) / 4; ++b) {
+            for (int b = 0; b < (D::NX + CPB - 1) / CPB; ++b) {
                 U4 w = b < pre_n_in ? e.pre[b < 3 ? b : 0]           // drawn inside the integrator of this control step (PreDraw)
                                    : rng_words(key, e.gid, e.episode, 0u, rng_tag(RNG_CH_RESET, RNG_GROUP_INIT, (uint32_t)b));
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (4 * b + k < D::NX)
-                        iv[4 * b + k] += rand_value(P.c.init_rand[4 * b + k], P.i.cold->init_rand[4 * b + k], u4_get(w, k), 0u);
+                for (int k = 0; k < CPB; ++k)
+                    if (CPB * b + k < D::NX)
+                        iv[CPB * b + k] += rand_value(P.c.init_rand[CPB * b + k], P.i.cold->init_rand[CPB * b + k], compact_word(w, k), 0u);
             }
         } else if (P.c.randomized_init) {
 #pragma unroll

@@ -242,13 +242,26 @@ __device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* 
     fence_out<T>(O);
 }
 
-template <int SYS, typename T, bool DIST, bool ONE>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                     const T* __restrict__ action, const T* __restrict__ adv,
-                                                     const typename OutTabOf<ONE>::type O) {
+// Output ownership of a step wave.  ROLE_ALL: one wave produces every output of its 64 envs (the kernel of every round so far).
+// Split launch (step_split_kernel, shards of <= SCG_SPLIT_MAX_ENVS envs — the one-wave-per-SIMD regime, where the launch is ONE
+// serial instruction chain per wave and half the SIMD's issue slots are idle): TWO waves per 64 envs.  Both load the state and
+// the action and integrate the control step — the same instruction sequence on the same inputs, bit-identical results — and each
+// then produces its own half of the outputs:
+//   ROLE_SCORE  reward, done, flags, mse, noisy action, the constraint rows, the episode statistics (read-modify-write);
+//   ROLE_STATE  observation, terminal observation, auto-reset (Philox draws), env.state, the workspace state and counters.
+// The serial tail behind the integrator (51 % of the wave's lifetime at 65 536 envs, profiles/r04_timeline_*) is cut in two and the
+// halves run side by side on the SIMD's two wave slots; the price is the second read of state + action (+40 B per env-step from the
+// memory side).  Neither role reads anything the other writes in the same launch.
+enum : int { ROLE_ALL = 0, ROLE_SCORE = 1, ROLE_STATE = 2 };
+
+template <int SYS, typename T, bool DIST, bool ONE, int ROLE>
+__device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, const InstParams<T>& I,
+                                          const T* __restrict__ action, const T* __restrict__ adv,
+                                          const typename OutTabOf<ONE>::type& O, const int wg) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
-    const int i = I.env_first + blockIdx.x * BLOCK + threadIdx.x;
+    constexpr bool SCORE = ROLE != ROLE_STATE, STATE = ROLE != ROLE_SCORE;
+    const int i = I.env_first + wg * BLOCK + threadIdx.x;
     const int N = I.num_envs;
     const bool live = i < I.env_end;
     // ---- memory round 1: kernargs — every pointer is fetched in this block, one scalar-memory round
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
         for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];     // caller's tensor: plain global load
         // unconditional load (an unbound accumulator reads a valid dummy address): a branch would split the
         // requests over two dependent rounds
-        (Q.ep_stats ? Q.ep_stats : slot_in<T>(make_rsrc(I.ws), I.state_off, 0, 4)).template load_row<4>(ep);
+        if constexpr (SCORE) (Q.ep_stats ? Q.ep_stats : slot_in<T>(make_rsrc(I.ws), I.state_off, 0, 4)).template load_row<4>(ep);
     }
 #ifndef SCG_SPEC
     const CfgParams<T>* cl;
@@ -305,7 +318,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     SCG_TL(2);
     // ---- memory round 3 (overlapped with the integrator): reference rows of X_GOAL for this step
     const bool pre_rows = P.c.task == SCG_TASK_TRAJ_TRACKING;
-    const bool pre_ext = pre_rows && P.c.cost == SCG_COST_RL_REWARD && P.c.obs_goal_horizon == 1;
+    const bool pre_ref = pre_rows && SCORE;             // the reference row feeds reward / mse only when tracking (ROLE_STATE: unused)
+    const bool pre_ext = pre_rows && STATE && P.c.cost == SCG_COST_RL_REWARD && P.c.obs_goal_horizon == 1;
     T ref_pre[D::NX], ext_pre[D::NX], ext_reset[D::NX];
     if (pre_rows) {
         const int last = P.c.goal_rows - 1;
@@ -313,8 +327,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
 #ifdef SCG_EXP_UNIFORM_GOAL
         r1 = 1;
 #endif
+        if (pre_ref) {
 #pragma unroll
-        for (int k = 0; k < D::NX; ++k) ref_pre[k] = goal[r1 * D::NX + k];
+            for (int k = 0; k < D::NX; ++k) ref_pre[k] = goal[r1 * D::NX + k];
+        }
         if (pre_ext) {
             int r2 = c0 + 2; r2 = r2 > last ? last : r2;
 #ifdef SCG_EXP_UNIFORM_GOAL
@@ -337,9 +353,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
         }
     }
     T st[D::NX], noisy[D::NU];
+    if constexpr (!SCORE) Q.c_values.soff = SCG_NO_OFF;                 // (the rows are evaluated for `done`, stored by ROLE_SCORE)
     typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, Q.c_values, (size_t)N,
-                                           pre_rows ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr,
+                                           pre_ref ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr,
                                            pre_ext ? ext_reset : nullptr);
+    if constexpr (SCORE) {
     Q.reward.store(r.reward);           // obs / reward / done / flags are always bound (checked by scg_step)
     Q.done.store(r.done ? 1 : 0);
     Q.flags.store(r.flags);
@@ -348,8 +366,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) Q.noisy_action.store(noisy[j], (size_t)j * N);
     }
+    }
     // columnar VecRecordEpisodeStatistics (record_episode_statistics.py:139-166)
-    if (Q.ep_stats) {
+    if (SCORE && Q.ep_stats) {
         ep[0] += r.reward;
         ep[1] += (T)1;
         ep[2] += (r.flags & FLAG_VIOLATION) ? (T)1 : (T)0;
@@ -358,6 +377,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
         const T nxt[4] = {r.done ? (T)0 : ep[0], r.done ? (T)0 : ep[1], r.done ? (T)0 : ep[2], r.done ? (T)0 : ep[3]};
         Q.ep_stats.template store_row<4>(nxt);
     }
+    if constexpr (!STATE) return;
     // observation of the step: goes to terminal_observation where the env is about to auto-reset, else it is the
     // returned obs (two write_obs call sites only: the disturbance code is inlined into each)
 #ifdef SCG_EXP_NO_RESET
@@ -407,6 +427,28 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
     Ops::store(P, i, e, do_reset);
     SCG_TL(7);
 }
+
+template <int SYS, typename T, bool DIST, bool ONE>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
+                                                     const T* __restrict__ action, const T* __restrict__ adv,
+                                                     const typename OutTabOf<ONE>::type O) {
+    step_body<SYS, T, DIST, ONE, ROLE_ALL>(Cg, I, action, adv, O, (int)blockIdx.x);
+}
+
+#ifdef SCG_SPEC
+// Split launch: 2 x (env groups rounded up to a multiple of 8) workgroups.  Workgroup b serves env group 8 (b / 16) + b % 8 in
+// role (b / 8) % 2: the two waves of a group are eight workgroups apart, i.e. (with the observed round-robin placement) on the same
+// XCD, so that the second read of the group's state can hit that XCD's L2; correctness does not depend on placement.
+template <int SYS, typename T, bool DIST, bool ONE>
+__global__ __launch_bounds__(BLOCK) void step_split_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
+                                                           const T* __restrict__ action, const T* __restrict__ adv,
+                                                           const typename OutTabOf<ONE>::type O) {
+    const int b = (int)blockIdx.x;
+    const int wg = ((b >> 4) << 3) | (b & 7);
+    if ((b >> 3) & 1) step_body<SYS, T, DIST, ONE, ROLE_STATE>(Cg, I, action, adv, O, wg);
+    else step_body<SYS, T, DIST, ONE, ROLE_SCORE>(Cg, I, action, adv, O, wg);
+}
+#endif
 
 // Output slots of the K-steps-per-launch kernels: write-back stores (SCG_SEQ_ST_AUX, see Slot in scg_env_core.h).
 template <typename V>

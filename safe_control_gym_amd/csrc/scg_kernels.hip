@@ -72,7 +72,21 @@ struct scg_env {
     uint8_t* d_oob;
     bool has_reset;
     bool has_dist;
+    int split_max;           // largest shard (envs) that takes the split step launch (specialised builds; scg_set_split_max_envs)
 };
+
+// Largest shard that takes the split step launch by default (environment variable SCG_SPLIT_MAX_ENVS overrides the built-in
+// threshold; 0 = never).  65 536 envs = one wave per SIMD: measured on MI355X (profiles/r05_step_kernel_ab.md).
+#ifndef SCG_SPLIT_MAX_ENVS
+#define SCG_SPLIT_MAX_ENVS 98304
+#endif
+static int default_split_max_envs() {
+    static const int v = [] {
+        const char* s = std::getenv("SCG_SPLIT_MAX_ENVS");
+        return s && *s ? std::atoi(s) : (int)SCG_SPLIT_MAX_ENVS;
+    }();
+    return v;
+}
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static size_t elem_size(int dtype) { return dtype == SCG_F64 ? 8 : 4; }
@@ -551,6 +565,7 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->d_state = w + L.state; e->d_param = w + L.param; e->d_step = (int32_t*)(w + L.step);
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
+    e->split_max = default_split_max_envs();
     e->has_dist = cfg->n_dist[0] > 0 || cfg->n_dist[1] > 0 || cfg->n_dist[2] > 0 || cfg->adversary_channel >= 0;
     hipError_t err = hipMemset(d_workspace, 0, L.total);
     if (err == hipSuccess) err = hipMemset(e->d_episode, 0xff, (size_t)cfg->num_envs * 4);   // first reset -> episode 0
@@ -651,6 +666,21 @@ static int launch_step(scg_env* env, int first, int count, const void* action, c
     const CfgParams<T>* C = (const CfgParams<T>*)env->d_cfg;
     InstParams<T> I = inst_of<T>(env);
     I.env_first = first; I.env_end = first + count;
+#ifdef SCG_SPEC
+    // Shards that leave SIMD wave slots empty (<= SCG_SPLIT_MAX_ENVS envs; 65 536 envs = one wave per SIMD) take the split launch:
+    // two waves per 64 envs, each producing half of the outputs (step_split_kernel, scg_env_kernels.h).  Larger shards are
+    // bandwidth-bound and keep one wave per 64 envs.  Same results bit for bit (tests/test_gpu_env_parity.py).
+    if (count <= env->split_max) {
+        const int grid2 = 2 * ((grid + 7) / 8 * 8);
+        if (one_base) {
+            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, true><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
+        } else {
+            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, false><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+        }
+        HIP_TRY(hipGetLastError());
+        return SCG_OK;
+    }
+#endif
     if (one_base) {
         DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
     } else {
@@ -849,6 +879,13 @@ extern "C" int scg_get_params(scg_env* env, double* h_params, int first_env, int
     return env->dtype == SCG_F64 ? copy_soa<double>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream)
                                  : copy_soa<float>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream);
 }
+extern "C" int scg_set_split_max_envs(scg_env* env, int max_envs) {
+    if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
+    if (max_envs < 0) return fail(SCG_ERR_INVALID, "max_envs must be >= 0");
+    env->split_max = max_envs;
+    return SCG_OK;
+}
+
 extern "C" int scg_set_seed(scg_env* env, uint64_t seed) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
     env->cfg.seed = seed;

@@ -9,8 +9,12 @@
 //                offsets).  Pair layout: variable j of a group uses block j/2 and the word pair (2*(j&1), 2*(j&1)+1):
 //                uniform / choice / integer draws consume the first word, normal draws both.  Compact layout, used
 //                for groups 0 and 1 when none of the group's randomised variables is a normal draw: variable j uses
-//                word j%4 of block j/4 (a Philox block costs ~20 quarter-rate 32x32 multiplies; the auto-reset path
-//                of the step kernel is its Philox blocks).
+//                21-BIT FIELD j%6 of block j/6 (compact_word below: fields 0-3 = the top 21 bits of the block's four
+//                words, fields 4 and 5 = their 11 / 10 low bits paired up), handed to the distributions in the top
+//                bits of a word.  A Philox block costs ~20 quarter-rate 32x32 multiplies and the auto-reset path of
+//                the step kernel is its Philox blocks: the six initial-state draws of the planar quadrotor are ONE
+//                block (round 4: two, four 32-bit words each), Quadrotor3D's twelve are two (three); 2^-21 is
+//                still finer than any initial-state or inertial-parameter range needs.
 //                j = INIT_STATE_LABELS index | inertial parameter index | 4 * scg_channel + list index
 //   u01(word)    = ((word >> 8) + 0.5) * 2^-24     (exact in fp32)
 //   normal(w0,w1)= sqrt(-2 ln u01(w0)) * cos(2 pi u01(w1))
@@ -71,6 +75,14 @@ SCG_HD U4 rng_words(RngKey key, uint32_t env, uint32_t episode, uint32_t step, u
 }
 
 SCG_HD uint32_t u4_get(const U4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// Compact reset-draw layout: 21-bit field k (0..5) of a block, left-aligned in a word (u01 / int_below read top bits).
+constexpr int COMPACT_PER_BLOCK = 6;
+SCG_HD uint32_t compact_word(const U4& v, int k) {
+    if (k < 4) return u4_get(v, k) & 0xfffff800u;
+    const uint32_t a = k == 4 ? v.x : v.z, b = k == 4 ? v.y : v.w;
+    return (a << 21) | ((b & 0x3ffu) << 11);
+}
 
 template <typename T>
 SCG_HD T u01(uint32_t w) { return ((T)(w >> 8) + (T)0.5) * (T)(1.0 / 16777216.0); }

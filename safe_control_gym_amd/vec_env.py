@@ -497,6 +497,11 @@ class HipVecEnv(VecEnv):
                                                ep.ctypes.data_as(C.POINTER(C.c_uint32)), 0, self.num_envs, self._stream()))
         return step, ep
 
+    def set_split_max_envs(self, max_envs):
+        """Tuning knob of the specialised libraries (scg_set_split_max_envs): shards of <= max_envs envs are stepped by two waves per
+        64 envs, each producing half of the outputs; 0 = one wave per 64 envs always.  Results are identical either way."""
+        self._chk(self._lib.scg_set_split_max_envs(self._h, int(max_envs)))
+
     def set_counters(self, step=None, episode=None):
         sp = None if step is None else np.ascontiguousarray(step, dtype=np.int32)
         ep = None if episode is None else np.ascontiguousarray(episode, dtype=np.uint32)

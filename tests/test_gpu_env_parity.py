@@ -428,8 +428,9 @@ def test_full_and_partial_waves_specialised_store_paths(name, dtype):
 
 @pytest.mark.parametrize('with_normal', [False, True], ids=['compact-words', 'pair-words'])
 def test_reset_draw_word_layouts(with_normal):
-    """Philox addressing of the reset draws (scg_rng.h): four one-word variables per block when no variable of the group is
-    a normal draw, otherwise two variables per block — kernels and oracle must pick the same layout."""
+    """Philox addressing of the reset draws (scg_rng.h): six 21-bit variables per block when no variable of the group is
+    a normal draw (fields 4 / 5 — init_theta, init_theta_dot here — are the paired low bits), otherwise two variables per
+    block — kernels and oracle must pick the same layout."""
     from oracle.envs import make_oracle_env, make_rng
     from oracle.vec import OracleVecEnv
     from safe_control_gym_amd.vec_env import HipVecEnv

@@ -56,3 +56,26 @@ def test_multi_step_run_equals_repeated_steps():
         outs.append((port.state.copy(), port.obs.copy(), port.step_ctr.copy(), port.episode.copy(), port.rew.copy()))
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_compact_fields_partition_the_block():
+    """scg_rng.h compact layout: the six 21-bit fields of a Philox block use every bit of the 128 at most once (126 of them),
+    left-aligned in a word; u01 of a field stays strictly inside (0, 1)."""
+    from oracle.rng import compact_words, u01_from_word
+    rs = np.random.RandomState(0)
+    w = rs.randint(0, 2 ** 32, size=(1000, 4), dtype=np.uint64).astype(np.uint32)
+    f = compact_words(w)
+    assert f.shape == (1000, 6) and np.all(f & np.uint32(0x7FF) == 0)
+    # rebuild the block from the fields: bits 11.. of each word from fields 0-3, the low 11 / 10 bits from fields 4, 5
+    x = (f[:, 0] | (f[:, 4] >> np.uint32(21)))
+    y_low = (f[:, 4] >> np.uint32(11)) & np.uint32(0x3FF)
+    z = (f[:, 2] | (f[:, 5] >> np.uint32(21)))
+    w_low = (f[:, 5] >> np.uint32(11)) & np.uint32(0x3FF)
+    np.testing.assert_array_equal(x, w[:, 0])
+    np.testing.assert_array_equal(z, w[:, 2])
+    np.testing.assert_array_equal(f[:, 1] | y_low, w[:, 1] & ~np.uint32(0x400))         # bit 10 of y / w is the one unused bit
+    np.testing.assert_array_equal(f[:, 3] | w_low, w[:, 3] & ~np.uint32(0x400))
+    u = u01_from_word(f)
+    assert u.min() > 0.0 and u.max() < 1.0
+    edge = compact_words(np.array([[0xFFFFFFFF] * 4, [0] * 4], dtype=np.uint32))
+    assert u01_from_word(edge).max() < 1.0 and u01_from_word(edge).min() > 0.0
