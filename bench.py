@@ -45,9 +45,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 # HBM traffic / executed-instruction counts come from committed rocprofv3 --pmc passes (tools/profile_round4.sh ->
 # tools/profile_post.py).  They describe ONE build of the kernels: the file carries the hash of the kernel sources it was measured
 # on, and a line printed from other sources drops the number (traffic: null, with the reason) instead of quoting a stale one.
-TRAFFIC_FILE = 'r04_hbm_traffic.json'
+TRAFFIC_FILE = 'r05_hbm_traffic.json'
 SEQ_K, SEQ_K_ALL = 32, 8        # control steps per launch of the two scg_step_sequence workloads (sequence_leg, tools/seq_profile.py)
 SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
+SPLIT_MAX_ENVS = int(os.environ.get('SCG_SPLIT_MAX_ENVS', 98304))      # scg_kernels.hip default: shards up to this size take the split step launch
 
 
 def parse():
@@ -248,13 +249,24 @@ class StepBench:
         return bool(self.torch.isfinite(self.out.reward).all().item()) and int(self.out.fin_length.max().item()) > 0
 
 
-def roofline_of(task, dtype_name, n, period_us):
+def roofline_of(task, dtype_name, n, period_us, driver_step_us=None, split=False):
+    """`frac` = algorithmic bytes per launch / the launch period measured HERE with HIP events inside back-to-back graph replays.
+    `frac_by_clock` puts the other two clocks beside it so that no reader takes one for another: the rocprofv3 --kernel-trace average
+    duration of the same kernel (committed under profiles/, quoted while the kernel-source hash matches; the tracer adds ~0.4 us per
+    dispatch) and the driver-timed step of this very run (`ms_per_step`: K = 20 steps per graph replay pay the replay floor)."""
     algo = ALGO_BYTES_PER_ENV_STEP.get(task) if dtype_name == 'f32' else None
     achieved = (algo * n / (period_us * 1e-6)) / 1e9 if algo else None
     traffic, src = traffic_of(task, dtype_name, n)
+    e, _ = pmc_entry(f'{task}/{dtype_name}/{n}')
+    rocprof_us = e.get('rocprof_avg_launch_us') if e else None
+    frac_of = lambda us: (algo * n / (us * 1e-6)) / 1e9 / HBM_PEAK_GBS if (algo and us) else None      # noqa: E731
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': traffic, 'traffic_source': src,
-            'kernel': KERNEL_NAME.get(task, 'step_kernel'), 'avg_launch_us': period_us, 'algorithmic_bytes_per_env_step': algo,
+            'frac_by_clock': {'in_graph_hip_events': {'us': period_us, 'frac': frac_of(period_us)},
+                              'rocprofv3_kernel_trace_avg': {'us': rocprof_us, 'frac': frac_of(rocprof_us)},
+                              'driver_timed_step': {'us': driver_step_us, 'frac': frac_of(driver_step_us)}},
+            'kernel': KERNEL_NAME.get(task, 'step_kernel') + (' as step_split_kernel (two waves per 64 envs, each half of the outputs)' if split else ''),
+            'avg_launch_us': period_us, 'algorithmic_bytes_per_env_step': algo,
             'valu_issue': valu_issue_of(task, dtype_name, n, period_us)}
 
 
@@ -505,8 +517,11 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
     # learner / rollout code objects, kernel attributes, first launches — were 0.45 s of the first seed's first iteration
     # (tools/ppo_iter_times.py: 455 ms, then 6.4 ms per iteration; the second seed's first iteration: 6.4 ms) and are not training.
     w_env = HipVecEnv(env_id, envs, seed=0, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
     PPO(w_env, config(), seed=0).train_step()
     torch.cuda.synchronize()
+    t_cold = time.perf_counter() - t_cold               # reported beside the clocks: what a fresh process pays once on top of them
     w_env.close()
     for seed in range(1, seeds + 1):
         env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
@@ -554,14 +569,19 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
             'last_eval_return': final, 'reached': len(ok1), 'reached_two_consecutive': len(ok2),
             'median_first_hit_s': statistics.median(ok1) if ok1 else None, 'median_two_consecutive_s': statistics.median(ok2) if ok2 else None,
             'median_s': statistics.median(ok2) if ok2 else None, 'budget_s_per_seed': budget_s,
+            'epoch_semantics': ('PARTIAL epochs (not upstream PPO: each epoch visits %d of its %d shuffled minibatches); the upstream-semantics '
+                                'figure is `full_epochs.median_s` of this object' % (mb_per_epoch, envs * rollout_steps // minibatch)) if mb_per_epoch
+                               else 'full epochs (upstream semantics, ppo_utils.py:113-146)',
+            'cold_start_s': t_cold, 'median_s_including_cold_start': (statistics.median(ok2) + t_cold) if ok2 else None,
             'hyper': f'MLP 12-128-128-{{2,1}} tanh, {epochs} epochs x {min(envs * rollout_steps // minibatch, mb_per_epoch or 10 ** 9)} minibatches of {minibatch}'
                      + (f' (PARTIAL epochs: {mb_per_epoch} of the {envs * rollout_steps // minibatch} minibatches of each shuffled epoch)' if mb_per_epoch else '')
                      + f', lr {lr:g}, '
                      f'target_kl {target_kl:g}, GAE 0.95, gamma 0.99, ent 0.01',
-            'path': 'scg_rollout_policy + scg_ppo_grad / scg_adam_gated (exact f32 MFMA); every iteration\'s weights evaluated by the fused '
-                    'deterministic rollout on a second stream',
+            'path': ('scg_rollout_policy + scg_ppo_step (gradient kernel, then reduction + gated Adam in one launch; exact f32 MFMA)' if world == 1 else
+                     'scg_rollout_policy + scg_ppo_grad -> all-reduce -> scg_adam_gated (exact f32 MFMA)')
+                    + '; every iteration\'s weights evaluated by the fused deterministic rollout on a second stream',
             'untimed_warmup': 'one train_step of a scratch instance (seed 0) before the first clock: code-object loads and first launches, '
-                              '0.45 s once per process'}
+                              'paid once per process (`cold_start_s`, measured here)'}
 
 
 def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, lr=1e-3, warm_up_steps=65536, eval_every=50,
@@ -782,7 +802,8 @@ def main():
                        'timing': (f'median of {repeats} timed repeats of the {done_steps}-step region' if repeats > 1 else 'one timed region')
                                  + ('; per rank: barrier + synchronize, clock, K steps, synchronize, clock, barrier; MAX over ranks' if world > 1 else ''),
                        'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))]},
-            'roofline': roofline_of(args.task, args.dtype, N, period_us),
+            'roofline': roofline_of(args.task, args.dtype, N, period_us, driver_step_us=1e6 * elapsed / done_steps,
+                                    split=bool(hb.env.specialized) and N <= SPLIT_MAX_ENVS),
         }
     full = not args.no_secondary and args.task == 'quadrotor_2D_track' and args.dtype == 'f32'
     # The learning legs run collectives (N > 1: RCCL).  A rank that dies or hangs inside one must not cost the run its line:

@@ -377,7 +377,7 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         const T nxt[4] = {r.done ? (T)0 : ep[0], r.done ? (T)0 : ep[1], r.done ? (T)0 : ep[2], r.done ? (T)0 : ep[3]};
         Q.ep_stats.template store_row<4>(nxt);
     }
-    if constexpr (!STATE) return;
+    if constexpr (!STATE) { SCG_TL(6); SCG_TL(7); return; }
     // observation of the step: goes to terminal_observation where the env is about to auto-reset, else it is the
     // returned obs (two write_obs call sites only: the disturbance code is inlined into each)
 #ifdef SCG_EXP_NO_RESET

@@ -1,0 +1,136 @@
+"""The K-steps-per-launch kernels DIRECTLY against the CPU oracle (not against scg_step): the loops they replace are
+`for t in range(K): vec_env.step(actions[t])` (dummy_vec_env.py:24-41) and PPO's collector (controllers/ppo/ppo.py:259-303).
+
+* scg_step_sequence (K = 8, every output of scg_step), float64, 250 control steps of quadrotor_2D_track from Philox-randomised
+  initial states through auto-resets: every per-step output == OracleVecEnv on the same seed and actions at 1e-9 (integers /
+  booleans exactly), on the generic and the specialised library;
+* scg_rollout_policy (the shipped Quadrotor2D policy in the loop, float32 — the kernel has no float64 build), 250 control steps:
+  the oracle is driven with the ACTIONS THE KERNEL RECORDED, so what is compared is the simulator inside the rollout kernel
+  against the float64 oracle over whole closed-loop episodes: per state dimension max|delta| / max|x| <= 1e-4 (north_star's
+  bar) for the episodes both sides hold to the same length, and the recorded action must be the actor's mean on the
+  recorded observation."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize('specialize', [False, True], ids=['generic', 'specialised'])
+def test_step_sequence_f64_free_running_vs_oracle(specialize):
+    from oracle.envs import make_oracle_env, make_rng
+    from oracle.vec import OracleEpisodeStats, OracleVecEnv
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    from tests.test_gpu_env_parity import _flags, _raw_state
+    env_id, cfg = load_task('quadrotor_2D_track')
+    n, K, launches, seed = 200, 8, 32, 21                 # 256 control steps >= 250; three full waves + a ragged one
+    oracle = make_oracle_env(env_id, n, make_rng('philox', n, seed), **cfg)
+    ovec = OracleVecEnv(oracle)
+    gpu = HipVecEnv(env_id, n, seed=seed, dtype=torch.float64, return_numpy=False, specialize=specialize, **cfg)
+    assert gpu.specialized == bool(specialize)
+    tol = dict(rtol=1e-9, atol=1e-10)
+    obs_o, _ = ovec.reset()
+    np.testing.assert_allclose(_np(gpu.reset_tensors()), obs_o, **tol)
+    rs = np.random.RandomState(5)
+    stats = OracleEpisodeStats(n)
+    n_done = 0
+    for launch in range(launches):
+        acts = rs.uniform(-1, 1, (K, n, 2))
+        if launch % 4 == 3:
+            acts *= 0.1                                    # gentle phases: some episodes run to the time limit
+        seq = gpu.step_sequence(torch.as_tensor(acts, dtype=torch.float64, device=gpu.device), terminal_obs=True, mse=True, c_values=True,
+                                fin_stats=True, state=True, noisy_action=True)
+        for t in range(K):
+            obs_o, rew_o, done_o, info = ovec.step(acts[t])
+            msg = f'launch {launch} t={t}'
+            np.testing.assert_array_equal(_np(seq['done'][t]).astype(bool), done_o, err_msg=msg)
+            np.testing.assert_array_equal(_np(seq['flags'][t]).astype(np.uint8) & 0x0F, _flags(info) & 0x0F, err_msg=msg)
+            np.testing.assert_allclose(_np(seq['reward'][t]), rew_o, err_msg=msg, **tol)
+            np.testing.assert_allclose(_np(seq['obs'][t]), obs_o, err_msg=msg, **tol)
+            np.testing.assert_allclose(_np(seq['mse'][t]), info['mse'], err_msg=msg, **tol)
+            np.testing.assert_allclose(_np(seq['state'][t]).T, oracle.state, err_msg=msg, **tol)
+            np.testing.assert_allclose(_np(seq['c_values'][t]).T, info['constraint_values'], rtol=0, atol=2e-8, err_msg=msg)
+            d = np.nonzero(done_o)[0]
+            n_done += len(d)
+            finished = stats.update(rew_o, done_o, info)         # VecRecordEpisodeStatistics (record_episode_statistics.py:139-166)
+            if len(d):
+                np.testing.assert_allclose(_np(seq['terminal_obs'][t])[d], info['terminal_observation'][d], err_msg=msg, **tol)
+                fin = _np(seq['fin_stats'][t])
+                for i, ep in finished:
+                    np.testing.assert_allclose(fin[i, 0], ep['r'], err_msg=msg, rtol=1e-9, atol=1e-9)
+                    assert fin[i, 1] == ep['l'], msg
+    assert n_done > n                                      # every env finished at least one episode on average
+    np.testing.assert_allclose(gpu.get_raw_state(), _raw_state(oracle), **tol)
+    step, ep = gpu.get_counters()
+    np.testing.assert_array_equal(step, oracle.ctrl_step_counter)
+    np.testing.assert_array_equal(ep.astype(np.int64), oracle.episode)
+    gpu.close()
+
+
+def test_rollout_policy_simulator_vs_oracle_on_the_recorded_actions():
+    from oracle.envs import make_oracle_env, make_rng
+    from oracle.vec import OracleVecEnv
+    from safe_control_gym_amd.ppo import PPO, PPOConfig
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task('quadrotor_2D_track')
+    cfg = dict(cfg, done_on_out_of_bound=True)
+    n, K, seed = 256, 250, 13
+    pol = np.load(os.path.join(GOLDEN, 'policies.npz'))
+    hidden = int(pol['quadrotor_2D_track/actor.pi_net.fcs.0.weight'].shape[0])
+    env = HipVecEnv(env_id, n, seed=seed, return_numpy=False, policy=(hidden, 'tanh'), **cfg)
+    pcfg = PPOConfig(hidden_dim=hidden, activation='tanh', use_gae=True, rollout_batch_size=n, rollout_steps=8, mini_batch_size=n * 4, opt_epochs=1)
+    ppo = PPO(env, pcfg, seed=0)
+    _load_shipped_policy(ppo, pol, 'quadrotor_2D_track')
+    assert ppo._fused_rollout
+    nobs, nu = env.spec.obs_dim, env.spec.nu
+    f = dict(device=env.device, dtype=torch.float32)
+    obs, actb, logp, rew = torch.zeros(K + 1, n, nobs, **f), torch.zeros(K, n, nu, **f), torch.zeros(K, n, **f), torch.zeros(K, n, **f)
+    done, flags = torch.zeros(K, n, dtype=torch.uint8, device=env.device), torch.zeros(K, n, dtype=torch.uint8, device=env.device)
+    term = torch.zeros(K, n, nobs, **f)
+    env.seed(seed); env.reset_tensors()
+    env.rollout_policy(ppo._policy_struct(True), K, obs, actb, logp, rew, done, flags, terminal_obs=term)
+    torch.cuda.synchronize()
+    # the recorded action is the actor's mean on the recorded observation
+    with torch.no_grad():
+        a_ref = ppo.agent.ac.act(obs[:K].reshape(K * n, nobs)).reshape(K, n, nu)
+    torch.testing.assert_close(actb, a_ref, rtol=1e-4, atol=2e-5)
+    oracle = make_oracle_env(env_id, n, make_rng('philox', n, seed), **cfg)
+    ovec = OracleVecEnv(oracle)
+    obs_o, _ = ovec.reset()
+    O, A, D = _np(obs), _np(actb), _np(done).astype(bool)
+    np.testing.assert_allclose(O[0], obs_o, rtol=2e-6, atol=2e-6)
+    alive = np.ones(n, dtype=bool)                          # envs whose episode boundaries have agreed so far
+    scale, worst = np.zeros(nobs), np.zeros(nobs)
+    n_cmp = 0
+    for t in range(K):
+        obs_o, rew_o, done_o, info = ovec.step(A[t])
+        alive &= (D[t] == done_o)                           # a boundary crossed on one side only desynchronises that env for good
+        keep = alive
+        n_cmp += int(keep.sum())
+        scale = np.maximum(scale, np.abs(obs_o[keep]).max(axis=0))
+        worst = np.maximum(worst, np.abs(O[t + 1][keep] - obs_o[keep]).max(axis=0))
+        d = keep & done_o
+        if d.any():
+            np.testing.assert_allclose(_np(term[t])[d], info['terminal_observation'][d], rtol=0, atol=1e-4 * np.maximum(scale, 1.0).max())
+        np.testing.assert_allclose(_np(rew[t])[keep], rew_o[keep], rtol=2e-4, atol=2e-5)
+    assert alive.mean() >= 0.95, alive.mean()
+    rel = worst / np.maximum(scale, 1e-12)
+    assert (rel <= 1e-4).all(), rel
+    assert D.sum() > 0                                       # episodes ended (time limit: 250 steps) and were reset inside the launch
+    env.close()
+
+
+def _load_shipped_policy(ppo, pol, task):
+    """tests/golden/policies.npz: the actor / critic tensors of the reference's shipped checkpoints under their state-dict names
+    (the parameters are views of the agent's flat buffer: load_state_dict copies in place)."""
+    ppo.agent.ac.load_state_dict({k[len(task) + 1:]: torch.as_tensor(pol[k]) for k in pol.files if k.startswith(task + '/')})

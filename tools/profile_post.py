@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
+SRC = os.path.join(ROOT, 'gpurun_out', os.environ.get('SCG_PROF_DIR', 'prof'))
 DST = os.path.join(ROOT, 'profiles')
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 # workload -> substring of the kernel it is about
@@ -30,8 +30,13 @@ def kernel_of(workload):
     return KERNEL_OF.get(workload, 'step_kernel')
 
 
+def is_kernel(kname, name):
+    """`kname` in a rocprof kernel name; 'step_kernel' also names the split launch of the same step (step_split_kernel, round 5)."""
+    return kname in name or (kname == 'step_kernel' and 'step_split_kernel' in name)
+
+
 def second_half_mean(rows, counter, kname):
-    v = [float(r['Counter_Value']) for r in rows if kname in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    v = [float(r['Counter_Value']) for r in rows if is_kernel(kname, r['Kernel_Name']) and r['Counter_Name'] == counter]
     v = v[len(v) // 2:]
     return (sum(v) / len(v), len(v)) if v else None
 
@@ -55,12 +60,13 @@ for d in sorted(glob.glob(f'{SRC}/kt_*')):
     stats = glob.glob(f'{d}/**/*kernel_stats.csv', recursive=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        keep = [r for r in rows if kname in r['Name'] or float(r['Percentage']) > 0.5]
+        keep = [r for r in rows if is_kernel(kname, r['Name']) or float(r['Percentage']) > 0.5]
         suffix = '' if dt == 'f32' else f'_{dt}'
         with open(f'{DST}/{TAG}_kernel_stats_{work}{suffix}_{N}.csv', 'w', newline='') as f:
             w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
         for r in keep:
-            if kname in r['Name']:
+            if is_kernel(kname, r['Name']):
+                entry['kernel_launched'] = 'step_split_kernel' if 'step_split_kernel' in r['Name'] else kname
                 entry['rocprof_avg_launch_us'] = float(r['AverageNs']) * 1e-3
                 entry['rocprof_calls'] = int(r['Calls'])
                 print(work, dt, N, kname, 'calls', r['Calls'], 'avg ns', r['AverageNs'], 'pct', r['Percentage'])
@@ -84,6 +90,11 @@ for d in sorted(glob.glob(f'{SRC}/kt_*')):
         if kname == 'step_kernel':
             entry['traffic_bytes_per_env_step'] = (fetch + write) / N
         print(work, dt, N, 'traffic B/launch', fetch + write, 'per env', (fetch + write) / N)
+    for C in ('SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_EA0_WRREQ_sum',
+              'TCC_EA0_WRREQ_64B_sum', 'TCC_EA0_WRREQ_STALL_sum', 'TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_VMEM_RD',
+              'TCP_PENDING_STALL_CYCLES_sum', 'TCP_TCC_READ_REQ_LATENCY_sum', 'TCP_TCC_READ_REQ_sum', 'TA_BUSY_avr', 'SQ_INST_CYCLES_VMEM'):
+        if C in vals:
+            entry.setdefault('counters', {})[C] = vals[C][0]
     if 'SQ_INSTS_VALU' in vals and 'SQ_WAVES' in vals and vals['SQ_WAVES'][0] > 0:
         entry['valu_instructions_per_wave'] = vals['SQ_INSTS_VALU'][0] / vals['SQ_WAVES'][0]
         entry['waves_per_launch'] = vals['SQ_WAVES'][0]
@@ -93,6 +104,6 @@ for d in sorted(glob.glob(f'{SRC}/kt_*')):
 if traffic:
     from safe_control_gym_amd import _lib
     traffic['_meta'] = {'source_hash': f'0x{_lib.source_hash():016x}', 'tag': TAG,
-                        'how': 'tools/profile_round4.sh on one MI355X (gpurun), condensed by tools/profile_post.py; the hash is of the kernel '
+                        'how': 'tools/profile_round5.sh (round 4: profile_round4.sh) on one MI355X (gpurun), condensed by tools/profile_post.py; the hash is of the kernel '
                                'sources in the tree when this file was written — run the two back to back'}
     json.dump(traffic, open(f'{DST}/{TAG}_hbm_traffic.json', 'w'), indent=1)

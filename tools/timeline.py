@@ -46,6 +46,8 @@ else:
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
         env = HipVecEnv(env_id, n, seed=1, return_numpy=False, **cfg)
         env.bind_outputs(state=None, noisy_action=None)
+        split = not (len(sys.argv) > 3 and sys.argv[3] == 'nosplit') and n <= 98304
+        env.set_split_max_envs((1 << 30) if split else 0)
         env.reset_tensors()
         acts = [torch.rand(n, 2, device='cuda') * 2 - 1 for _ in range(16)]
         L = env._lib
@@ -57,18 +59,32 @@ else:
                 torch.cuda.synchronize()
                 buf = np.zeros(4096 * 8, dtype=np.uint64)
                 assert L.scg_exp_timeline(buf.ctypes.data, buf.size) == 0
-                t = buf.reshape(4096, 8)[:max(1, n // 64)].astype(np.int64)
+                groups = max(1, n // 64)
+                n_waves = 2 * ((groups + 7) // 8 * 8) if split else groups       # split launch: workgroup b = role (b / 8) % 2
+                t = buf.reshape(4096, 8)[:min(n_waves, 4096)].astype(np.int64)
                 rows.append(t)
-        t = np.stack(rows)                                # [iters][waves][marks]; XCD clocks are not mutually synchronised
-        d = np.diff(t, axis=2).reshape(-1, 7)             # per-wave phase durations
-        tot = (t[:, :, 7] - t[:, :, 0]).reshape(-1)
-        print(f'{n} envs, {t.shape[1]} waves, {t.shape[0]} launches; shader-clock ticks per phase (per wave)')
-        print(f'  {"phase":34s} {"mean":>7s} {"p10":>7s} {"p50":>7s} {"p90":>7s} {"share":>6s}')
-        for k in range(7):
-            col = d[:, k]
-            print(f'  {MARKS[k] + " -> " + MARKS[k + 1]:34s} {col.mean():7.0f} {np.percentile(col, 10):7.0f} {np.median(col):7.0f} '
-                  f'{np.percentile(col, 90):7.0f} {col.mean() / tot.mean():6.1%}')
-        print(f'  {"entry -> end":34s} {tot.mean():7.0f} {np.percentile(tot, 10):7.0f} {np.median(tot):7.0f} {np.percentile(tot, 90):7.0f}')
+        t_all = np.stack(rows)                            # [iters][waves][marks]; XCD clocks are not mutually synchronised
+        wave = np.arange(t_all.shape[1])
+        roles = [('every output (one wave per 64 envs)', np.ones_like(wave, dtype=bool))] if not split else \
+            [('ROLE_SCORE (reward / done / constraint rows / statistics)', ((wave >> 3) & 1) == 0),
+             ('ROLE_STATE (observation / auto-reset / state)', ((wave >> 3) & 1) == 1)]
+        for name, sel in roles:
+            t = t_all[:, sel, :]
+            d = np.diff(t, axis=2).reshape(-1, 7)             # per-wave phase durations
+            tot = (t[:, :, 7] - t[:, :, 0]).reshape(-1)
+            print(f'{n} envs, {name}: {t.shape[1]} waves, {t.shape[0]} launches; shader-clock ticks per phase (per wave)')
+            print(f'  {"phase":34s} {"mean":>7s} {"p10":>7s} {"p50":>7s} {"p90":>7s} {"share":>6s}')
+            for k in range(7):
+                col = d[:, k]
+                print(f'  {MARKS[k] + " -> " + MARKS[k + 1]:34s} {col.mean():7.0f} {np.percentile(col, 10):7.0f} {np.median(col):7.0f} '
+                      f'{np.percentile(col, 90):7.0f} {col.mean() / tot.mean():6.1%}')
+            print(f'  {"entry -> end":34s} {tot.mean():7.0f} {np.percentile(tot, 10):7.0f} {np.median(tot):7.0f} {np.percentile(tot, 90):7.0f}')
+        # spread of the waves' entry times within a launch (per XCD clock domain the marks are comparable: workgroup b runs on XCD b % 8)
+        ent = t_all[:, :, 0]
+        per_xcd = [ent[:, x::8].max(axis=1) - ent[:, x::8].min(axis=1) for x in range(8)]
+        print(f'  first -> last wave entry within one XCD (dispatch spread): mean {np.mean(per_xcd):.0f} ticks, max {np.max(per_xcd):.0f}')
+        endspan = [t_all[:, x::8, 7].max(axis=1) - t_all[:, x::8, 0].min(axis=1) for x in range(8)]
+        print(f'  first entry -> last end within one XCD: mean {np.mean(endspan):.0f} ticks')
         sys.stdout.flush(); os._exit(0)
     finally:
         shutil.copy('/tmp/keep.so', real)
