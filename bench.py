@@ -48,7 +48,22 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 TRAFFIC_FILE = 'r05_hbm_traffic.json'
 SEQ_K, SEQ_K_ALL = 32, 8        # control steps per launch of the two scg_step_sequence workloads (sequence_leg, tools/seq_profile.py)
 SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
-SPLIT_MAX_ENVS = int(os.environ.get('SCG_SPLIT_MAX_ENVS', 98304))      # scg_kernels.hip default: shards up to this size take the split step launch
+# scg_kernels.hip defaults (scg_set_step_launch): which launch geometry of the step kernel a shard of N envs takes
+LAUNCH_SPLIT_MAX = int(os.environ.get('SCG_SPLIT_MAX_ENVS', 32768))
+LAUNCH_PAIR_MAX = int(os.environ.get('SCG_PAIR_MAX_ENVS', 98304))
+LAUNCH_WIDE_MIN = int(os.environ.get('SCG_WIDE_MIN_ENVS', 2097152))
+
+
+def launch_geometry(n, specialised):
+    if not specialised:
+        return 'step_kernel (generic library: 256-thread workgroups, parameters staged in LDS)'
+    if n <= LAUNCH_SPLIT_MAX:
+        return 'step_split_kernel (two independent waves per 64 envs, each half of the outputs)'
+    if n <= LAUNCH_PAIR_MAX and n >= 256:
+        return 'step_pair_kernel (paired waves: one integrates, both evaluate behind one workgroup barrier)'
+    if n >= LAUNCH_WIDE_MIN:
+        return 'step_wide_kernel (256-thread workgroups)'
+    return 'step_kernel (one wave per 64 envs, one-wave workgroups)'
 
 
 def parse():
@@ -249,7 +264,7 @@ class StepBench:
         return bool(self.torch.isfinite(self.out.reward).all().item()) and int(self.out.fin_length.max().item()) > 0
 
 
-def roofline_of(task, dtype_name, n, period_us, driver_step_us=None, split=False):
+def roofline_of(task, dtype_name, n, period_us, driver_step_us=None, geometry=None):
     """`frac` = algorithmic bytes per launch / the launch period measured HERE with HIP events inside back-to-back graph replays.
     `frac_by_clock` puts the other two clocks beside it so that no reader takes one for another: the rocprofv3 --kernel-trace average
     duration of the same kernel (committed under profiles/, quoted while the kernel-source hash matches; the tracer adds ~0.4 us per
@@ -265,7 +280,7 @@ def roofline_of(task, dtype_name, n, period_us, driver_step_us=None, split=False
             'frac_by_clock': {'in_graph_hip_events': {'us': period_us, 'frac': frac_of(period_us)},
                               'rocprofv3_kernel_trace_avg': {'us': rocprof_us, 'frac': frac_of(rocprof_us)},
                               'driver_timed_step': {'us': driver_step_us, 'frac': frac_of(driver_step_us)}},
-            'kernel': KERNEL_NAME.get(task, 'step_kernel') + (' as step_split_kernel (two waves per 64 envs, each half of the outputs)' if split else ''),
+            'kernel': KERNEL_NAME.get(task, 'step_kernel') + (f' launched as {geometry}' if geometry else ''),
             'avg_launch_us': period_us, 'algorithmic_bytes_per_env_step': algo,
             'valu_issue': valu_issue_of(task, dtype_name, n, period_us)}
 
@@ -584,6 +599,40 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
                               'paid once per process (`cold_start_s`, measured here)'}
 
 
+def multi_gpu_readiness(torch, dist, world):
+    """What ONE GPU can say about the N > 1 path (DESIGN.md section 5 holds the expectation table these numbers feed): the number
+    and size of the collectives per learner iteration and the fixed cost of one such all-reduce on the RCCL path (one rank: enqueue
+    + kernel, no wire), eager and captured in a HIP graph — the data-parallel PPO epoch is one graph replay (ppo.py::_dp_epoch)."""
+    from safe_control_gym_amd import parallel
+    res = {'ppo': {'collectives_per_iteration': 64, 'bucket_bytes': 4 * 36742, 'what': 'flat fp32 gradients of actor + critic (12-128-128-{2,1}) + the approx-KL slot, '
+                   'SUM all-reduce, 1 / world folded into scg_adam_gated_scaled; 2 epochs x 32 minibatches', 'host_enqueues_per_iteration_over_rccl': 2,
+                   'host_path': 'one HIP-graph replay per epoch: 32 x (gradient kernel, reduction, all-reduce, gated Adam)'},
+           'sac': {'collectives_per_vector_step': 32, 'bucket_bytes': 4 * 61451, 'what': 'the flat fp32 gradient vector (actor + log alpha + both critics, 24-128-128 nets) SUM-all-reduced '
+                   'twice per gradient step (after the actor phase, after the critic phase), 16 gradient steps per vector step (sac.py::_fused_step_dp)',
+                   'host_enqueues_per_vector_step_over_rccl': 1, 'host_path': 'one HIP-graph replay per vector step (16 gradient steps, 32 all-reduces)'},
+           'env_shards': 'independent (global env ids [rank N, (rank + 1) N)): no data-path collective, weak scaling',
+           'measured_with_more_than_one_gpu': False}
+    made = False
+    try:
+        if world == 1 and not dist.is_initialized():
+            import socket
+            s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ['MASTER_PORT'] = str(port)
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
+            made = True
+        res['allreduce_us'] = parallel.allreduce_probe((4 * 36742, 4 * 61451))
+        res['allreduce_us']['note'] = f'{dist.get_world_size()} rank(s), in-place fp32 SUM, microseconds per collective'
+    except Exception as exc:                                            # noqa: BLE001
+        res['allreduce_us'] = {'error': repr(exc)[:200]}
+    finally:
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:                                           # noqa: BLE001
+                pass
+    return res
+
+
 def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, lr=1e-3, warm_up_steps=65536, eval_every=50,
             buffer=4_000_000, world=1, rank=0, param_rand=None):
     """SAC wall-clock-to-reward on BASELINE config #5's env (Quadrotor3D figure-8 tracking, white-noise dynamics disturbance,
@@ -803,7 +852,7 @@ def main():
                                  + ('; per rank: barrier + synchronize, clock, K steps, synchronize, clock, barrier; MAX over ranks' if world > 1 else ''),
                        'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))]},
             'roofline': roofline_of(args.task, args.dtype, N, period_us, driver_step_us=1e6 * elapsed / done_steps,
-                                    split=bool(hb.env.specialized) and N <= SPLIT_MAX_ENVS),
+                                    geometry=launch_geometry(N, bool(hb.env.specialized))),
         }
     full = not args.no_secondary and args.task == 'quadrotor_2D_track' and args.dtype == 'f32'
     # The learning legs run collectives (N > 1: RCCL).  A rank that dies or hangs inside one must not cost the run its line:
@@ -872,6 +921,8 @@ def main():
         if rank == 0:
             out['sac'] = res
     watchdog.cancel()
+    if rank == 0 and full:
+        out['multi_gpu'] = multi_gpu_readiness(torch, dist, world)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.task, hb.cfg, hb.env_id, args.cpu_seconds, N)

@@ -79,6 +79,11 @@ int scg_ppo_grad(const scg_ppo_grad_args* args, void* stream);
 int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor, float lr_critic,
                    float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, uint32_t* d_block_counter,
                    void* stream);
+/* The same with every read of d_g (the gradients AND the approx-KL slot d_g[n]) multiplied by grad_scale: data-parallel callers
+ * SUM-all-reduce the flat gradient buffer and pass 1 / world here instead of launching a division in between. */
+int scg_adam_gated_scaled(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor, float lr_critic,
+                          float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats, uint32_t* d_block_counter,
+                          float grad_scale, void* stream);
 
 /* One optimiser step of PPOAgent.update (ppo_utils.py:113-146) on ONE GPU in two launches: the gradient kernel of scg_ppo_grad, then
  * a kernel that sums the workgroups' partial gradients AND applies the two gated Adam steps of scg_adam_gated element by element (each

@@ -663,6 +663,14 @@ struct EnvOps {
         e.gid = (uint32_t)(P.i.env_id_offset + i);
         e.pre_n = 0;
     }
+    // counters only (the consumer wave of a paired step launch: its raw state arrives through LDS)
+    __device__ static __forceinline__ void load_counters(const PV<T>& P, int i, E& e) {
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
+        e.step = slot_in<int32_t>(ws, P.i.step_off, i).load();
+        e.episode = slot_in<uint32_t>(ws, P.i.episode_off, i).load();
+        e.gid = (uint32_t)(P.i.env_id_offset + i);
+        e.pre_n = 0;
+    }
     __device__ static __forceinline__ void load_params(const PV<T>& P, int i, E& e) {
         const size_t N = (size_t)P.i.num_envs;
         if (P.c.per_env_params) {
@@ -1101,15 +1109,30 @@ SCG_BOX_UNROLL
 
     // One control step, no auto-reset.  `act_in` = raw controller action; `adv` = adversary action or null.
     // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
+    // = advance() (action pre-processing, disturbances, the engine substeps: the raw state in `e` moves) followed by evaluate()
+    // (env.state, reward, done, mse, constraint rows, time limit: pure functions of the advanced state and the noisy action).  The
+    // paired step launch (step_pair_kernel) runs the two halves in different waves.
     template <int SLOT_AUX>
     __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,
                                                       T* st, T* noisy_out, Slot<T, SLOT_AUX> c_out, size_t c_stride,
                                                       const T* ref_pre = nullptr, const T* ext_pre = nullptr,
                                                       const T* ext_reset = nullptr) {
+        T noisy[D::NU];
+        advance(P, e, act_in, adv, key, env_index, noisy);
+        if (noisy_out) {
+#pragma unroll
+            for (int j = 0; j < D::NU; ++j) noisy_out[j] = noisy[j];
+        }
+        return evaluate(P, goal_tab, e, noisy, env_index, st, c_out, c_stride, ref_pre, ext_pre, ext_reset);
+    }
+
+    // First half of step(): `noisy` = the action after normalisation, action disturbances and the adversary, BEFORE clipping.
+    __device__ static __forceinline__ void advance(const PV<T>& P, E& e, const T* act_in, const T* adv, RngKey key, int env_index,
+                                                   T* noisy) {
         const int32_t c0 = e.step;      // ctrl_step_counter before the increment
         // ---- _preprocess_control
-        T noisy[D::NU], clipped[D::NU];
+        T clipped[D::NU];
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) {
             T a = act_in[j];
@@ -1140,10 +1163,7 @@ SCG_BOX_UNROLL
             }
         }
 #pragma unroll
-        for (int j = 0; j < D::NU; ++j) {
-            clipped[j] = m_clamp(noisy[j], P.c.act_low[j], P.c.act_high[j]);
-            if (noisy_out) noisy_out[j] = noisy[j];
-        }
+        for (int j = 0; j < D::NU; ++j) clipped[j] = m_clamp(noisy[j], P.c.act_low[j], P.c.act_high[j]);
         // ---- physics
         if (P.c.integrator == SCG_INT_RK4) {
             rk4_advance(P, e, clipped);
@@ -1622,6 +1642,19 @@ SCG_BOX_UNROLL
             }
         }
         }   // integrator
+    }
+
+    // Second half of step(): everything the reference derives from the advanced state.  `e.step` is still the PRE-increment counter
+    // on entry and is incremented here.
+    template <int SLOT_AUX>
+    __device__ static __forceinline__ StepResult evaluate(const PV<T>& P, const GoalTab<T>& goal_tab, E& e, const T* noisy, int env_index,
+                                                          T* st, Slot<T, SLOT_AUX> c_out, size_t c_stride,
+                                                          const T* ref_pre = nullptr, const T* ext_pre = nullptr,
+                                                          const T* ext_reset = nullptr) {
+        const int32_t c0 = e.step;      // ctrl_step_counter before the increment
+        T clipped[D::NU];
+#pragma unroll
+        for (int j = 0; j < D::NU; ++j) clipped[j] = m_clamp(noisy[j], P.c.act_low[j], P.c.act_high[j]);
         state_vector(e, st);
         // rows of X_GOAL requested before the integrator: retire them here, ahead of the first store
         if (ref_pre) {

@@ -72,20 +72,25 @@ struct scg_env {
     uint8_t* d_oob;
     bool has_reset;
     bool has_dist;
-    int split_max;           // largest shard (envs) that takes the split step launch (specialised builds; scg_set_split_max_envs)
+    // step-launch geometry of the specialised builds by shard size (scg_set_step_launch): <= split_max: two waves per 64 envs, each
+    // the whole step for half of the outputs; <= pair_max: paired waves (one advances, both evaluate); >= wide_min: 256-thread workgroups
+    int split_max, pair_max, wide_min;
 };
 
-// Largest shard that takes the split step launch by default (environment variable SCG_SPLIT_MAX_ENVS overrides the built-in
-// threshold; 0 = never).  65 536 envs = one wave per SIMD: measured on MI355X (profiles/r05_step_kernel_ab.md).
+// Step-launch geometry by shard size, measured on MI355X (profiles/r05_step_kernel_ab.md); the environment variables of the same names
+// override the built-in thresholds at scg_create, scg_set_step_launch per handle.
 #ifndef SCG_SPLIT_MAX_ENVS
-#define SCG_SPLIT_MAX_ENVS 98304
+#define SCG_SPLIT_MAX_ENVS 32768          // <= half a wave per SIMD: two independent waves per 64 envs (step_split_kernel)
 #endif
-static int default_split_max_envs() {
-    static const int v = [] {
-        const char* s = std::getenv("SCG_SPLIT_MAX_ENVS");
-        return s && *s ? std::atoi(s) : (int)SCG_SPLIT_MAX_ENVS;
-    }();
-    return v;
+#ifndef SCG_PAIR_MAX_ENVS
+#define SCG_PAIR_MAX_ENVS 98304           // around one wave per SIMD: paired waves (step_pair_kernel)
+#endif
+#ifndef SCG_WIDE_MIN_ENVS
+#define SCG_WIDE_MIN_ENVS 2097152         // streaming from HBM: 256-thread workgroups (step_wide_kernel)
+#endif
+static int launch_default(const char* name, int built_in) {
+    const char* s = std::getenv(name);
+    return s && *s ? std::atoi(s) : built_in;
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -565,7 +570,9 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->d_state = w + L.state; e->d_param = w + L.param; e->d_step = (int32_t*)(w + L.step);
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
-    e->split_max = default_split_max_envs();
+    e->split_max = launch_default("SCG_SPLIT_MAX_ENVS", SCG_SPLIT_MAX_ENVS);
+    e->pair_max = launch_default("SCG_PAIR_MAX_ENVS", SCG_PAIR_MAX_ENVS);
+    e->wide_min = launch_default("SCG_WIDE_MIN_ENVS", SCG_WIDE_MIN_ENVS);
     e->has_dist = cfg->n_dist[0] > 0 || cfg->n_dist[1] > 0 || cfg->n_dist[2] > 0 || cfg->adversary_channel >= 0;
     hipError_t err = hipMemset(d_workspace, 0, L.total);
     if (err == hipSuccess) err = hipMemset(e->d_episode, 0xff, (size_t)cfg->num_envs * 4);   // first reset -> episode 0
@@ -676,6 +683,40 @@ static int launch_step(scg_env* env, int first, int count, const void* action, c
             DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, true><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
         } else {
             DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, false><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+        }
+        HIP_TRY(hipGetLastError());
+        return SCG_OK;
+    }
+    // Paired launch (step_pair_kernel): full workgroups of PAIR_ENVS envs; what is left of the shard (< PAIR_ENVS envs) goes through the
+    // plain kernel below as a second, small launch.
+    if (count <= env->pair_max && count >= PAIR_ENVS) {
+        const int groups = count / PAIR_ENVS;
+        InstParams<T> Ip = I;
+        Ip.env_end = first + groups * PAIR_ENVS;
+        if (one_base) {
+            DISPATCH_SYS(env, T, (step_pair_kernel<S, T, DD, true><<<dim3(groups), dim3(2 * PAIR_ENVS), 0, st>>>(C, Ip, (const T*)action, (const T*)adv, O1)));
+        } else {
+            DISPATCH_SYS(env, T, (step_pair_kernel<S, T, DD, false><<<dim3(groups), dim3(2 * PAIR_ENVS), 0, st>>>(C, Ip, (const T*)action, (const T*)adv, O)));
+        }
+        HIP_TRY(hipGetLastError());
+        const int rest = count - groups * PAIR_ENVS;
+        if (rest == 0) return SCG_OK;
+        I.env_first = first + groups * PAIR_ENVS;
+        const int grid_r = (rest + BLOCK - 1) / BLOCK;
+        if (one_base) {
+            DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid_r), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
+        } else {
+            DISPATCH_SYS(env, T, (step_kernel<S, T, DD, false><<<dim3(grid_r), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+        }
+        HIP_TRY(hipGetLastError());
+        return SCG_OK;
+    }
+    if (count >= env->wide_min) {
+        const int grid_w = (count + WIDE_BLOCK - 1) / WIDE_BLOCK;
+        if (one_base) {
+            DISPATCH_SYS(env, T, (step_wide_kernel<S, T, DD, true><<<dim3(grid_w), dim3(WIDE_BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
+        } else {
+            DISPATCH_SYS(env, T, (step_wide_kernel<S, T, DD, false><<<dim3(grid_w), dim3(WIDE_BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
         }
         HIP_TRY(hipGetLastError());
         return SCG_OK;
@@ -879,10 +920,11 @@ extern "C" int scg_get_params(scg_env* env, double* h_params, int first_env, int
     return env->dtype == SCG_F64 ? copy_soa<double>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream)
                                  : copy_soa<float>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream);
 }
-extern "C" int scg_set_split_max_envs(scg_env* env, int max_envs) {
+extern "C" int scg_set_step_launch(scg_env* env, int split_max_envs, int pair_max_envs, int wide_min_envs) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
-    if (max_envs < 0) return fail(SCG_ERR_INVALID, "max_envs must be >= 0");
-    env->split_max = max_envs;
+    if (split_max_envs >= 0) env->split_max = split_max_envs;
+    if (pair_max_envs >= 0) env->pair_max = pair_max_envs;
+    if (wide_min_envs >= 0) env->wide_min = wide_min_envs;
     return SCG_OK;
 }
 

@@ -681,13 +681,14 @@ struct AdamArgs {
     float target_kl;
     float* stats_acc; const float* stats;       // running sums over the update: 3 losses, kl, actor steps taken
     unsigned int* done;     // block counter (0 between launches): the last block to finish advances the step counts
+    float gscale;           // every read of `g` (gradients and the approx-KL slot) is scaled by this: 1 / world after a SUM all-reduce
 };
 
 // Every thread reads the step counts before its block signs off; the LAST block to sign off advances them (and the running
 // statistics) and re-arms the counter — one launch instead of an update kernel plus a one-thread bookkeeping kernel.
 __global__ __launch_bounds__(256) void adam_gated_kernel(const AdamArgs A) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const float kl = A.g[A.n];
+    const float kl = A.g[A.n] * A.gscale;
     const bool gate = A.target_kl <= 0.0f || kl <= 1.5f * A.target_kl;
     const float t_actor = A.steps[0] + 1.0f, t_critic = A.steps[1] + 1.0f;
     if (e < A.n) {
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256) void adam_gated_kernel(const AdamArgs A) {
         if (critic || gate) {
             const float t = critic ? t_critic : t_actor;
             const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-            const float g = A.g[e];
+            const float g = A.g[e] * A.gscale;
             const float m = b1 * A.m[e] + (1.0f - b1) * g;
             const float v = b2 * A.v[e] + (1.0f - b2) * g * g;
             A.m[e] = m; A.v[e] = v;
@@ -847,12 +848,19 @@ extern "C" int scg_ppo_step(const scg_ppo_grad_args* a, float* d_m, float* d_v, 
     return 0;
 }
 
-extern "C" int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor,
-                              float lr_critic, float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats,
-                              uint32_t* d_block_counter, void* stream) {
+extern "C" int scg_adam_gated_scaled(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor,
+                                     float lr_critic, float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats,
+                                     uint32_t* d_block_counter, float grad_scale, void* stream) {
     if (!d_p || !d_g || !d_m || !d_v || !d_steps || !d_block_counter || n <= 0) return fail(-1, "scg_adam_gated: bad argument");
-    AdamArgs A{d_p, d_g, d_m, d_v, n, n_actor, lr_actor, lr_critic, d_steps, target_kl, d_stats_acc, d_stats, d_block_counter};
+    AdamArgs A{d_p, d_g, d_m, d_v, n, n_actor, lr_actor, lr_critic, d_steps, target_kl, d_stats_acc, d_stats, d_block_counter, grad_scale};
     adam_gated_kernel<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(A);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int scg_adam_gated(float* d_p, const float* d_g, float* d_m, float* d_v, int n, int n_actor, float lr_actor,
+                              float lr_critic, float* d_steps, float target_kl, float* d_stats_acc, const float* d_stats,
+                              uint32_t* d_block_counter, void* stream) {
+    return scg_adam_gated_scaled(d_p, d_g, d_m, d_v, n, n_actor, lr_actor, lr_critic, d_steps, target_kl, d_stats_acc, d_stats,
+                                 d_block_counter, 1.0f, stream);
 }

@@ -36,6 +36,53 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def collectives_capturable():
+    """True when a collective on a device tensor can be recorded into a HIP graph with the kernels around it: RCCL (torch's "nccl"
+    backend).  gloo stages through the host and cannot."""
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
+
+
+def allreduce_probe(nbytes_list=(147 * 1024, 246 * 1024), reps=200, device=None):
+    """Latency of an in-place SUM all-reduce of `nbytes` fp32 on THIS process group, eager (one enqueue per call) and captured
+    (50 collectives per HIP-graph replay), in microseconds per collective.  With one rank it measures the fixed cost of the RCCL
+    path (enqueue, kernel launch, no wire) — the part of a data-parallel optimiser step that the number of GPUs does not change."""
+    out = {}
+    if not collectives_capturable():
+        return {'error': 'needs an initialised "nccl" (RCCL) process group'}
+    dev = device or torch.device('cuda', torch.cuda.current_device())
+    for nbytes in nbytes_list:
+        t = torch.zeros(nbytes // 4, device=dev)
+        for _ in range(10):
+            dist.all_reduce(t)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(t)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        row = {'eager_us': 1e3 * e0.elapsed_time(e1) / reps}
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(50):
+                    dist.all_reduce(t)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(max(1, reps // 50)):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            row['captured_us'] = 1e3 * e0.elapsed_time(e1) / (50 * max(1, reps // 50))
+        except Exception as exc:                                    # noqa: BLE001
+            row['captured_us'] = None
+            row['capture_error'] = repr(exc)[:200]
+        out[str(nbytes)] = row
+    out['world'] = dist.get_world_size()
+    return out
+
+
 def _through_host(t):
     """gloo (tests: several ranks sharing one GPU) has no device collectives in this build: stage device tensors on the host."""
     return t.is_cuda and dist.get_backend() == 'gloo'

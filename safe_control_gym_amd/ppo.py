@@ -190,6 +190,7 @@ class PPOAgent:
         self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
                           and _learn.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._fused = None
+        self.dp_path, self.dp_capture_error = None, None                   # how the last data-parallel epoch ran (_dp_epoch)
         self._fused_step_ok = bool(cfg.extra.get('fused_step', True))      # (False: scg_ppo_grad + scg_adam_gated also on one rank — A/B, tests)
 
     # ---- graphed update -------------------------------------------------------------------------------------
@@ -265,14 +266,57 @@ class PPOAgent:
         st = F['C'].c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _learn.check(F['lib'], F['lib'].scg_ppo_grad(F['C'].byref(F['args']), st))
 
-    def _fused_adam(self, F):
+    def _fused_adam(self, F, grad_scale=1.0):
+        """The two gated Adam steps on the flat buffers; `grad_scale` multiplies every read of the gradient buffer (1 / world after
+        the SUM all-reduce of a data-parallel step: no division launch in between)."""
         from safe_control_gym_amd import _learn
         fl, cfg, C = self._flat, self.cfg, F['C']
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _learn.check(F['lib'], F['lib'].scg_adam_gated(
+        _learn.check(F['lib'], F['lib'].scg_adam_gated_scaled(
             fl['p'].data_ptr(), fl['g'].data_ptr(), fl['m'].data_ptr(), fl['v'].data_ptr(), fl['n'], fl['n_a'],
             float(cfg.actor_lr), float(cfg.critic_lr), fl['steps'].data_ptr(), float(cfg.target_kl),
-            F['stats_acc'].data_ptr(), F['stats'].data_ptr(), F['adam_sync'].data_ptr(), st))
+            F['stats_acc'].data_ptr(), F['stats'].data_ptr(), F['adam_sync'].data_ptr(), float(grad_scale), st))
+
+    def _dp_minibatches(self, F, perm, n_mb, world):
+        """Data-parallel minibatch loop of one epoch: gradient kernel -> ONE flat SUM all-reduce (both networks' gradients + the
+        approx-KL slot) -> gated Adam reading the sum x 1 / world."""
+        for j in range(n_mb):
+            F['args'].d_idx = perm[j].data_ptr()
+            self._fused_grad(F)
+            parallel.all_reduce_sum_(self._flat['g'])
+            self._fused_adam(F, 1.0 / world)
+
+    def _dp_epoch(self, F, perm, bank, n_mb, world):
+        """One epoch of data-parallel optimiser steps.  Over RCCL (backend "nccl") the whole loop — n_mb x (gradient kernel, reduction,
+        all-reduce, Adam) — is ONE HIP-graph replay per epoch: the collective is captured with the kernels around it, so an iteration
+        costs the host `opt_epochs` replays instead of n_mb x opt_epochs enqueue round trips (64 per iteration in bench.py's
+        configuration).  The first epoch that sees a (permutation bank, n_mb) pair runs eagerly (it warms the communicator up for this
+        message size), the second captures; a capture that fails falls back to the eager loop for good (recorded in `dp_path`)."""
+        graphs = F.setdefault('dp_graphs', {})
+        key = (bank, n_mb)
+        state = graphs.get(key)
+        want = parallel.collectives_capturable() and self.cfg.extra.get('graph_collectives', True)
+        if not want or state == 'eager':
+            self.dp_path = 'eager'
+            return self._dp_minibatches(F, perm, n_mb, world)
+        if state is None:
+            graphs[key] = 'warm'
+            self.dp_path = 'eager (first epoch on this buffer: warm-up)'
+            return self._dp_minibatches(F, perm, n_mb, world)
+        if state == 'warm':
+            try:
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._dp_minibatches(F, perm, n_mb, world)
+                graphs[key] = state = g
+            except Exception as exc:                                  # noqa: BLE001  (no capture support in this build: stay eager)
+                graphs[key] = 'eager'
+                self.dp_capture_error = repr(exc)[:200]
+                self.dp_path = 'eager (capture failed)'
+                return self._dp_minibatches(F, perm, n_mb, world)
+        state.replay()
+        self.dp_path = f'one graph replay per epoch ({n_mb} x (grad, reduce, all-reduce, adam))'
 
     def _fused_step(self, F):
         """One optimiser step on ONE rank in two launches (scg_ppo_step): gradient kernel, then reduction + gated Adam in one kernel.
@@ -318,6 +362,7 @@ class PPOAgent:
         from safe_control_gym_amd import _learn
         if 'perm' not in F or F['perm'].shape[1] != n_mb * mb:
             F['perm'] = torch.empty(2, n_mb * mb, dtype=torch.int32, device=self.device)
+            F.pop('dp_graphs', None)                                # (captured epochs hold the old buffer's addresses)
         for k, v in data.items():
             if F['data'][k].data_ptr() != v.data_ptr():
                 F['data'][k].copy_(v)
@@ -334,16 +379,21 @@ class PPOAgent:
                     _learn.check(F['lib'], F['lib'].scg_random_permutation(perm.data_ptr(), M, n_mb * mb, key,
                                                                            F['C'].c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
                     perm = perm.view(n_mb, mb)
-                for j in range(n_mb):
-                    F['args'].d_idx = perm[j].data_ptr()
-                    if world == 1 and self._fused_step_ok:
-                        self._fused_step(F)                         # gradient kernel + (reduction and gated Adam in one launch)
-                        continue
-                    self._fused_grad(F)
-                    if world > 1:                                   # gradients of both networks + approx_kl, one collective
-                        parallel.all_reduce_sum_(self._flat['g'])
-                        self._flat['g'].div_(world)
-                    self._fused_adam(F)
+                if world > 1 or cfg.extra.get('force_data_parallel'):   # gradients of both networks + approx_kl: one collective per step
+                    # (force_data_parallel: the data-parallel path on ONE rank — tests and the 1-GPU measurement of its fixed cost)
+                    bank = ((self._perm_count - 1) % 2) if generator is None else None      # (the bank `perm` was just written to)
+                    if bank is None:
+                        self._dp_minibatches(F, perm, n_mb, world)
+                    else:
+                        self._dp_epoch(F, perm, bank, n_mb, world)
+                else:
+                    for j in range(n_mb):
+                        F['args'].d_idx = perm[j].data_ptr()
+                        if self._fused_step_ok:
+                            self._fused_step(F)                     # gradient kernel + (reduction and gated Adam in one launch)
+                        else:
+                            self._fused_grad(F)
+                            self._fused_adam(F)
                 F['keep'] = perm                                    # (the index rows must outlive the queued launches)
             if self._flat.get('bank'):                              # an odd number of fused steps: the counts are in the scratch bank
                 self._flat['steps'].copy_(self._flat['steps_b'])

@@ -204,6 +204,7 @@ class SACAgent:
                           and _sac.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._flat = self._flatten(low, high) if self.use_fused else None
         self._fused = None
+        self.dp_path, self.dp_capture_error = None, None       # how the last data-parallel update ran (_update_fused)
         if self.use_fused:          # one-time kernel attributes NOW (not a stream operation: must not fall into a later graph capture)
             with torch.cuda.device(self.log_alpha.device):
                 D = _sac.lib(obs_dim, cfg.hidden_dim, act_dim, cfg.activation)
@@ -294,7 +295,7 @@ class SACAgent:
         the critics' gradient are averaged over the ranks where sac_utils.py's update would call backward() — two all-reduces of
         the flat gradient vector per step (RCCL; latency-bound at 246 KB), everything else stays the fused kernels."""
         from safe_control_gym_amd import _sac
-        g, world = self._flat['g'], parallel.world_size()
+        g, world = self._flat['g'], max(parallel.world_size(), 1)
         self._fused_step(F, _sac.ACTOR_GRAD)
         parallel.all_reduce_sum_(g)
         g.div_(world)
@@ -312,8 +313,33 @@ class SACAgent:
         F = self._fused
         F['acc'].zero_()
         dev = self._flat['p'].device
-        if parallel.world_size() > 1:               # collectives between the parts of a step: launched eagerly, not captured
+        if parallel.world_size() > 1 or self.cfg.extra.get('force_data_parallel'):
+            # Collectives between the parts of a step.  Over RCCL the n_updates steps (two all-reduces each) are ONE HIP-graph replay —
+            # the first call runs eagerly (it warms the communicator up), the second captures; over gloo, or if the capture fails, the
+            # steps are enqueued one by one (`dp_path` says which ran).
             with torch.cuda.device(dev):
+                key = ('dp', n_updates)
+                state = F['graphs'].get(key)
+                if parallel.collectives_capturable() and self.cfg.extra.get('graph_collectives', True) and state != 'eager':
+                    if state is None:
+                        F['graphs'][key] = 'warm'
+                    elif state == 'warm':
+                        try:
+                            torch.cuda.synchronize(dev)
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g):
+                                for _ in range(n_updates):
+                                    self._fused_step_dp(F)
+                            F['graphs'][key] = state = g
+                        except Exception as exc:                    # noqa: BLE001
+                            F['graphs'][key] = state = 'eager'
+                            self.dp_capture_error = repr(exc)[:200]
+                    if isinstance(state, torch.cuda.CUDAGraph):
+                        state.replay()
+                        self.dp_path = f'one graph replay per vector step ({n_updates} gradient steps, {2 * n_updates} all-reduces)'
+                        st = (F['acc'] / n_updates).tolist()
+                        return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
+                self.dp_path = 'eager'
                 for _ in range(n_updates):
                     self._fused_step_dp(F)
             st = (F['acc'] / n_updates).tolist()

@@ -106,6 +106,7 @@ def test_rollout_policy_simulator_vs_oracle_on_the_recorded_actions():
     torch.testing.assert_close(actb, a_ref, rtol=1e-4, atol=2e-5)
     oracle = make_oracle_env(env_id, n, make_rng('philox', n, seed), **cfg)
     ovec = OracleVecEnv(oracle)
+    ovec.reset()                                            # (PPO's constructor had reset `env` once already: same episode indices)
     obs_o, _ = ovec.reset()
     O, A, D = _np(obs), _np(actb), _np(done).astype(bool)
     np.testing.assert_allclose(O[0], obs_o, rtol=2e-6, atol=2e-6)

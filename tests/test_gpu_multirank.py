@@ -261,3 +261,48 @@ print('RCCL_ONE_RANK_OK')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
     res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and 'RCCL_ONE_RANK_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_graph_captured_data_parallel_epoch_over_rccl_with_one_rank():
+    """The data-parallel PPO optimiser loop as the driver's N > 1 runs execute it over RCCL — per epoch ONE HIP-graph replay of
+    n_mb x (gradient kernel, reduction, flat all-reduce, gated Adam reading the sum x 1 / world) — on one GPU: a one-rank `nccl`
+    process group with `force_data_parallel`, three iterations (eager warm-up, capture, replay), must leave bit for bit the weights
+    of the single-rank scg_ppo_grad + scg_adam_gated loop; and the probe behind bench.py's `multi_gpu` object runs."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from safe_control_gym_amd import parallel
+from safe_control_gym_amd.ppo import PPO, PPOConfig
+from safe_control_gym_amd.registration import load_task
+from safe_control_gym_amd.vec_env import HipVecEnv
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+assert parallel.collectives_capturable()
+env_id, cfg = load_task('quadrotor_2D_track')
+def run(extra):
+    env = HipVecEnv(env_id, 2048, seed=3, return_numpy=False, policy=(128, 'tanh'), **cfg)
+    torch.manual_seed(0)
+    ppo = PPO(env, PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, rollout_batch_size=2048, rollout_steps=16,
+                             mini_batch_size=4096, opt_epochs=2, target_kl=0.03, extra=extra), seed=0)
+    for _ in range(3):
+        res = ppo.train_step()
+    torch.cuda.synchronize()
+    p = ppo.agent._flat['p'].clone()
+    path = ppo.agent.dp_path
+    env.close()
+    return p, path, res
+p_ref, _, r_ref = run({'fused_step': False})
+p_dp, path, r_dp = run({'force_data_parallel': True})
+assert path and path.startswith('one graph replay per epoch'), path
+assert torch.equal(p_ref, p_dp), float((p_ref - p_dp).abs().max())
+assert r_ref['minibatches'] == r_dp['minibatches'] == 16 and abs(r_ref['approx_kl'] - r_dp['approx_kl']) < 1e-6
+probe = parallel.allreduce_probe()
+assert probe['world'] == 1 and probe['150528']['eager_us'] > 0 and probe['150528']['captured_us'] > 0, probe
+print('PROBE', probe)
+dist.destroy_process_group()
+print('DP_GRAPH_OK')
+'''
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'DP_GRAPH_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

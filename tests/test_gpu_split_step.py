@@ -1,7 +1,9 @@
-"""Split step launch (step_split_kernel, include/scg_hip.h: scg_set_split_max_envs): two waves per 64 envs, each producing half
-of the outputs of the control step, must give bit for bit what the one-wave-per-64-envs launch gives — every output of scg_step,
-the episode statistics, the simulator state and counters — across auto-resets, ragged tails and env-group counts that are not a
-multiple of eight (the split grid is padded to 16-workgroup packets), for every shipped task, float32 and float64."""
+"""Launch geometries of scg_step in the specialised libraries (include/scg_hip.h: scg_set_step_launch) — the split launch (two
+independent waves per 64 envs, each producing half of the outputs), the paired launch (one wave integrates, both evaluate behind
+one workgroup barrier; full 256-env workgroups + a plain launch for the rest of the shard) and the wide launch (256-thread
+workgroups) — must give bit for bit what the one-wave-per-64-envs launch gives: every output of scg_step, the episode statistics,
+the simulator state and counters, across auto-resets, ragged tails and group counts that are not a multiple of the launch's
+packet, for every shipped task, float32 and float64."""
 import numpy as np
 import pytest
 
@@ -15,10 +17,15 @@ CASES = [('quadrotor_2D_track', {}), ('cartpole_stab', {}), ('quadrotor_3D_track
              'M': {'distrib': 'uniform', 'low': -0.002, 'high': 0.002}, 'Iyy': {'distrib': 'uniform', 'low': -1e-6, 'high': 1e-6}}})]
 
 
+NEVER = 2 ** 31 - 1
+MODES = {'split': (NEVER, 0, NEVER), 'pair': (0, NEVER, NEVER), 'wide': (0, 0, 0)}
+
+
+@pytest.mark.parametrize('mode', list(MODES))
 @pytest.mark.parametrize('n', [64, 200, 1000, 1536])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64], ids=['f32', 'f64'])
 @pytest.mark.parametrize('task,over', CASES, ids=[c[0] + ('_' + '_'.join(c[1]) if c[1] else '') for c in CASES])
-def test_split_launch_equals_single_wave_launch(task, over, dtype, n):
+def test_launch_geometry_equals_single_wave_launch(task, over, dtype, n, mode):
     if n in (64, 1536) and (over or dtype == torch.float64):
         pytest.skip('geometry cases run on the plain float32 configs')
     from safe_control_gym_amd.registration import load_task
@@ -26,8 +33,8 @@ def test_split_launch_equals_single_wave_launch(task, over, dtype, n):
     env_id, cfg = load_task(task)
     cfg = dict(cfg, **over)
     a, b = [HipVecEnv(env_id, n, seed=4, dtype=dtype, return_numpy=False, specialize=True, **cfg) for _ in range(2)]
-    a.set_split_max_envs(1 << 30)                   # always split
-    b.set_split_max_envs(0)                         # never
+    a.set_step_launch(*MODES[mode])
+    b.set_step_launch(0, 0, NEVER)                  # one wave per 64 envs, one-wave workgroups
     g = torch.Generator(device='cpu').manual_seed(11)
     oa, ob = a.reset_tensors(), b.reset_tensors()
     assert torch.equal(oa, ob)
@@ -53,15 +60,14 @@ def test_split_launch_equals_single_wave_launch(task, over, dtype, n):
     a.close(); b.close()
 
 
-def test_split_threshold_is_a_per_env_setting_and_rejects_negative_values():
-    from safe_control_gym_amd import _lib as L
+def test_launch_thresholds_are_a_per_handle_setting():
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task('quadrotor_2D_track')
     env = HipVecEnv(env_id, 128, seed=0, return_numpy=False, specialize=False, **cfg)     # generic library: accepted, no effect
-    env.set_split_max_envs(4096)
+    env.set_step_launch(4096, 8192, 0)
+    env.set_step_launch(pair_max=0)                 # None = unchanged
     env.reset_tensors()
-    env.step_tensors(torch.zeros(128, 2, device=env.device))
-    with pytest.raises(L.ScgError):
-        env.set_split_max_envs(-1)
+    out = env.step_tensors(torch.zeros(128, 2, device=env.device))
+    assert bool(torch.isfinite(out.obs).all())
     env.close()

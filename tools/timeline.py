@@ -46,8 +46,12 @@ else:
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
         env = HipVecEnv(env_id, n, seed=1, return_numpy=False, **cfg)
         env.bind_outputs(state=None, noisy_action=None)
-        split = not (len(sys.argv) > 3 and sys.argv[3] == 'nosplit') and n <= 98304
-        env.set_split_max_envs((1 << 30) if split else 0)
+        mode = sys.argv[3] if len(sys.argv) > 3 else 'default'          # default (the library's thresholds) | plain | split | pair
+        NEVER = 2 ** 31 - 1
+        if mode != 'default':
+            env.set_step_launch(*{'plain': (0, 0, NEVER), 'split': (NEVER, 0, NEVER), 'pair': (0, NEVER, NEVER)}[mode])
+        split = mode == 'split' or (mode == 'default' and n <= 32768)
+        pair = mode == 'pair' or (mode == 'default' and 32768 < n <= 98304)
         env.reset_tensors()
         acts = [torch.rand(n, 2, device='cuda') * 2 - 1 for _ in range(16)]
         L = env._lib
@@ -60,14 +64,15 @@ else:
                 buf = np.zeros(4096 * 8, dtype=np.uint64)
                 assert L.scg_exp_timeline(buf.ctypes.data, buf.size) == 0
                 groups = max(1, n // 64)
-                n_waves = 2 * ((groups + 7) // 8 * 8) if split else groups       # split launch: workgroup b = role (b / 8) % 2
+                n_waves = 2 * ((groups + 7) // 8 * 8) if split else (2 * groups if pair else groups)   # split: workgroup b = role (b / 8) % 2
                 t = buf.reshape(4096, 8)[:min(n_waves, 4096)].astype(np.int64)
                 rows.append(t)
         t_all = np.stack(rows)                            # [iters][waves][marks]; XCD clocks are not mutually synchronised
         wave = np.arange(t_all.shape[1])
-        roles = [('every output (one wave per 64 envs)', np.ones_like(wave, dtype=bool))] if not split else \
-            [('ROLE_SCORE (reward / done / constraint rows / statistics)', ((wave >> 3) & 1) == 0),
-             ('ROLE_STATE (observation / auto-reset / state)', ((wave >> 3) & 1) == 1)]
+        role_state = (((wave >> 3) & 1) == 1) if split else (((wave >> 2) & 1) == 1)     # pair: waves 4-7 of each 8-wave workgroup
+        roles = [('every output (one wave per 64 envs)', np.ones_like(wave, dtype=bool))] if not (split or pair) else \
+            [('ROLE_SCORE (reward / done / constraint rows / statistics)' + (' + advance' if pair else ''), ~role_state),
+             ('ROLE_STATE (observation / auto-reset / state)', role_state)]
         for name, sel in roles:
             t = t_all[:, sel, :]
             d = np.diff(t, axis=2).reshape(-1, 7)             # per-wave phase durations
@@ -85,6 +90,6 @@ else:
         print(f'  first -> last wave entry within one XCD (dispatch spread): mean {np.mean(per_xcd):.0f} ticks, max {np.max(per_xcd):.0f}')
         endspan = [t_all[:, x::8, 7].max(axis=1) - t_all[:, x::8, 0].min(axis=1) for x in range(8)]
         print(f'  first entry -> last end within one XCD: mean {np.mean(endspan):.0f} ticks')
-        sys.stdout.flush(); os._exit(0)
+        sys.stdout.flush(); shutil.copy('/tmp/keep.so', real); os._exit(0)      # (os._exit skips the finally block)
     finally:
         shutil.copy('/tmp/keep.so', real)
