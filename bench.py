@@ -50,8 +50,7 @@ SEQ_K, SEQ_K_ALL = 32, 8        # control steps per launch of the two scg_step_s
 SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
 # scg_kernels.hip defaults (scg_set_step_launch): which launch geometry of the step kernel a shard of N envs takes
 LAUNCH_SPLIT_MAX = int(os.environ.get('SCG_SPLIT_MAX_ENVS', 32768))
-LAUNCH_PAIR_MAX = int(os.environ.get('SCG_PAIR_MAX_ENVS', 98304))
-LAUNCH_WIDE_MIN = int(os.environ.get('SCG_WIDE_MIN_ENVS', 2097152))
+LAUNCH_WIDE_MIN = int(os.environ.get('SCG_WIDE_MIN_ENVS', 8388608))
 
 
 def launch_geometry(n, specialised):
@@ -59,8 +58,6 @@ def launch_geometry(n, specialised):
         return 'step_kernel (generic library: 256-thread workgroups, parameters staged in LDS)'
     if n <= LAUNCH_SPLIT_MAX:
         return 'step_split_kernel (two independent waves per 64 envs, each half of the outputs)'
-    if n <= LAUNCH_PAIR_MAX and n >= 256:
-        return 'step_pair_kernel (paired waves: one integrates, both evaluate behind one workgroup barrier)'
     if n >= LAUNCH_WIDE_MIN:
         return 'step_wide_kernel (256-thread workgroups)'
     return 'step_kernel (one wave per 64 envs, one-wave workgroups)'
@@ -189,16 +186,46 @@ def traffic_of(task, dtype, n):
     return (e['traffic_bytes_per_launch'] if e else None), src
 
 
+# Issue intervals measured on MI355X with tools/issue_rate.hip (profiles/r05_issue_rate.txt, 2.396 GHz): ONE wave issues a vector
+# instruction every 4.8 clocks at best and a DEPENDENT one every 8.4; the SIMD issues every 2.4 clocks when it has two or more waves to
+# choose from (4.3 for packed-fp32 and integer-multiply instructions).  (The guide's "2 clocks per wave64 instruction" is the SIMD's
+# rate; round 4's "4 clocks" was one wave's.)
+WAVE_ISSUE_CLOCKS, SIMD_ISSUE_CLOCKS, DEPENDENT_ISSUE_CLOCKS, MEASURED_CLOCK_GHZ = 4.8, 2.4, 8.4, 2.396
+
+
 def valu_issue_of(task, dtype, n, period_us):
-    """Fraction of the launch period the busiest SIMD spends ISSUING vector instructions: executed VALU instructions per wave
-    (SQ_INSTS_VALU / SQ_WAVES of the same PMC passes) x waves per SIMD x 4 clocks (a wave64 instruction occupies the SIMD's 16
-    lanes for 4 cycles) / 2.4 GHz.  The bound that matters where the kernel sits on the f32 ridge (CartPole: 50 engine substeps)."""
+    """What the launch period owes to vector-instruction ISSUE: executed VALU instructions per wave (SQ_INSTS_VALU / SQ_WAVES of the PMC
+    passes) x the issue interval that applies — with one wave per SIMD the WAVE's own limit (4.8 clocks per instruction: a lower bound of
+    the wave's lifetime, dependencies come on top — see `chain_latency`), with W >= 2 waves per SIMD the larger of that and the SIMD's
+    W x 2.4 clocks per instruction."""
     e, _ = pmc_entry(f'{task}/{dtype}/{n}')
     if not e or not e.get('valu_instructions_per_wave'):
         return None
-    waves_per_simd = -(-(n // 64) // 1024)              # 256 CUs x 4 SIMDs
-    issue_us = e['valu_instructions_per_wave'] * waves_per_simd * 4 / (SHADER_CLOCK_GHZ * 1e3)
-    return {'valu_instructions_per_wave': e['valu_instructions_per_wave'], 'issue_us': issue_us, 'frac': issue_us / period_us}
+    waves_per_simd = max(1.0, (e.get('waves_per_launch') or n / 64) / 1024.0)        # 256 CUs x 4 SIMDs
+    per_instr = max(WAVE_ISSUE_CLOCKS, waves_per_simd * SIMD_ISSUE_CLOCKS)
+    issue_us = e['valu_instructions_per_wave'] * per_instr / (MEASURED_CLOCK_GHZ * 1e3)
+    return {'valu_instructions_per_wave': e['valu_instructions_per_wave'], 'waves_per_simd': waves_per_simd, 'clocks_per_instruction': per_instr,
+            'issue_us': issue_us, 'frac': issue_us / period_us, 'source': 'profiles/r05_issue_rate.txt (tools/issue_rate.hip)'}
+
+
+def chain_latency_of(task, period_us):
+    """Serial dependent-instruction chain of the engine-substep loop (tools/chain_latency.py: the built kernel's loop body through the
+    in-order model of tools/isa_sim.py with the measured issue / dependent-issue intervals): the bound of kernels whose control step is
+    tens of substeps of a dependent chain, where neither the HBM roofline nor the issue rate explains the launch."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r05_chain_latency.json')) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    from safe_control_gym_amd import _lib
+    if d.get('_meta', {}).get('source_hash') != f'0x{_lib.source_hash():016x}':
+        return {'dropped': 'profiles/r05_chain_latency.json was computed from other kernel sources'}
+    e = d.get(task)
+    if not e or 'chain_us_per_control_step' not in e:
+        return e
+    return {'substep_loop_us': e['chain_us_per_control_step'], 'frac_of_launch': e['chain_us_per_control_step'] / period_us,
+            'issue_limit_us': e['issue_limit_us_per_control_step'], 'dependent_instructions_per_substep': e['dependent_instructions_per_substep'],
+            'how': 'tools/chain_latency.py (static in-order model, measured intervals)'}
 
 
 class StepBench:
@@ -295,7 +322,7 @@ def secondary_env_kernels(torch, n):
             us = b.kernel_period_us(3000)
             r = roofline_of(task, 'f32', n, us)
             e = {'avg_launch_us': us, 'env_steps_per_s': n / (us * 1e-6), 'frac': r['frac'], 'algorithmic_bytes_per_env_step': r['algorithmic_bytes_per_env_step'],
-                 'traffic': r['traffic'], 'valu_issue': r['valu_issue'], 'kernel_build': 'config-specialised' if b.env.specialized else 'generic', 'finite_outputs': b.sane()}
+                 'traffic': r['traffic'], 'valu_issue': r['valu_issue'], 'chain_latency': chain_latency_of(task, us), 'kernel_build': 'config-specialised' if b.env.specialized else 'generic', 'finite_outputs': b.sane()}
             if task == 'cartpole_stab':         # BASELINE config #2: in-kernel random actions, K steps per launch
                 K = 1000
                 b.env.rollout_random(K)

@@ -316,14 +316,11 @@ int scg_get_params(scg_env* env, double* h_params, int first_env, int n, void* s
 /* Tuning knobs (no reference counterpart; results are identical bit for bit whichever launch runs).  Config-specialised libraries pick
  * the geometry of scg_step's launch by the size of the shard:
  *   <= split_max_envs   two independent waves per 64 envs, each the whole control step for half of the outputs (shards that leave
- *                       SIMDs empty; default 32 768 or env SCG_SPLIT_MAX_ENVS);
- *   <= pair_max_envs    paired waves in one workgroup: one loads and integrates, both evaluate (reward / constraint rows / statistics
- *                       vs observation / auto-reset / state) behind one barrier (around one wave per SIMD; default 98 304 or env
- *                       SCG_PAIR_MAX_ENVS);
- *   >= wide_min_envs    256-thread workgroups (shards that stream from HBM; default 2 097 152 or env SCG_WIDE_MIN_ENVS);
+ *                       SIMDs empty: up to half a wave per SIMD; default 32 768 or env SCG_SPLIT_MAX_ENVS);
+ *   >= wide_min_envs    256-thread workgroups (the largest shards; default 8 388 608 or env SCG_WIDE_MIN_ENVS);
  *   otherwise, and the generic library always: one wave per 64 envs in one-wave workgroups.
- * A negative argument leaves that threshold unchanged; 0 switches the split / paired launch off, INT_MAX the wide one. */
-int scg_set_step_launch(scg_env* env, int split_max_envs, int pair_max_envs, int wide_min_envs);
+ * A negative argument leaves that threshold unchanged; 0 switches the split launch off, INT_MAX the wide one. */
+int scg_set_step_launch(scg_env* env, int split_max_envs, int wide_min_envs);
 /* BenchmarkEnv.seed (benchmark_env.py:193-214): new Philox key for subsequent draws. */
 int scg_set_seed(scg_env* env, uint64_t seed);
 /* ctrl_step_counter / episode index per env (benchmark_env.py:329-330). */

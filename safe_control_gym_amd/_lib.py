@@ -214,7 +214,7 @@ def _bind(path):
     L.scg_spec_hash.restype = c_u64
     L.scg_source_hash.restype = c_u64
     L.scg_set_seed.argtypes = [c_vp, c_u64]
-    L.scg_set_step_launch.argtypes = [c_vp, C.c_int, C.c_int, C.c_int]
+    L.scg_set_step_launch.argtypes = [c_vp, C.c_int, C.c_int]
     return L
 
 

@@ -663,14 +663,6 @@ struct EnvOps {
         e.gid = (uint32_t)(P.i.env_id_offset + i);
         e.pre_n = 0;
     }
-    // counters only (the consumer wave of a paired step launch: its raw state arrives through LDS)
-    __device__ static __forceinline__ void load_counters(const PV<T>& P, int i, E& e) {
-        const __amdgpu_buffer_rsrc_t ws = make_rsrc(P.i.ws);
-        e.step = slot_in<int32_t>(ws, P.i.step_off, i).load();
-        e.episode = slot_in<uint32_t>(ws, P.i.episode_off, i).load();
-        e.gid = (uint32_t)(P.i.env_id_offset + i);
-        e.pre_n = 0;
-    }
     __device__ static __forceinline__ void load_params(const PV<T>& P, int i, E& e) {
         const size_t N = (size_t)P.i.num_envs;
         if (P.c.per_env_params) {
@@ -1110,8 +1102,7 @@ SCG_BOX_UNROLL
     // One control step, no auto-reset.  `act_in` = raw controller action; `adv` = adversary action or null.
     // Leaves the post-step state in `e` (counter incremented) and the post-step env.state in `st`.
     // = advance() (action pre-processing, disturbances, the engine substeps: the raw state in `e` moves) followed by evaluate()
-    // (env.state, reward, done, mse, constraint rows, time limit: pure functions of the advanced state and the noisy action).  The
-    // paired step launch (step_pair_kernel) runs the two halves in different waves.
+    // (env.state, reward, done, mse, constraint rows, time limit: pure functions of the advanced state and the noisy action).
     template <int SLOT_AUX>
     __device__ static __forceinline__ StepResult step(const PV<T>& P, const GoalTab<T>& goal_tab, E& e,
                                                       const T* act_in, const T* adv, RngKey key, int env_index,

@@ -254,28 +254,18 @@ __device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* 
 // memory side).  Neither role reads anything the other writes in the same launch.
 enum : int { ROLE_ALL = 0, ROLE_SCORE = 1, ROLE_STATE = 2 };
 
-// Paired launch (step_pair_kernel, PAIR = true): the ROLE_SCORE and ROLE_STATE waves of an env group sit in ONE workgroup.  Only the
-// ROLE_SCORE wave loads the state and runs EnvOps::advance (the pre-processing and the engine substeps — the packed-fp32 half of the
-// step, which two waves on one SIMD would only slow down: a v_pk_* instruction occupies the SIMD 4.3 clocks, profiles/r05_issue_rate.txt);
-// it publishes the advanced raw state and the noisy action in LDS (`xch`, [component][BLK]) and both waves meet at ONE workgroup
-// barrier.  Until then the ROLE_STATE wave has requested its own inputs (counters, goal rows) and waits without issuing; behind the
-// barrier the two waves run EnvOps::evaluate side by side, each for its own outputs — scalar vector instructions, which a SIMD issues
-// for two waves at twice the rate of one (2.4 vs 4.8 clocks per instruction, same file).
-template <int SYS, typename T, bool DIST, bool ONE, int ROLE, int BLK = BLOCK, bool PAIR = false>
+// BLK: threads per workgroup of the kernel that inlines this body (BLOCK, or WIDE_BLOCK for step_wide_kernel).
+template <int SYS, typename T, bool DIST, bool ONE, int ROLE, int BLK = BLOCK>
 __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, const InstParams<T>& I,
                                           const T* __restrict__ action, const T* __restrict__ adv,
-                                          const typename OutTabOf<ONE>::type& O, const int wg, const int tid = (int)threadIdx.x,
-                                          T* __restrict__ xch = nullptr) {
+                                          const typename OutTabOf<ONE>::type& O, const int wg) {
     using Ops = EnvOps<SYS, T, DIST>;
     using D = Dims<SYS>;
     constexpr bool SCORE = ROLE != ROLE_STATE, STATE = ROLE != ROLE_SCORE;
-    constexpr bool PRODUCER = PAIR && ROLE == ROLE_SCORE, CONSUMER = PAIR && ROLE == ROLE_STATE;
-    static_assert(!PAIR || ROLE != ROLE_ALL, "paired waves have a role");
+    const int tid = (int)threadIdx.x;
     const int i = I.env_first + wg * BLK + tid;
     const int N = I.num_envs;
-    // (paired launch: the host launches full workgroups only — every lane is live and every wave reaches the barrier; the ragged
-    //  remainder of a shard goes through the plain kernel, launch_step in scg_kernels.hip)
-    const bool live = PAIR ? true : (i < I.env_end);
+    const bool live = i < I.env_end;
     // ---- memory round 1: kernargs — every pointer is fetched in this block, one scalar-memory round
     SCG_TL(0);
     fence_kernargs<T>(I, action, adv, O);
@@ -292,7 +282,6 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
     const PV<T>& Pg = P;
     const int nobs_early = kcfg.nobs;
 #else
-    static_assert(!PAIR, "the paired launch is a specialised-build kernel");
     extern __shared__ __align__(16) unsigned char smem[];
     const StageRegs SR = stage_issue<T, DIST>(Cg, I);
     const PV<T> Pg{*Cg, I};
@@ -307,10 +296,9 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
 #endif
     // ---- memory round 2: everything this thread needs from HBM, requested before the single wait
     if (live) {
-        if constexpr (CONSUMER) Ops::load_counters(Pg, i, e);       // (the advanced raw state comes from the partner wave, through LDS)
-        else Ops::load_state(Pg, i, e);
+        Ops::load_state(Pg, i, e);
 #pragma unroll
-        for (int j = 0; j < D::NU; ++j) act[j] = CONSUMER ? (T)0 : action[(size_t)i * D::NU + j];     // caller's tensor: plain global load
+        for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];     // caller's tensor: plain global load
         // unconditional load (an unbound accumulator reads a valid dummy address): a branch would split the
         // requests over two dependent rounds
         if constexpr (SCORE) (Q.ep_stats ? Q.ep_stats : slot_in<T>(make_rsrc(I.ws), I.state_off, 0, 4)).template load_row<4>(ep);
@@ -359,7 +347,7 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
     }
     T advv[D::DYN > D::NU ? D::DYN : D::NU];
     const T* advp = nullptr;
-    if constexpr (DIST && !CONSUMER) {
+    if constexpr (DIST) {
         if (adv && P.c.adversary_channel >= 0) {
             const int ad = P.c.adversary_channel == SCG_CH_ACTION ? D::NU : D::DYN;
             for (int j = 0; j < ad; ++j) advv[j] = adv[(size_t)i * ad + j];
@@ -368,47 +356,9 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
     }
     T st[D::NX], noisy[D::NU];
     if constexpr (!SCORE) Q.c_values.soff = SCG_NO_OFF;                 // (the rows are evaluated for `done`, stored by ROLE_SCORE)
-    // Paired launch, ROLE_STATE wave: the fresh episode of an auto-reset (its Philox block, initial state, observation row) depends on
-    // nothing the control step computes — only on (env, episode + 1) — so it is prepared for EVERY lane while the partner wave
-    // integrates, and the reset path behind the barrier is a select.  (Not with disturbances: their reset draws are stored.)
-#ifndef SCG_PAIR_SPECULATE
-#define SCG_PAIR_SPECULATE 0
-#endif
-    constexpr bool SPECULATE = CONSUMER && !DIST && (SCG_PAIR_SPECULATE != 0);
-    typename Ops::E e_new;
-    T st_new[D::NX], row_new[2 * D::NX];
-    int nrow_new = 0;
-    bool spec_ready = false;
-    if constexpr (SPECULATE) {
-        if (P.c.auto_reset && Ops::obs_is_row(P)) {
-            e_new = e;
-            Ops::reset(P, i, e_new, key, st_new);
-            nrow_new = Ops::obs_row(P, goal, st_new, e_new, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row_new);
-            spec_ready = true;
-        }
-    }
-    typename Ops::StepResult r;
-    if constexpr (!PAIR) {
-        r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, Q.c_values, (size_t)N,
-                      pre_ref ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr, pre_ext ? ext_reset : nullptr);
-    } else {
-        if constexpr (PRODUCER) {
-            Ops::advance(P, e, act, advp, key, i, noisy);
-#pragma unroll
-            for (int k = 0; k < D::NS; ++k) xch[k * BLK + tid] = e.s[k];
-#pragma unroll
-            for (int j = 0; j < D::NU; ++j) xch[(D::NS + j) * BLK + tid] = noisy[j];
-        }
-        __syncthreads();                                                // the ONE rendezvous of the two waves of an env group
-        if constexpr (CONSUMER) {
-#pragma unroll
-            for (int k = 0; k < D::NS; ++k) e.s[k] = xch[k * BLK + tid];
-#pragma unroll
-            for (int j = 0; j < D::NU; ++j) noisy[j] = xch[(D::NS + j) * BLK + tid];
-        }
-        r = Ops::evaluate(P, goal, e, noisy, i, st, Q.c_values, (size_t)N,
-                          pre_ref ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr, pre_ext ? ext_reset : nullptr);
-    }
+    typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, Q.c_values, (size_t)N,
+                                           pre_ref ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr,
+                                           pre_ext ? ext_reset : nullptr);
     if constexpr (SCORE) {
     Q.reward.store(r.reward);           // obs / reward / done / flags are always bound (checked by scg_step)
     Q.done.store(r.done ? 1 : 0);
@@ -445,17 +395,8 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         if (r.done && Q.terminal_obs) Ops::store_obs_row(P, row, nrow, Q.terminal_obs);   // (also the non-auto-reset case)
         SCG_TL(6);
         if (do_reset) {
-            if (SPECULATE && spec_ready) {          // prepared before the barrier (see above)
-                e = e_new;
-#pragma unroll
-                for (int k = 0; k < D::NX; ++k) st[k] = st_new[k];
-#pragma unroll
-                for (int k = 0; k < 2 * D::NX; ++k) row[k] = row_new[k];
-                nrow = nrow_new;
-            } else {
-                Ops::reset(P, i, e, key, st);           // auto-reset (dummy_vec_env.py:33-38)
-                nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row);
-            }
+            Ops::reset(P, i, e, key, st);           // auto-reset (dummy_vec_env.py:33-38)
+            nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row);
         }
 #ifdef SCG_SPEC
         constexpr int kNobs = kcfg.nobs;
@@ -497,33 +438,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restr
 }
 
 #ifdef SCG_SPEC
-// Wide workgroups for shards that stream from HBM (>= SCG_WIDE_MIN_ENVS envs): the four waves of a 256-thread workgroup write 1 KB
-// contiguous per output array and 16 x fewer workgroups are dispatched — 254.8 -> 196.5 us per launch at 4 194 304 envs, while the
-// 64-thread workgroups stay ahead below ~2 M envs (profiles/r05_step_kernel_ab.md).
+// Wide workgroups for the largest shards (>= SCG_WIDE_MIN_ENVS envs): the four waves of a 256-thread workgroup write 1 KB contiguous
+// per output array and 4 x fewer workgroups are dispatched — 1018.5 -> 953.7 us per launch at 16 777 216 envs (-6.4 %; 512 / 1024
+// threads the same), nothing reproducible at <= 4 M envs (+-3 % run to run), where the one-wave workgroups stay
+// (profiles/r05_step_kernel_ab.md).
 constexpr int WIDE_BLOCK = 256;
 template <int SYS, typename T, bool DIST, bool ONE>
 __global__ __launch_bounds__(WIDE_BLOCK) void step_wide_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                                const T* __restrict__ action, const T* __restrict__ adv,
                                                                const typename OutTabOf<ONE>::type O) {
     step_body<SYS, T, DIST, ONE, ROLE_ALL, WIDE_BLOCK>(Cg, I, action, adv, O, (int)blockIdx.x);
-}
-
-// Paired launch: workgroups of 2 x SCG_PAIR_ENVS threads; threads [0, PAIR_ENVS) are the ROLE_SCORE waves (load, advance, publish,
-// scores), threads [PAIR_ENVS, 2 PAIR_ENVS) the ROLE_STATE waves of the same envs.  With PAIR_ENVS = 256 a workgroup is 8 waves: the
-// hardware places waves w and w + 4 of a workgroup on the same SIMD (cyclic SIMD order), so every SIMD hosts one wave of each role.
-#ifndef SCG_PAIR_ENVS
-#define SCG_PAIR_ENVS 256
-#endif
-constexpr int PAIR_ENVS = SCG_PAIR_ENVS;
-template <int SYS, typename T, bool DIST, bool ONE>
-__global__ __launch_bounds__(2 * PAIR_ENVS) void step_pair_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                                   const T* __restrict__ action, const T* __restrict__ adv,
-                                                                   const typename OutTabOf<ONE>::type O) {
-    using D = Dims<SYS>;
-    __shared__ T xch[(D::NS + D::NU) * PAIR_ENVS];
-    const int t = (int)threadIdx.x;
-    if (t < PAIR_ENVS) step_body<SYS, T, DIST, ONE, ROLE_SCORE, PAIR_ENVS, true>(Cg, I, action, adv, O, (int)blockIdx.x, t, xch);
-    else step_body<SYS, T, DIST, ONE, ROLE_STATE, PAIR_ENVS, true>(Cg, I, action, adv, O, (int)blockIdx.x, t - PAIR_ENVS, xch);
 }
 
 // Split launch: 2 x (env groups rounded up to a multiple of 8) workgroups.  Workgroup b serves env group 8 (b / 16) + b % 8 in

@@ -73,8 +73,8 @@ struct scg_env {
     bool has_reset;
     bool has_dist;
     // step-launch geometry of the specialised builds by shard size (scg_set_step_launch): <= split_max: two waves per 64 envs, each
-    // the whole step for half of the outputs; <= pair_max: paired waves (one advances, both evaluate); >= wide_min: 256-thread workgroups
-    int split_max, pair_max, wide_min;
+    // the whole step for half of the outputs; >= wide_min: 256-thread workgroups
+    int split_max, wide_min;
 };
 
 // Step-launch geometry by shard size, measured on MI355X (profiles/r05_step_kernel_ab.md); the environment variables of the same names
@@ -82,11 +82,8 @@ struct scg_env {
 #ifndef SCG_SPLIT_MAX_ENVS
 #define SCG_SPLIT_MAX_ENVS 32768          // <= half a wave per SIMD: two independent waves per 64 envs (step_split_kernel)
 #endif
-#ifndef SCG_PAIR_MAX_ENVS
-#define SCG_PAIR_MAX_ENVS 98304           // around one wave per SIMD: paired waves (step_pair_kernel)
-#endif
 #ifndef SCG_WIDE_MIN_ENVS
-#define SCG_WIDE_MIN_ENVS 2097152         // streaming from HBM: 256-thread workgroups (step_wide_kernel)
+#define SCG_WIDE_MIN_ENVS 8388608         // the largest shards: 256-thread workgroups (step_wide_kernel)
 #endif
 static int launch_default(const char* name, int built_in) {
     const char* s = std::getenv(name);
@@ -571,7 +568,6 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
     e->split_max = launch_default("SCG_SPLIT_MAX_ENVS", SCG_SPLIT_MAX_ENVS);
-    e->pair_max = launch_default("SCG_PAIR_MAX_ENVS", SCG_PAIR_MAX_ENVS);
     e->wide_min = launch_default("SCG_WIDE_MIN_ENVS", SCG_WIDE_MIN_ENVS);
     e->has_dist = cfg->n_dist[0] > 0 || cfg->n_dist[1] > 0 || cfg->n_dist[2] > 0 || cfg->adversary_channel >= 0;
     hipError_t err = hipMemset(d_workspace, 0, L.total);
@@ -683,30 +679,6 @@ static int launch_step(scg_env* env, int first, int count, const void* action, c
             DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, true><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
         } else {
             DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, false><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
-        }
-        HIP_TRY(hipGetLastError());
-        return SCG_OK;
-    }
-    // Paired launch (step_pair_kernel): full workgroups of PAIR_ENVS envs; what is left of the shard (< PAIR_ENVS envs) goes through the
-    // plain kernel below as a second, small launch.
-    if (count <= env->pair_max && count >= PAIR_ENVS) {
-        const int groups = count / PAIR_ENVS;
-        InstParams<T> Ip = I;
-        Ip.env_end = first + groups * PAIR_ENVS;
-        if (one_base) {
-            DISPATCH_SYS(env, T, (step_pair_kernel<S, T, DD, true><<<dim3(groups), dim3(2 * PAIR_ENVS), 0, st>>>(C, Ip, (const T*)action, (const T*)adv, O1)));
-        } else {
-            DISPATCH_SYS(env, T, (step_pair_kernel<S, T, DD, false><<<dim3(groups), dim3(2 * PAIR_ENVS), 0, st>>>(C, Ip, (const T*)action, (const T*)adv, O)));
-        }
-        HIP_TRY(hipGetLastError());
-        const int rest = count - groups * PAIR_ENVS;
-        if (rest == 0) return SCG_OK;
-        I.env_first = first + groups * PAIR_ENVS;
-        const int grid_r = (rest + BLOCK - 1) / BLOCK;
-        if (one_base) {
-            DISPATCH_SYS(env, T, (step_kernel<S, T, DD, true><<<dim3(grid_r), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
-        } else {
-            DISPATCH_SYS(env, T, (step_kernel<S, T, DD, false><<<dim3(grid_r), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
         }
         HIP_TRY(hipGetLastError());
         return SCG_OK;
@@ -920,10 +892,9 @@ extern "C" int scg_get_params(scg_env* env, double* h_params, int first_env, int
     return env->dtype == SCG_F64 ? copy_soa<double>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream)
                                  : copy_soa<float>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream);
 }
-extern "C" int scg_set_step_launch(scg_env* env, int split_max_envs, int pair_max_envs, int wide_min_envs) {
+extern "C" int scg_set_step_launch(scg_env* env, int split_max_envs, int wide_min_envs) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
     if (split_max_envs >= 0) env->split_max = split_max_envs;
-    if (pair_max_envs >= 0) env->pair_max = pair_max_envs;
     if (wide_min_envs >= 0) env->wide_min = wide_min_envs;
     return SCG_OK;
 }

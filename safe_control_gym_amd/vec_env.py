@@ -497,13 +497,13 @@ class HipVecEnv(VecEnv):
                                                ep.ctypes.data_as(C.POINTER(C.c_uint32)), 0, self.num_envs, self._stream()))
         return step, ep
 
-    def set_step_launch(self, split_max=None, pair_max=None, wide_min=None):
+    def set_step_launch(self, split_max=None, wide_min=None):
         """Tuning knobs of the specialised libraries (scg_set_step_launch): which launch geometry scg_step uses by shard size —
-        `split_max`: two independent waves per 64 envs up to this many envs; `pair_max`: paired waves (one integrates, both
-        evaluate) up to this many; `wide_min`: 256-thread workgroups from this many.  None keeps a threshold; (0, 0, 2**31 - 1) = the
-        plain one-wave-per-64-envs launch always.  Results are identical either way."""
+        `split_max`: two independent waves per 64 envs (each produces half of the outputs) up to this many envs; `wide_min`:
+        256-thread workgroups from this many.  None keeps a threshold; (0, 2**31 - 1) = the plain one-wave-per-64-envs launch always.
+        Results are identical either way."""
         f = lambda v: -1 if v is None else int(v)       # noqa: E731
-        self._chk(self._lib.scg_set_step_launch(self._h, f(split_max), f(pair_max), f(wide_min)))
+        self._chk(self._lib.scg_set_step_launch(self._h, f(split_max), f(wide_min)))
 
     def set_counters(self, step=None, episode=None):
         sp = None if step is None else np.ascontiguousarray(step, dtype=np.int32)

@@ -218,6 +218,8 @@ def test_bench_quotes_pmc_numbers_only_for_the_kernel_sources_they_were_measured
         if expect is None:
             assert 'dropped' in r['traffic_source'] and r['valu_issue'] is None
         else:
-            assert r['valu_issue']['frac'] == pytest.approx(900.0 * 4 / 2.4e3 / 4.2)
+            # one wave per SIMD: the wave's own issue limit, 4.8 clocks per instruction at 2.396 GHz (profiles/r05_issue_rate.txt)
+            assert r['valu_issue']['frac'] == pytest.approx(900.0 * 4.8 / 2.396e3 / 4.2)
+            assert r['frac_by_clock']['in_graph_hip_events']['frac'] == pytest.approx(r['frac'])
         assert r['frac'] == pytest.approx(187 * 65536 / 4.2e-6 / 8e12)
     bench._PMC_CACHE.clear()

@@ -5,10 +5,10 @@
   initial states through auto-resets: every per-step output == OracleVecEnv on the same seed and actions at 1e-9 (integers /
   booleans exactly), on the generic and the specialised library;
 * scg_rollout_policy (the shipped Quadrotor2D policy in the loop, float32 — the kernel has no float64 build), 250 control steps:
-  the oracle is driven with the ACTIONS THE KERNEL RECORDED, so what is compared is the simulator inside the rollout kernel
-  against the float64 oracle over whole closed-loop episodes: per state dimension max|delta| / max|x| <= 1e-4 (north_star's
-  bar) for the episodes both sides hold to the same length, and the recorded action must be the actor's mean on the
-  recorded observation."""
+  the oracle is driven with the ACTIONS THE KERNEL RECORDED from the STATES THE KERNEL RECORDED (re-synchronised every step, like
+  the float32 one-step tests of scg_step): every control step, terminal observation and in-launch auto-reset of the simulator
+  inside the rollout kernel against the float64 oracle at the one-step float32 tolerance (2e-5), and the recorded action must
+  be the actor's mean on the recorded observation.  (The closed-loop 1000-step bar of north_star is tests/test_gpu_parity_scale.py's.)"""
 import os
 
 import numpy as np
@@ -83,7 +83,6 @@ def test_rollout_policy_simulator_vs_oracle_on_the_recorded_actions():
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task('quadrotor_2D_track')
-    cfg = dict(cfg, done_on_out_of_bound=True)
     n, K, seed = 256, 250, 13
     pol = np.load(os.path.join(GOLDEN, 'policies.npz'))
     hidden = int(pol['quadrotor_2D_track/actor.pi_net.fcs.0.weight'].shape[0])
@@ -108,26 +107,34 @@ def test_rollout_policy_simulator_vs_oracle_on_the_recorded_actions():
     ovec = OracleVecEnv(oracle)
     ovec.reset()                                            # (PPO's constructor had reset `env` once already: same episode indices)
     obs_o, _ = ovec.reset()
-    O, A, D = _np(obs), _np(actb), _np(done).astype(bool)
-    np.testing.assert_allclose(O[0], obs_o, rtol=2e-6, atol=2e-6)
-    alive = np.ones(n, dtype=bool)                          # envs whose episode boundaries have agreed so far
-    scale, worst = np.zeros(nobs), np.zeros(nobs)
-    n_cmp = 0
+    O, A, D, T = _np(obs), _np(actb), _np(done).astype(bool), _np(term)
+    np.testing.assert_allclose(O[0], obs_o, rtol=2e-6, atol=2e-6)          # the fresh episodes' Philox draws
+    idx = np.arange(n)
+    worst, scale, worst_r, n_done = np.zeros(nobs), np.ones(nobs), 0.0, 0
+    alive = np.ones(n, dtype=bool)
     for t in range(K):
+        # re-synchronise: the oracle continues from the state the KERNEL recorded for step t (observation = state | goal row), so
+        # that what is compared is one control step of the simulator inside the rollout kernel, not an open-loop replay of an
+        # unstable plant (whose float32 rounding differences grow exponentially without the feedback)
+        x = O[t][:, :6]
+        zero = np.zeros(n)
+        quat = np.stack([zero, np.sin(0.5 * x[:, 4]), zero, np.cos(0.5 * x[:, 4])], axis=1)
+        oracle.set_body_state(idx, np.stack([x[:, 0], zero, x[:, 2]], axis=1), quat, np.stack([x[:, 1], zero, x[:, 3]], axis=1),
+                              np.stack([zero, x[:, 5], zero], axis=1))
         obs_o, rew_o, done_o, info = ovec.step(A[t])
-        alive &= (D[t] == done_o)                           # a boundary crossed on one side only desynchronises that env for good
-        keep = alive
-        n_cmp += int(keep.sum())
-        scale = np.maximum(scale, np.abs(obs_o[keep]).max(axis=0))
+        alive &= (D[t] == done_o)           # an episode boundary crossed on one side only (a bound within float32 rounding): that env's
+        keep = alive & ~done_o              # counters differ from here on — dropped from the comparison for the rest of the rollout
         worst = np.maximum(worst, np.abs(O[t + 1][keep] - obs_o[keep]).max(axis=0))
-        d = keep & done_o
+        scale = np.maximum(scale, np.abs(obs_o[keep]).max(axis=0))
+        worst_r = max(worst_r, float(np.abs(_np(rew[t])[alive] - rew_o[alive]).max()))
+        d = alive & done_o
+        n_done += int(d.sum())
         if d.any():
-            np.testing.assert_allclose(_np(term[t])[d], info['terminal_observation'][d], rtol=0, atol=1e-4 * np.maximum(scale, 1.0).max())
-        np.testing.assert_allclose(_np(rew[t])[keep], rew_o[keep], rtol=2e-4, atol=2e-5)
-    assert alive.mean() >= 0.95, alive.mean()
-    rel = worst / np.maximum(scale, 1e-12)
-    assert (rel <= 1e-4).all(), rel
-    assert D.sum() > 0                                       # episodes ended (time limit: 250 steps) and were reset inside the launch
+            np.testing.assert_allclose(T[t][d], info['terminal_observation'][d], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(O[t + 1][d], obs_o[d], rtol=2e-6, atol=2e-6)      # the auto-reset inside the launch: same Philox draws
+    assert alive.mean() >= 0.98, alive.mean()
+    assert (worst[:6] <= 2e-5 * scale[:6]).all() and worst_r <= 3e-5, (worst, scale, worst_r)      # (the one-step tolerances of test_gpu_env_parity.py)
+    assert n_done > 0                                        # episodes ended (time limit: 250 steps) and were reset inside the launch
     env.close()
 
 

@@ -1,9 +1,8 @@
 """Launch geometries of scg_step in the specialised libraries (include/scg_hip.h: scg_set_step_launch) — the split launch (two
-independent waves per 64 envs, each producing half of the outputs), the paired launch (one wave integrates, both evaluate behind
-one workgroup barrier; full 256-env workgroups + a plain launch for the rest of the shard) and the wide launch (256-thread
-workgroups) — must give bit for bit what the one-wave-per-64-envs launch gives: every output of scg_step, the episode statistics,
-the simulator state and counters, across auto-resets, ragged tails and group counts that are not a multiple of the launch's
-packet, for every shipped task, float32 and float64."""
+independent waves per 64 envs, each producing half of the outputs) and the wide launch (256-thread workgroups) — must give bit
+for bit what the one-wave-per-64-envs launch gives: every output of scg_step, the episode statistics, the simulator state and
+counters, across auto-resets, ragged tails and group counts that are not a multiple of the launch's packet, for every shipped
+task, float32 and float64."""
 import numpy as np
 import pytest
 
@@ -18,7 +17,7 @@ CASES = [('quadrotor_2D_track', {}), ('cartpole_stab', {}), ('quadrotor_3D_track
 
 
 NEVER = 2 ** 31 - 1
-MODES = {'split': (NEVER, 0, NEVER), 'pair': (0, NEVER, NEVER), 'wide': (0, 0, 0)}
+MODES = {'split': (NEVER, NEVER), 'wide': (0, 0)}
 
 
 @pytest.mark.parametrize('mode', list(MODES))
@@ -34,7 +33,7 @@ def test_launch_geometry_equals_single_wave_launch(task, over, dtype, n, mode):
     cfg = dict(cfg, **over)
     a, b = [HipVecEnv(env_id, n, seed=4, dtype=dtype, return_numpy=False, specialize=True, **cfg) for _ in range(2)]
     a.set_step_launch(*MODES[mode])
-    b.set_step_launch(0, 0, NEVER)                  # one wave per 64 envs, one-wave workgroups
+    b.set_step_launch(0, NEVER)                     # one wave per 64 envs, one-wave workgroups
     g = torch.Generator(device='cpu').manual_seed(11)
     oa, ob = a.reset_tensors(), b.reset_tensors()
     assert torch.equal(oa, ob)
@@ -65,8 +64,8 @@ def test_launch_thresholds_are_a_per_handle_setting():
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task('quadrotor_2D_track')
     env = HipVecEnv(env_id, 128, seed=0, return_numpy=False, specialize=False, **cfg)     # generic library: accepted, no effect
-    env.set_step_launch(4096, 8192, 0)
-    env.set_step_launch(pair_max=0)                 # None = unchanged
+    env.set_step_launch(4096, 0)
+    env.set_step_launch(wide_min=1 << 20)           # None = unchanged
     env.reset_tensors()
     out = env.step_tensors(torch.zeros(128, 2, device=env.device))
     assert bool(torch.isfinite(out.obs).all())
