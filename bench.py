@@ -639,24 +639,33 @@ def multi_gpu_readiness(torch, dist, world):
                    'host_enqueues_per_vector_step_over_rccl': 1, 'host_path': 'one HIP-graph replay per vector step (16 gradient steps, 32 all-reduces)'},
            'env_shards': 'independent (global env ids [rank N, (rank + 1) N)): no data-path collective, weak scaling',
            'measured_with_more_than_one_gpu': False}
-    made = False
+    # The probe runs in a CHILD process (a one-rank "nccl" group of its own): nothing it does — a failed capture, an abort inside the
+    # communicator — can cost this process its JSON line.
+    import subprocess
+    code = ("import os, sys, json, socket, torch, torch.distributed as dist\n"
+            "sys.path.insert(0, os.getcwd())\n"
+            "from safe_control_gym_amd import parallel\n"
+            "s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+            "torch.cuda.set_device(0)\n"
+            "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+            "r = parallel.allreduce_probe((4 * 36742, 4 * 61451))\n"
+            "print('PROBE_JSON ' + json.dumps(r)); sys.stdout.flush()\n"
+            "dist.destroy_process_group()\n")
     try:
-        if world == 1 and not dist.is_initialized():
-            import socket
-            s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ['MASTER_PORT'] = str(port)
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
-            made = True
-        res['allreduce_us'] = parallel.allreduce_probe((4 * 36742, 4 * 61451))
-        res['allreduce_us']['note'] = f'{dist.get_world_size()} rank(s), in-place fp32 SUM, microseconds per collective'
+        if world != 1:
+            raise RuntimeError('measured on the one-GPU run only')
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith('PROBE_JSON ')]
+        if not line:
+            raise RuntimeError('probe printed nothing: ' + (p.stderr or '')[-300:])
+        res['allreduce_us'] = json.loads(line[-1][len('PROBE_JSON '):])
+        res['allreduce_us']['note'] = 'one rank (enqueue + kernel, no wire), in-place fp32 SUM, microseconds per collective; child process'
     except Exception as exc:                                            # noqa: BLE001
-        res['allreduce_us'] = {'error': repr(exc)[:200]}
-    finally:
-        if made:
-            try:
-                dist.destroy_process_group()
-            except Exception:                                           # noqa: BLE001
-                pass
+        res['allreduce_us'] = {'error': repr(exc)[:300]}
     return res
 
 
@@ -954,7 +963,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.task, hb.cfg, hb.env_id, args.cpu_seconds, N)
             out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
-        print(json.dumps(out))
+        print(json.dumps(out, default=str))
     if world > 1:
         dist.destroy_process_group()
 

@@ -38,5 +38,15 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ppo_ite
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sac_iteration -o p -- \
     python tools/sac_time_to_reward.py --budget 12 --eval-every 100000 > $OUT/sac_iteration.log 2>&1 < /dev/null
 fi
+# counter CSVs carry one row per dispatch of EVERY kernel (torch's included): keep the rows of this package's kernels only (gpurun merges <= 64 MiB back)
+python - <<'PY'
+import csv, glob, os
+for f in glob.glob(os.path.join('gpurun_out', 'prof', '**', '*counter_collection.csv'), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    keep = [r for r in rows if 'scg::' in r.get('Kernel_Name', '') or 'step_' in r.get('Kernel_Name', '')]
+    if rows:
+        with open(f, 'w', newline='') as g:
+            w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
+PY
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete; find $OUT -name '*.db' -delete; find $OUT -name '*.log' -size +200k -delete
 du -sh $OUT; ls $OUT | head -80
