@@ -36,7 +36,11 @@ def is_kernel(kname, name):
 
 
 def second_half_mean(rows, counter, kname):
-    v = [float(r['Counter_Value']) for r in rows if is_kernel(kname, r['Kernel_Name']) and r['Counter_Name'] == counter]
+    sel = [r for r in rows if is_kernel(kname, r['Kernel_Name']) and r['Counter_Name'] == counter]
+    if sel and 'Dispatches_Averaged' in sel[0]:             # condensed on the box by tools/profile_round5.sh: already the second-half mean
+        r = max(sel, key=lambda q: int(q['Dispatches_Total']))
+        return float(r['Counter_Value']), int(r['Dispatches_Averaged'])
+    v = [float(r['Counter_Value']) for r in sel]
     v = v[len(v) // 2:]
     return (sum(v) / len(v), len(v)) if v else None
 

@@ -38,15 +38,27 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ppo_ite
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sac_iteration -o p -- \
     python tools/sac_time_to_reward.py --budget 12 --eval-every 100000 > $OUT/sac_iteration.log 2>&1 < /dev/null
 fi
-# counter CSVs carry one row per dispatch of EVERY kernel (torch's included): keep the rows of this package's kernels only (gpurun merges <= 64 MiB back)
+# counter CSVs carry one row per dispatch (and counter dimension) of EVERY kernel: several MB per pass.  They are condensed ON THE BOX to
+# one row per (kernel, counter) — the mean over the second half of the dispatches of the per-dispatch sum — in p_counter_collection.csv's own
+# column names (what tools/profile_post.py reads), so that gpurun can merge the directory back (<= 64 MiB).
 python - <<'PY'
-import csv, glob, os
+import collections, csv, glob, os
 for f in glob.glob(os.path.join('gpurun_out', 'prof', '**', '*counter_collection.csv'), recursive=True):
-    rows = list(csv.DictReader(open(f)))
-    keep = [r for r in rows if 'scg::' in r.get('Kernel_Name', '') or 'step_' in r.get('Kernel_Name', '')]
-    if rows:
-        with open(f, 'w', newline='') as g:
-            w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))        # (kernel, counter) -> dispatch -> sum over rows
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        k = (r.get('Kernel_Name', ''), r.get('Counter_Name', ''))
+        if 'scg::' not in k[0] and 'step_' not in k[0]:
+            continue
+        per[k][r.get('Dispatch_Id', '0')] += float(r.get('Counter_Value', 0) or 0)
+        meta[k] = (r.get('VGPR_Count', ''), r.get('SGPR_Count', ''), r.get('Grid_Size', ''), r.get('Workgroup_Size', ''))
+    with open(f, 'w', newline='') as g:
+        w = csv.writer(g)
+        w.writerow(['Kernel_Name', 'Counter_Name', 'Counter_Value', 'Dispatches_Averaged', 'Dispatches_Total', 'VGPR_Count', 'SGPR_Count', 'Grid_Size', 'Workgroup_Size'])
+        for k, d in per.items():
+            ids = sorted(d, key=lambda x: int(x) if x.isdigit() else 0)
+            half = ids[len(ids) // 2:]
+            w.writerow([k[0], k[1], sum(d[i] for i in half) / max(1, len(half)), len(half), len(ids)] + list(meta[k]))
 PY
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete; find $OUT -name '*.db' -delete; find $OUT -name '*.log' -size +200k -delete
-du -sh $OUT; ls $OUT | head -80
+du -sh $OUT; du -sk $OUT/* | sort -n | tail -5
