@@ -134,7 +134,7 @@ def source_hash():
         with open(os.path.normpath(os.path.join(CSRC_DIR, name)), 'rb') as f:
             h.update(name.encode() + b'\0' + f.read())
     h.update(CODEGEN_FLAGS.encode())
-    h.update(b'sched:q2=max-ilp,q3dist=iterative-ilp')              # (sched_flags below: part of what a library was built with)
+    h.update(b'sched:q2=max-ilp,q3=max-ilp,q3dist=iterative-ilp')              # (sched_flags below: part of what a library was built with)
     return int.from_bytes(h.digest()[:8], 'little')
 
 
@@ -267,7 +267,10 @@ def sched_flags(cfg):
     in-order issue chain, so instruction ORDER is time; same-box A/B in tools/sessions/s39.sh / s40.sh, profiles/r03_summary.md):
     Quadrotor2D float kernels gain 3 % from LLVM's max-ILP strategy (5.38 -> 5.22 us), the disturbed Quadrotor3D kernels 2.4 % from
     the iterative-ILP one (11.12 -> 10.86 us; it crashes the compiler on the 2-D kernels, hence the fallback in build_spec);
-    CartPole (-2.6 %) and the plain Quadrotor3D kernels (+-0.5 %) keep the default.  A list of alternatives, first that compiles."""
+    CartPole (-2.6 %) keeps the default.  The plain Quadrotor3D kernels: round 3 / 4 measured +-0.5 % / -1.2 % and kept the default; on round 5's
+    sources (21-bit reset draws, EnvOps::step = advance + evaluate) the default schedule came out 4 % SLOWER than round 4's kernel on the same
+    box (8.60 vs 8.27 us) and max-ilp 2 % faster than it (8.04-8.16 us; tools/sessions/s111.sh, profiles/r05_step_kernel_ab.md section 5):
+    max-ilp since round 5.  A list of alternatives, first that compiles."""
     has_dist = any(int(n) > 0 for n in cfg.n_dist) or int(cfg.adversary_channel) >= 0       # (= SCG_SPEC_DIST, scg_kernels.hip)
     if int(cfg.dtype) != F32:
         return [[]]
@@ -275,6 +278,8 @@ def sched_flags(cfg):
         return [['-mllvm', '-amdgpu-sched-strategy=max-ilp'], []]
     if int(cfg.system) == QUAD_3D and has_dist:
         return [['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'], []]
+    if int(cfg.system) == QUAD_3D:
+        return [['-mllvm', '-amdgpu-sched-strategy=max-ilp'], []]
     return [[]]
 
 
