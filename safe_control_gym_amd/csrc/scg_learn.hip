@@ -573,47 +573,35 @@ __device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay, int log
     return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
 }
 
-// 256 partial-vector words per block (four consecutive words per lane: 16-byte loads), the workgroups' partials split over the block's
-// four waves (each wave keeps several independent loads in flight; one wave walking all 128 partials of a word was a 128-deep
-// dependent-latency chain), then a fixed-order sum of the four: deterministic — every WORD is summed in the order it always was
-// (round 5: dword loads made this launch 6.6 us for 19 MB).
-constexpr int RED_WORDS = 256;                                      // words per block of the two reduction kernels
-__device__ __forceinline__ f32x4 reduce_partials(const float* __restrict__ partials, int n_wg, int net, int k4, int grp, bool in_range,
-                                                 f32x4 (*part)[64], int kl) {
-    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (in_range) {
+// 64 partial-vector words per block, the workgroups' partials split over the block's four waves (each wave keeps several
+// independent loads in flight; one wave walking all 128 partials of a word was a 128-deep dependent-latency chain), then a
+// fixed-order sum of the four: deterministic.
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
+    __shared__ float part[4][64];
+    const int net = blockIdx.y;
+    const int kl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
+    const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
+    float s = 0.0f;
+    if (k < words) {
 #pragma unroll 8
-        for (int g = grp; g < n_wg; g += 4) s += *reinterpret_cast<const f32x4*>(partials + ((size_t)g * 2 + net) * PARTIAL_STRIDE + k4);
+        for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
     }
     part[grp][kl] = s;
     __syncthreads();
-    return (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
-}
-
-__global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
-    __shared__ f32x4 part[4][64];
-    const int net = blockIdx.y;
-    const int kl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int k4 = (blockIdx.x * 64 + kl) * 4;
-    const int words = net == 0 ? partial_words<NU>() : partial_words<1>();      // (multiples of 4: static_assert in grad_net)
-    const f32x4 s4 = reduce_partials(R.partials, R.n_wg, net, k4, grp, k4 < words, part, kl);
-    if (grp != 0 || k4 >= words) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k4 + j;
-        float s = s4[j];
-        const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
-        if (d >= 0) {
-            if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
-            R.grad[d] = s;
-        } else if (d == -2) {                                   // loss sum
-            R.stats[net == 0 ? 0 : 1] = s;
-        } else if (d == -3 && net == 0) {                       // approx-KL: rides in the gradient buffer's last slot
-            R.grad[R.n_params] = s;
-            R.stats[3] = s;
-        } else if (d == -4 && net == 0) {                       // entropy_loss (written by one workgroup of the gradient kernel)
-            R.stats[2] = s;
-        }
+    if (grp != 0 || k >= words) return;
+    s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
+    const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
+    if (d >= 0) {
+        if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
+        R.grad[d] = s;
+    } else if (d == -2) {                                   // loss sum
+        R.stats[net == 0 ? 0 : 1] = s;
+    } else if (d == -3 && net == 0) {                       // approx-KL: rides in the gradient buffer's last slot
+        R.grad[R.n_params] = s;
+        R.stats[3] = s;
+    } else if (d == -4 && net == 0) {                       // entropy_loss (written by one workgroup of the gradient kernel)
+        R.stats[2] = s;
     }
 }
 
@@ -629,12 +617,12 @@ struct StepArgs {
     const float* steps_in; float* steps_out; float target_kl; float* stats_acc;
 };
 __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const StepArgs S) {
-    __shared__ f32x4 part[4][64];
+    __shared__ float part[4][64];
     __shared__ float klw[4];
     const ReduceArgs& R = S.R;
     const int net = blockIdx.y;
     const int kl_ = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int k4 = (blockIdx.x * 64 + kl_) * 4;
+    const int k = blockIdx.x * 64 + kl_;
     const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
     {
         constexpr int KW = GradLds<NU>::STAT + 1;           // the actor's approx-KL word
@@ -644,42 +632,44 @@ __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const StepArgs S) 
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         if (kl_ == 0) klw[grp] = v;
     }
-    const f32x4 s4 = reduce_partials(R.partials, R.n_wg, net, k4, grp, k4 < words, part, kl_);     // (its barrier also publishes klw)
-    if (grp != 0 || k4 >= words) return;
+    float s = 0.0f;
+    if (k < words) {
+#pragma unroll 8
+        for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
+    }
+    part[grp][kl_] = s;
+    __syncthreads();
+    if (grp != 0 || k >= words) return;
+    s = (part[0][kl_] + part[1][kl_]) + (part[2][kl_] + part[3][kl_]);
     const float kl = (klw[0] + klw[1]) + (klw[2] + klw[3]);
     const bool gate = S.target_kl <= 0.0f || kl <= 1.5f * S.target_kl;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k4 + j;
-        float s = s4[j];
-        const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
-        if (d >= 0) {
-            if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
-            R.grad[d] = s;
-            const bool critic = net == 1;
-            if (critic || gate) {
-                const float t = S.steps_in[critic ? 1 : 0] + 1.0f;
-                const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-                const float m = b1 * S.m[d] + (1.0f - b1) * s;
-                const float v = b2 * S.v[d] + (1.0f - b2) * s * s;
-                S.m[d] = m; S.v[d] = v;
-                const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-                const float lr = critic ? S.lr_critic : S.lr_actor;
-                S.p[d] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
-            }
-        } else if (d == -2) {                                   // loss sum
-            R.stats[net == 0 ? 0 : 1] = s;
-            if (S.stats_acc) S.stats_acc[net == 0 ? 0 : 1] += s;
-        } else if (d == -3 && net == 0) {                       // approx-KL (+ the step's bookkeeping: this thread is unique in the launch)
-            R.grad[R.n_params] = kl;
-            R.stats[3] = kl;
-            S.steps_out[0] = S.steps_in[0] + (gate ? 1.0f : 0.0f);
-            S.steps_out[1] = S.steps_in[1] + 1.0f;
-            if (S.stats_acc) { S.stats_acc[3] += kl; S.stats_acc[4] += gate ? 1.0f : 0.0f; }
-        } else if (d == -4 && net == 0) {                       // entropy_loss
-            R.stats[2] = s;
-            if (S.stats_acc) S.stats_acc[2] += s;
+    const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
+    if (d >= 0) {
+        if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
+        R.grad[d] = s;
+        const bool critic = net == 1;
+        if (critic || gate) {
+            const float t = S.steps_in[critic ? 1 : 0] + 1.0f;
+            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+            const float m = b1 * S.m[d] + (1.0f - b1) * s;
+            const float v = b2 * S.v[d] + (1.0f - b2) * s * s;
+            S.m[d] = m; S.v[d] = v;
+            const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+            const float lr = critic ? S.lr_critic : S.lr_actor;
+            S.p[d] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
         }
+    } else if (d == -2) {                                   // loss sum
+        R.stats[net == 0 ? 0 : 1] = s;
+        if (S.stats_acc) S.stats_acc[net == 0 ? 0 : 1] += s;
+    } else if (d == -3 && net == 0) {                       // approx-KL (+ the step's bookkeeping: this thread is unique in the launch)
+        R.grad[R.n_params] = kl;
+        R.stats[3] = kl;
+        S.steps_out[0] = S.steps_in[0] + (gate ? 1.0f : 0.0f);
+        S.steps_out[1] = S.steps_in[1] + 1.0f;
+        if (S.stats_acc) { S.stats_acc[3] += kl; S.stats_acc[4] += gate ? 1.0f : 0.0f; }
+    } else if (d == -4 && net == 0) {                       // entropy_loss
+        R.stats[2] = s;
+        if (S.stats_acc) S.stats_acc[2] += s;
     }
 }
 
@@ -824,7 +814,7 @@ extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
     ReduceArgs R;
     R.partials = G.partials; R.n_wg = a->n_workgroups; R.actor = a->actor; R.critic = a->critic; R.logstd_off = a->logstd_off;
     R.n_params = a->n_params; R.entropy_coef = a->entropy_coef; R.params = a->d_params; R.grad = a->d_grad; R.stats = a->d_stats;
-    ppo_reduce_kernel<<<dim3((PARTIAL_STRIDE + RED_WORDS - 1) / RED_WORDS, 2), dim3(256), 0, st>>>(R);
+    ppo_reduce_kernel<<<dim3((PARTIAL_STRIDE + 63) / 64, 2), dim3(256), 0, st>>>(R);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -853,7 +843,7 @@ extern "C" int scg_ppo_step(const scg_ppo_grad_args* a, float* d_m, float* d_v, 
     S.R.n_params = a->n_params; S.R.entropy_coef = a->entropy_coef; S.R.params = a->d_params; S.R.grad = a->d_grad; S.R.stats = a->d_stats;
     S.p = const_cast<float*>(a->d_params); S.m = d_m; S.v = d_v; S.lr_actor = lr_actor; S.lr_critic = lr_critic;
     S.steps_in = d_steps_in; S.steps_out = d_steps_out; S.target_kl = target_kl; S.stats_acc = d_stats_acc;
-    ppo_reduce_adam_kernel<<<dim3((PARTIAL_STRIDE + RED_WORDS - 1) / RED_WORDS, 2), dim3(256), 0, st>>>(S);
+    ppo_reduce_adam_kernel<<<dim3((PARTIAL_STRIDE + 63) / 64, 2), dim3(256), 0, st>>>(S);
     HIP_TRY(hipGetLastError());
     return 0;
 }

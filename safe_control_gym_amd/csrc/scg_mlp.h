@@ -115,29 +115,7 @@ __device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, in
             if (k < N1) lds[L::W1F + k] = v[it];
         }
     }
-    // Four consecutive inputs of one output row (in = 4 m .. 4 m + 3) are four consecutive words q of ONE lane of the image
-    // (row(q, h) = (q & 3) + 8 (q >> 2) + 4 h), 16-byte aligned for both lane strides: with W2 itself 16-byte aligned in the parameter
-    // vector the fill is H^2 / 4 / NTHR 16-byte loads and as many ds_write_b128 per thread instead of four times as many dword moves
-    // (round 5: the fill was 4.8 us of every scg_ppo_grad call).  Same words, same places.
-    bool w2_filled = false;
-    if constexpr ((H * H / 4) % NTHR == 0 && (SS % 4) == 0) {
-        if ((reinterpret_cast<uintptr_t>(w.W2) & 15) == 0) {
-            constexpr int IT4 = H * H / 4 / NTHR;
-            f32x4 v[IT4];
-#pragma unroll
-            for (int j = 0; j < IT4; ++j) v[j] = reinterpret_cast<const f32x4*>(w.W2)[tid + j * NTHR];
-#pragma unroll
-            for (int j = 0; j < IT4; ++j) {
-                const int k = 4 * (tid + j * NTHR);
-                const int o = k / H, in = k % H;
-                const int rho = o >> 5, i = o & 31, tau = in >> 5, r = in & 31;
-                const int q = 4 * (r >> 3), h = (r >> 2) & 1;
-                *reinterpret_cast<f32x4*>(lds + L::W2F + (rho * L::NT + tau) * L::TILE2 + (i + 32 * h) * L::S + q) = v[j];
-            }
-            w2_filled = true;
-        }
-    }
-    if (!w2_filled) {                                                   // source order: W2[o][in], in fastest
+    {                                                                   // source order: W2[o][in], in fastest
         static_assert((H * H) % NTHR == 0, "workgroup size must divide H * H");
         constexpr int IT = H * H / NTHR, CH = fill_chunk(IT);         // H = 96: 36 loads per thread in two chunks of 18
         static_assert(IT % CH == 0, "chunking");
