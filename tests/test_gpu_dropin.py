@@ -294,7 +294,17 @@ def test_safe_explorer_ppo_controller_id_and_its_two_phases():
         assert {'agent', 'safety_layer', 'obs_normalizer', 'reward_normalizer'} <= set(st)
         assert set(st['safety_layer']) == {'constraint_models', 'optimizers'} and '11.fcs.1.weight' in st['safety_layer']['constraint_models']
         trained = {k: v.clone() for k, v in pre.safety_layer.constraint_models.state_dict().items()}
+        assert st['pretrain_steps'] == 4                   # the pre-training progress travels with the checkpoint (upstream: total_steps)
         pre.close()
+        # a resumed pre-training run continues where the checkpoint stopped instead of repeating all `constraint_epochs`
+        res = make('safe_explorer_ppo', env_func, training=True, checkpoint_path=os.path.join(out, 'res', 'model_latest.pt'),
+                   output_dir=os.path.join(out, 'res'), seed=2, pretraining=True, constraint_steps_per_epoch=256 * 12, constraint_epochs=6,
+                   constraint_eval_steps=256 * 4, eval_interval=0, log_interval=1, **common)
+        res.reset()
+        res.load(os.path.join(out, 'pre', 'model_latest.pt'))
+        assert res.total_steps == 4
+        assert len(res.learn()) == 2 and res.total_steps == 6          # epochs 5 and 6 only
+        res.close()
         with pytest.raises(AssertionError):                                                  # second phase without `pretrained`
             c = make('safe_explorer_ppo', env_func, training=True, output_dir=out, seed=2, pretraining=False, **common)
             c.reset()

@@ -306,3 +306,47 @@ print('DP_GRAPH_OK')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
     res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and 'DP_GRAPH_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_graph_captured_data_parallel_sac_steps_over_rccl_with_one_rank():
+    """SAC's data-parallel gradient steps (actor phase -> all-reduce -> critic phase -> all-reduce -> finish, sac.py::_fused_step_dp) as ONE
+    HIP-graph replay per vector step over RCCL: on a one-rank `nccl` group with `force_data_parallel`, four updates of 4 gradient steps
+    each (eager warm-up, capture, replays) must leave bit for bit the parameters, target networks and Adam moments of the same steps
+    enqueued one by one (`graph_collectives: False`)."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from safe_control_gym_amd import parallel
+from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+dev = torch.device('cuda', 0)
+low, high = -torch.ones(4, device=dev), torch.ones(4, device=dev)
+g = torch.Generator(device='cpu').manual_seed(5)
+n = 8192
+data = [torch.randn(n, 24, generator=g), torch.rand(n, 4, generator=g) * 2 - 1, torch.randn(n, generator=g), torch.randn(n, 24, generator=g),
+        (torch.rand(n, 1, generator=g) > 0.05).float()]
+def run(extra):
+    torch.manual_seed(3)
+    ag = SACAgent(24, 4, low, high, SACConfig(hidden_dim=128, activation='relu', use_entropy_tuning=True, extra=dict(extra, force_data_parallel=True)), dev)
+    assert ag.use_fused
+    buf = DeviceReplay(n, 24, 4, dev)
+    buf.push(*[t.to(dev) for t in data])
+    for _ in range(4):
+        res = ag.update_from_buffer(buf, 1024, 4)
+    torch.cuda.synchronize()
+    fl = ag._flat
+    return {k: fl[k].clone() for k in ('p', 'targ', 'm', 'v', 'steps')}, ag.dp_path, res
+a, path_a, _ = run({'graph_collectives': False})
+b, path_b, res = run({})
+assert path_a == 'eager' and path_b.startswith('one graph replay per vector step'), (path_a, path_b)
+for k in a:
+    assert torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+assert all(map(lambda v: v == v, res.values()))
+dist.destroy_process_group()
+print('SAC_DP_GRAPH_OK')
+'''
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and 'SAC_DP_GRAPH_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
