@@ -16,7 +16,7 @@ configs' env kernels: cartpole_stab incl. the fused random-action rollout of con
 HBM roofline at this N), `fused_rollout` (K steps per launch with the PPO actor in the loop), `ppo` (budgeted wall-clock-to-reward runs at
 BASELINE config #3's batch: 2 partial epochs x 32 minibatches of 16 256 per iteration, with `ppo.full_epochs` and `ppo.envs_16384` beside
 it), `sac` (config #5's env; `sac.param_randomised` = with flyable parameter disturbances, target re-measured under them), `cpu_baseline`.
-`roofline.traffic`, `roofline.valu_issue`, `f64.traffic`, `sequence.*.traffic*` are quoted from profiles/r04_hbm_traffic.json (rocprofv3
+`roofline.traffic`, `roofline.valu_issue`, `f64.traffic`, `sequence.*.traffic*` are quoted from profiles/r05_hbm_traffic.json (rocprofv3
 --pmc passes) only while that file names the hash of the kernel sources in this tree.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU with
@@ -42,7 +42,7 @@ ALGO_BYTES_PER_ENV_STEP = {'quadrotor_2D_track': 187, 'cartpole_stab': 111, 'qua
 KERNEL_NAME = {'quadrotor_2D_track': 'step_kernel<QUAD_2D,float>', 'cartpole_stab': 'step_kernel<CARTPOLE,float>',
                'quadrotor_3D_track': 'step_kernel<QUAD_3D,float>', 'quadrotor_3D_track_disturbed': 'step_kernel<QUAD_3D,float,DIST>'}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# HBM traffic / executed-instruction counts come from committed rocprofv3 --pmc passes (tools/profile_round4.sh ->
+# HBM traffic / executed-instruction counts come from committed rocprofv3 --pmc passes (tools/profile_round5.sh ->
 # tools/profile_post.py).  They describe ONE build of the kernels: the file carries the hash of the kernel sources it was measured
 # on, and a line printed from other sources drops the number (traffic: null, with the reason) instead of quoting a stale one.
 TRAFFIC_FILE = 'r05_hbm_traffic.json'
@@ -160,7 +160,7 @@ _PMC_CACHE = {}
 
 
 def pmc_entry(key):
-    """Entry `key` of profiles/r04_hbm_traffic.json if that file was measured on THESE kernel sources, else (None, why)."""
+    """Entry `key` of profiles/r05_hbm_traffic.json if that file was measured on THESE kernel sources, else (None, why)."""
     if 'file' not in _PMC_CACHE:
         try:
             with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
@@ -181,7 +181,7 @@ def pmc_entry(key):
 
 def traffic_of(task, dtype, n):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this very command (separate FETCH_SIZE / WRITE_SIZE
-    passes, gfx950 x2 fetch correction — tools/profile_round4.sh, tools/profile_post.py)."""
+    passes, gfx950 x2 fetch correction — tools/profile_round5.sh, tools/profile_post.py)."""
     e, src = pmc_entry(f'{task}/{dtype}/{n}')
     return (e['traffic_bytes_per_launch'] if e else None), src
 
