@@ -14,7 +14,7 @@ Secondary objects (rank 0, N = 1): `f64` (the float64 kernels of the same worklo
 configs' env kernels: cartpole_stab incl. the fused random-action rollout of config #2, quadrotor_3D_track[_disturbed]),
 `gae` (scg_gae timing + its own roofline), `sequence` (scg_step_sequence: K control steps per launch, the mode that carries >= 0.40 of the
 HBM roofline at this N), `fused_rollout` (K steps per launch with the PPO actor in the loop), `ppo` (budgeted wall-clock-to-reward runs at
-BASELINE config #3's batch: 2 partial epochs x 32 minibatches of 16 256 per iteration, with `ppo.full_epochs` and `ppo.envs_16384` beside
+BASELINE config #3's batch: 3 partial epochs x 16 minibatches of 16 256 per iteration, with `ppo.full_epochs` and `ppo.envs_16384` beside
 it), `sac` (config #5's env; `sac.param_randomised` = with flyable parameter disturbances, target re-measured under them), `cpu_baseline`.
 `roofline.traffic`, `roofline.valu_issue`, `f64.traffic`, `sequence.*.traffic*` are quoted from profiles/r05_hbm_traffic.json (rocprofv3
 --pmc passes) only while that file names the hash of the kernel sources in this tree.
@@ -529,8 +529,14 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
     # samples, 2 PARTIAL epochs of 32 minibatches of 16 256 (a uniform half of the rollout; PPOConfig.extra minibatches_per_epoch)
     # reach the target in 0.71 s median (0.60-0.77) where 2 full epochs of 32 x 65 024 need 1.30 s; the full-epoch figure stays in
     # the line (`full_epochs`).  Also probed: 1 x 64 of 16 256: 0.98 s; 2 x 16 of 32 512: 0.89; 2 x 32 of 32 512: 0.97; 2 x 16 of 65 024: 0.95.
+    # round 5 (tools/sessions/s118.sh, s119.sh; 8 seeds per setting, two boxes; profiles/r05_ppo_probe_*.json): the same optimiser-step budget
+    # spent as 3 partial epochs x 16 minibatches (48 steps per iteration instead of 64) needs the same ~ 95 iterations and reaches the target
+    # 14 % earlier on both boxes (median 0.649 vs 0.755 s and 0.790 vs 0.937 s); 4 x 12: 0.634; 2 x 24: 0.829 (slow box); 2 x 16: 0.723; 4 x 16:
+    # 0.729; lr 3e-3, target_kl 0.05, 16-step rollouts, 8128-row minibatches: all slower.
     if mb_per_epoch == 'auto':
-        mb_per_epoch = 32 if (envs >= 65536 and minibatch is None) else None
+        mb_per_epoch = 16 if (envs >= 65536 and minibatch is None) else None
+        if mb_per_epoch and epochs is None:
+            epochs = 3
     if minibatch is None:
         minibatch = 16256
     if epochs is None:
@@ -631,9 +637,9 @@ def multi_gpu_readiness(torch, dist, world):
     and size of the collectives per learner iteration and the fixed cost of one such all-reduce on the RCCL path (one rank: enqueue
     + kernel, no wire), eager and captured in a HIP graph — the data-parallel PPO epoch is one graph replay (ppo.py::_dp_epoch)."""
     from safe_control_gym_amd import parallel
-    res = {'ppo': {'collectives_per_iteration': 64, 'bucket_bytes': 4 * 36742, 'what': 'flat fp32 gradients of actor + critic (12-128-128-{2,1}) + the approx-KL slot, '
-                   'SUM all-reduce, 1 / world folded into scg_adam_gated_scaled; 2 epochs x 32 minibatches', 'host_enqueues_per_iteration_over_rccl': 2,
-                   'host_path': 'one HIP-graph replay per epoch: 32 x (gradient kernel, reduction, all-reduce, gated Adam)'},
+    res = {'ppo': {'collectives_per_iteration': 48, 'bucket_bytes': 4 * 36742, 'what': 'flat fp32 gradients of actor + critic (12-128-128-{2,1}) + the approx-KL slot, '
+                   'SUM all-reduce, 1 / world folded into scg_adam_gated_scaled; 3 epochs x 16 minibatches', 'host_enqueues_per_iteration_over_rccl': 3,
+                   'host_path': 'one HIP-graph replay per epoch: 16 x (gradient kernel, reduction, all-reduce, gated Adam)'},
            'sac': {'collectives_per_vector_step': 32, 'bucket_bytes': 4 * 61451, 'what': 'the flat fp32 gradient vector (actor + log alpha + both critics, 24-128-128 nets) SUM-all-reduced '
                    'twice per gradient step (after the actor phase, after the critic phase), 16 gradient steps per vector step (sac.py::_fused_step_dp)',
                    'host_enqueues_per_vector_step_over_rccl': 1, 'host_path': 'one HIP-graph replay per vector step (16 gradient steps, 32 all-reduces)'},
