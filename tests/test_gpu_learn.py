@@ -139,6 +139,29 @@ def test_gated_adam_kernel_equals_the_graphed_torch_adam():
     assert F['stats_acc'][4].item() == ref['steps'][0]
 
 
+def test_scaled_adam_reads_the_summed_gradient_times_one_over_world():
+    """scg_adam_gated_scaled (the data-parallel step: SUM all-reduce, then Adam reading g x 1 / world — gradients AND the approx-KL slot that
+    gates the actor) == scg_adam_gated on the mean gradient: bit for bit with a power-of-two world (the scaling is exact), over steps with
+    the gate open and closed, where the SUMMED approx-KL alone would close it."""
+    a, b = _agent(12, 128, 2, 'tanh'), _agent(12, 128, 2, 'tanh')
+    Fa, Fb = (x._build_fused(_data(12, 2, 256, x), 256) for x in (a, b))
+    b._flat['p'].copy_(a._flat['p'])
+    n = a._flat['n']
+    g = torch.Generator(device='cuda').manual_seed(2)
+    world = 4
+    for kl in (0.001, 0.02, 0.5, 0.025):                     # gate: kl <= 1.5 target_kl = 0.03; 0.02 x 4 and 0.025 x 4 exceed it: only the MEAN may gate
+        grad = torch.randn(n + 1, device='cuda', generator=g) * 0.1
+        grad[n] = kl
+        a._flat['g'].copy_(grad)
+        a._fused_adam(Fa)
+        b._flat['g'].copy_(grad * world)                     # what the SUM all-reduce of `world` identical ranks leaves
+        b._fused_adam(Fb, 1.0 / world)
+    torch.cuda.synchronize()
+    for k in ('p', 'm', 'v', 'steps'):
+        assert torch.equal(a._flat[k], b._flat[k]), k
+    assert a._flat['steps'].tolist() == [3.0, 4.0]           # the actor skipped the kl = 0.5 step only
+
+
 @pytest.mark.parametrize('cap', [None, 3], ids=['full_epochs', 'partial_epochs'])
 def test_fused_update_matches_the_torch_update_statistically(cap):
     """A whole PPOAgent.update through the fused kernels vs the graphed PyTorch path from identical parameters, data and
