@@ -773,6 +773,8 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
             'reached': len(ok1), 'reached_two_consecutive': len(ok2), 'median_first_hit_s': statistics.median(ok1) if ok1 else None,
             'median_two_consecutive_s': statistics.median(ok2) if ok2 else None, 'median_s': statistics.median(ok2) if ok2 else None,
             'budget_s_per_seed': budget_s, 'fused_update': fused,
+            'scope': ("BASELINE config #5's ENV and algorithm (Quadrotor3D lemniscate tracking, dynamics disturbance, constraint evaluation, SAC) on "
+                      f'{world} GPU(s) at {envs} envs per GPU; config #5 itself names 8 x MI355X, which has not been run (DESIGN.md section 5)'),
             'hyper': f'MLP 24-128-128 relu (actor + twin Q), batch {batch}, {updates_per_step} gradient steps per vector step of {envs} envs, '
                      f'lr {lr:g}, warm-up {warm_up_steps} env steps, tau 0.005, alpha 0.2'}
 
