@@ -223,3 +223,27 @@ def test_bench_quotes_pmc_numbers_only_for_the_kernel_sources_they_were_measured
             assert r['frac_by_clock']['in_graph_hip_events']['frac'] == pytest.approx(r['frac'])
         assert r['frac'] == pytest.approx(187 * 65536 / 4.2e-6 / 8e12)
     bench._PMC_CACHE.clear()
+
+
+def test_bench_names_the_launch_geometry_and_gates_the_chain_model_on_the_source_hash(tmp_path, monkeypatch):
+    """bench.py's `roofline.kernel` names the launch geometry scg_step picks for the shard size (scg_kernels.hip defaults, scg_set_step_launch),
+    and `chain_latency` is quoted only from a model file computed on THESE kernel sources."""
+    import json
+    import bench
+    from safe_control_gym_amd import _lib
+    assert 'step_split_kernel' in bench.launch_geometry(16384, True) and 'step_split_kernel' in bench.launch_geometry(32768, True)
+    assert bench.launch_geometry(65536, True).startswith('step_kernel (one wave per 64 envs')
+    assert 'step_wide_kernel' in bench.launch_geometry(16777216, True) and 'step_wide_kernel' not in bench.launch_geometry(4194304, True)
+    assert 'generic library' in bench.launch_geometry(65536, False)
+    src = open(os.path.join(ROOT, 'safe_control_gym_amd', 'csrc', 'scg_kernels.hip')).read()
+    assert f'#define SCG_SPLIT_MAX_ENVS {bench.LAUNCH_SPLIT_MAX}' in src and f'#define SCG_WIDE_MIN_ENVS {bench.LAUNCH_WIDE_MIN}' in src
+    os.makedirs(tmp_path / 'profiles')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    model = {'_meta': {'source_hash': f'0x{_lib.source_hash():016x}'},
+             'cartpole_stab': {'chain_us_per_control_step': 3.7, 'issue_limit_us_per_control_step': 2.7, 'dependent_instructions_per_substep': 21.0}}
+    (tmp_path / 'profiles' / 'r05_chain_latency.json').write_text(json.dumps(model))
+    got = bench.chain_latency_of('cartpole_stab', 5.5)
+    assert got['frac_of_launch'] == pytest.approx(3.7 / 5.5) and got['issue_limit_us'] == 2.7
+    model['_meta']['source_hash'] = '0x0123456789abcdef'
+    (tmp_path / 'profiles' / 'r05_chain_latency.json').write_text(json.dumps(model))
+    assert 'dropped' in bench.chain_latency_of('cartpole_stab', 5.5)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: SCG_PAIR_MAX_ENVS and the pe64 / pe128 / spec tags belong to the paired launch, which this session measured and the round then removed)
 # round 5, GPU session 2: the paired step launch (bitwise tests, A/B at 65 536 envs for the four tasks, workgroup-size / speculation variants, N sweep),
 # workgroup sizes in the streaming regime (1 M - 16 M envs), the graph-captured data-parallel epoch over one-rank RCCL, timelines.
 cd "$GRAFT_REPO_ROOT" || exit 1
