@@ -51,13 +51,16 @@ SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
 # scg_kernels.hip defaults (scg_set_step_launch): which launch geometry of the step kernel a shard of N envs takes
 LAUNCH_SPLIT_MAX = int(os.environ.get('SCG_SPLIT_MAX_ENVS', 32768))
 LAUNCH_WIDE_MIN = int(os.environ.get('SCG_WIDE_MIN_ENVS', 8388608))
+LAUNCH_WSBACK = (int(os.environ.get('SCG_WSBACK_MIN_ENVS', 131072)), int(os.environ.get('SCG_WSBACK_MAX_ENVS', 524288)))
 
 
-def launch_geometry(n, specialised):
+def launch_geometry(n, specialised, task='quadrotor_2D_track'):
     if not specialised:
         return 'step_kernel (generic library: 256-thread workgroups, parameters staged in LDS)'
     if n <= LAUNCH_SPLIT_MAX:
-        return 'step_split_kernel (two independent waves per 64 envs, each half of the outputs)'
+        return 'step_split_kernel (the two waves of a 128-thread workgroup per 64 envs, each half of the outputs, one barrier)'
+    if LAUNCH_WSBACK[0] <= n <= LAUNCH_WSBACK[1] and n < LAUNCH_WIDE_MIN and not task.startswith('cartpole'):
+        return 'step_wsback_kernel (one wave per 64 envs, workspace arrays stored write-back)'
     if n >= LAUNCH_WIDE_MIN:
         return 'step_wide_kernel (256-thread workgroups)'
     return 'step_kernel (one wave per 64 envs, one-wave workgroups)'
@@ -509,6 +512,35 @@ def shipped_ppo_score(torch, eval_env, tag='quadrotor_2D_track', hidden=128, act
             'episodes': evals * eval_env.num_envs}
 
 
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense float32 matrix peak (v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz)
+LEARNER_SUMS_FILE = 'r06_learner_kernel_sums.json'
+
+
+def mlp_flops(nin, h, nout, backward=False):
+    """Algorithmic flops of one row through nin -> h -> h -> nout: forward 2 (nin h + h h + h nout); with backward x 3 (forward, data
+    gradient, weight gradient — DESIGN.md 4.6's accounting: the first layer's unused data gradient is counted, as the 864 MFMAs per tile are)."""
+    f = 2 * (nin * h + h * h + h * nout)
+    return 3 * f if backward else f
+
+
+def learner_kernel_sum(key):
+    """Sum of kernel durations of one learner iteration (rocprofv3 --kernel-trace of tools/learner_profile.py, condensed into
+    profiles/r06_learner_kernel_sums.json) — quoted only while that file names the hashes of the learner / simulator sources of this tree."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', LEARNER_SUMS_FILE)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, f'profiles/{LEARNER_SUMS_FILE} not present'
+    from safe_control_gym_amd import _learn, _lib, _sac
+    want = {'env': f'0x{_lib.source_hash():016x}', 'learn': f'0x{_learn.source_hash():016x}', 'sac': f'0x{_sac.source_hash():016x}'}
+    have = d.get('_meta', {}).get('source_hashes', {})
+    need = ('env', 'learn') if key.startswith('ppo') else ('env', 'sac')
+    if any(have.get(k) != want[k] for k in need):
+        return None, f'profiles/{LEARNER_SUMS_FILE} was measured on other kernel sources: dropped'
+    e = d.get(key)
+    return (e, f'profiles/{LEARNER_SUMS_FILE} (rocprofv3 --kernel-trace --stats, {key})') if e else (None, f'profiles/{LEARNER_SUMS_FILE} has no entry {key}')
+
+
 def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=None, lr=2e-3, target_kl=0.03, epochs=None, rollout_steps=32,
             target=None, mb_per_epoch='auto'):
     """PPO wall-clock until the deterministic-policy evaluation reaches the reference reward on BASELINE config #3's batch
@@ -565,12 +597,21 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
     # learner / rollout code objects, kernel attributes, first launches — were 0.45 s of the first seed's first iteration
     # (tools/ppo_iter_times.py: 455 ms, then 6.4 ms per iteration; the second seed's first iteration: 6.4 ms) and are not training.
     w_env = HipVecEnv(env_id, envs, seed=0, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
+    w_eval = HipVecEnv(env_id, EVAL_ENVS, seed=0, return_numpy=False, policy=pol, **ev_cfg)
     torch.cuda.synchronize()
     t_cold = time.perf_counter()
-    PPO(w_env, config(), seed=0).train_step()
+    w_ppo = PPO(w_env, config(), seed=0)
+    w_aev = AsyncEvaluator(w_ppo, w_eval)
+    for _ in range(3):                                  # eager, captured, replayed (PPO._run_iteration) + the evaluator's first launch
+        w_ppo.train_step(lazy=(world == 1))
+        w_aev.launch()
+    w_aev.poll(wait=True)
     torch.cuda.synchronize()
     t_cold = time.perf_counter() - t_cold               # reported beside the clocks: what a fresh process pays once on top of them
-    w_env.close()
+    w_env.close(); w_eval.close()
+    del w_ppo, w_aev
+    RUN_AHEAD = 2                                       # iterations the host may have enqueued beyond the one the GPU is running
+    wall_it, dev_it, paths = [], [], []
     for seed in range(1, seeds + 1):
         env = HipVecEnv(env_id, envs, seed=seed, env_id_offset=rank * envs, return_numpy=False, policy=pol, **cfg)
         eval_env = HipVecEnv(env_id, EVAL_ENVS, seed=seed * 111, return_numpy=False, policy=pol, **ev_cfg)
@@ -578,38 +619,117 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
         ppo = PPO(env, pcfg, seed=seed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        t_first, t_both, best, it, streak, last_ret = None, None, -1e30, 0, 0, None
-        max_it = int(budget_s / 0.005)                  # iteration cap (identical on every rank: no rank leaves a collective alone)
+        t_first, t_both, best, it, streak, last_ret, cap_err = None, None, -1e30, 0, 0, None, None
+        max_it = int(budget_s / 0.004)                  # iteration cap (identical on every rank: no rank leaves a collective alone)
         aev = AsyncEvaluator(ppo, eval_env)
-        while it < max_it:
-            ppo.train_step()
-            it += 1
-            ev = aev.poll()
-            torch.cuda.current_stream().synchronize()
-            el = time.perf_counter() - t0
-            if ev is not None:
-                last_ret = ev['ep_return']
-                best = max(best, last_ret)
-                streak = streak + 1 if last_ret >= target else 0
-                if streak >= 1 and t_first is None:
-                    t_first = el
-            flag = torch.tensor([1.0 if streak >= 2 else 0.0, 1.0 if el > budget_s else 0.0], device=env.device)
-            if world > 1:                               # rank 0 decides for everybody
-                parallel.broadcast_(flag, 0)
-            if flag[0].item() > 0:
-                t_both = el
-                break
-            if flag[1].item() > 0:
-                break
-            aev.launch(tag=it)
+
+        def seen(ev, el):
+            """Book one finished evaluation at host time `el`; True when the stopping rule (two consecutive >= target) holds."""
+            nonlocal last_ret, best, streak, t_first
+            last_ret = ev['ep_return']
+            best = max(best, last_ret)
+            streak = streak + 1 if last_ret >= target else 0
+            if streak >= 1 and t_first is None:
+                t_first = el
+            return streak >= 2
+
+        if world == 1:
+            # ONE rank: nothing in this loop waits for the GPU.  Each train_step(lazy=True) is one HIP-graph replay (collection, GAE,
+            # normalisation, 48 optimiser steps); the host stays at most RUN_AHEAD iterations ahead of the device (an event per
+            # iteration, polled), the evaluator's result arrives through its own event, and the clock is read when a finished
+            # evaluation is SEEN — the weights that earned it existed by then.  The iterations still queued when the rule holds are
+            # drained outside the clock.
+            pending, ev_times = [], []
+            stop = False
+            while it < max_it and not stop:
+                res = ppo.train_step(lazy=True)
+                it += 1
+                ev_times.append(res['events'])
+                pending.append(res['events'][2])
+                aev.launch(tag=it)
+                while True:
+                    ev = aev.poll()
+                    el = time.perf_counter() - t0
+                    if ev is not None and seen(ev, el):
+                        t_both, stop = el, True
+                        break
+                    if el > budget_s:
+                        stop = True
+                        break
+                    while pending and pending[0].query():
+                        pending.pop(0)
+                    if len(pending) <= RUN_AHEAD:
+                        break
+            t_loop = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_drained = time.perf_counter() - t0
+            # steady-state iteration: device time between the end events of consecutive replays, median (one replay per iteration)
+            gaps = sorted(1e-3 * a[2].elapsed_time(b[2]) for a, b in zip(ev_times[2:-1], ev_times[3:]))
+            dev_it.append(gaps[len(gaps) // 2] if gaps else None)
+            wall_it.append(t_drained / max(it, 1))
+            paths.append('one HIP-graph replay per iteration' if getattr(ppo, '_iter_graph', None) and ppo._iter_graph.get('graph') is not None else 'per-launch enqueue')
+        else:
+            while it < max_it:
+                ppo.train_step()
+                it += 1
+                ev = aev.poll()
+                torch.cuda.current_stream().synchronize()
+                el = time.perf_counter() - t0
+                hit = ev is not None and seen(ev, el)
+                flag = torch.tensor([1.0 if (hit or streak >= 2) else 0.0, 1.0 if el > budget_s else 0.0], device=env.device)
+                parallel.broadcast_(flag, 0)                # rank 0 decides for everybody
+                if flag[0].item() > 0:
+                    t_both = el
+                    break
+                if flag[1].item() > 0:
+                    break
+                aev.launch(tag=it)
+            torch.cuda.synchronize()
+            wall_it.append((time.perf_counter() - t0) / max(it, 1)); dev_it.append(None); paths.append(ppo.agent.dp_path)
+            cap_err = ppo.agent.dp_capture_error
         last = aev.poll(wait=True)
         if last is not None:
             best = max(best, last['ep_return'])
             last_ret = last['ep_return']
         first.append(t_first); both.append(t_both); its.append(it); best_all.append(best); final.append(last_ret)
         env.close(); eval_env.close()
+    ranks = None
+    if world > 1:
+        # one row per rank, so that a driver line can be read against DESIGN.md section 5's expectation table: how the data-parallel epoch
+        # ran on THAT rank (captured graph / eager + why), its iteration time (synchronised loop: wall = device), and the spread
+        mine = {'rank': rank, 'dp_path': paths[-1] if paths else None, 'dp_capture_error': cap_err if paths else None,
+                'iteration_ms': 1e3 * statistics.median(wall_it) if wall_it else None}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     ok1, ok2 = [t for t in first if t is not None], [t for t in both if t is not None]
-    return {'target_return': target, 'target_source': 'shipped ppo_model_quadrotor_2D_track.pt under this protocol' if shipped else 'caller',
+    # ---- where an iteration's time goes, and what fraction of the float32 matrix peak its algorithmic work is
+    n_steps_it = epochs * min(envs * rollout_steps // minibatch, mb_per_epoch or 10 ** 9)
+    flops_it = (envs * rollout_steps * mlp_flops(12, 128, 2) + envs * (rollout_steps + 1) * mlp_flops(12, 128, 1)
+                + n_steps_it * minibatch * (mlp_flops(12, 128, 2, True) + mlp_flops(12, 128, 1, True)))
+    wall_ms = 1e3 * statistics.median(wall_it) if wall_it else None
+    dev_ok = [d for d in dev_it if d is not None]
+    dev_ms = 1e3 * statistics.median(dev_ok) if dev_ok else None
+    ks, ks_src = learner_kernel_sum(f'ppo/{envs}/{n_steps_it}x{minibatch}')
+    ks_ms = ks['kernel_sum_ms_per_iteration'] if ks else None
+    frac = lambda ms: (flops_it / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if ms else None        # noqa: E731
+    iteration_ms = {'wall_per_iteration': wall_ms, 'device_steady_state': dev_ms, 'kernel_sum': ks_ms,
+                    'gap': (wall_ms - ks_ms) if (wall_ms and ks_ms) else None, 'wall_over_kernel_sum': (wall_ms / ks_ms) if (wall_ms and ks_ms) else None,
+                    'kernel_sum_source': ks_src, 'host_path': paths[0] if paths else None,
+                    'what': 'wall = (clock start .. queue drained) / iterations, median over seeds (includes the capture iteration and the evaluator '
+                            'beside it); device_steady_state = median distance between consecutive iterations\' end events; kernel_sum = rocprofv3'}
+    learner_roofline = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': F32_MFMA_PEAK_TFLOPS, 'flops_per_iteration': flops_it,
+                        'kernel_sum_ms': ks_ms, 'wall_ms': wall_ms, 'achieved': (flops_it / (wall_ms * 1e-3) / 1e12) if wall_ms else None,
+                        'frac_of_f32_mfma_peak': frac(wall_ms), 'frac_on_kernel_time': frac(ks_ms),
+                        'gap_frac': ((wall_ms - ks_ms) / wall_ms) if (wall_ms and ks_ms) else None,
+                        'work': f'collector actor passes {envs} x {rollout_steps} rows + critic passes on {rollout_steps + 1} x {envs} rows + '
+                                f'{n_steps_it} optimiser steps x {minibatch} rows x (forward + data gradient + weight gradient) of both networks'}
+    per_rank = {}
+    if ranks:
+        ms = [r['iteration_ms'] for r in ranks if r and r.get('iteration_ms')]
+        per_rank = {'ranks': ranks, 'iteration_ms_max_over_ranks': max(ms) if ms else None,
+                    'iteration_ms_skew_max_minus_min': (max(ms) - min(ms)) if ms else None}
+    return {**per_rank, 'iteration_ms': iteration_ms, 'roofline': learner_roofline,
+            'target_return': target, 'target_source': 'shipped ppo_model_quadrotor_2D_track.pt under this protocol' if shipped else 'caller',
             'shipped_model_eval': shipped, 'eval_protocol': f'{EVAL_ENVS} distinct episodes per evaluation, one per eval env, initial state = '
             f'config init + U(x +-0.5, z +-0.5, pitch +-0.1, velocities +-0.01) per episode (fresh draws every evaluation), deterministic '
             f'policy, mean return', 'envs_per_gpu': envs, 'rollout_steps': rollout_steps, 'n_gpus': world, 'seeds': list(range(1, seeds + 1)),
@@ -668,8 +788,15 @@ def multi_gpu_readiness(torch, dist, world):
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('PROBE_JSON ')]
         if not line:
             raise RuntimeError('probe printed nothing: ' + (p.stderr or '')[-300:])
-        res['allreduce_us'] = json.loads(line[-1][len('PROBE_JSON '):])
-        res['allreduce_us']['note'] = 'one rank (enqueue + kernel, no wire), in-place fp32 SUM, microseconds per collective; child process'
+        pr = json.loads(line[-1][len('PROBE_JSON '):])
+        for k, row in pr.items():                       # a one-rank in-place all-reduce is ELIDED by RCCL once captured: not a cost of anything
+            if isinstance(row, dict) and 'captured_us' in row:
+                row['captured_us_one_rank_elided'] = row.pop('captured_us')
+        res['allreduce_us'] = pr
+        res['allreduce_us']['note'] = ('ONE rank, child process: eager_us = host enqueue + the no-op kernel of the RCCL path (no wire); '
+                                       'captured_us_one_rank_elided is what a graph replay of 50 one-rank in-place all-reduces costs per '
+                                       'collective — RCCL elides them, so it measures NOTHING about the captured data-parallel step; the wire terms of '
+                                       'DESIGN.md section 5 are estimates until a --gpus N line carries this probe on a real group')
     except Exception as exc:                                            # noqa: BLE001
         res['allreduce_us'] = {'error': repr(exc)[:300]}
     return res
@@ -711,7 +838,7 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
     det0 = Det(shipped)
     evs = [evaluate(det0, eval_env) for _ in range(4)]
     target = sum(e['ep_return'] for e in evs) / len(evs)
-    first, both, best_all, steps_all, grads_all, rate = [], [], [], [], [], []
+    first, both, best_all, steps_all, grads_all, rate, vstep_ms = [], [], [], [], [], [], []
     # untimed: a scratch instance (seed 0) takes a few vector steps, gradient steps and one evaluation-sized policy call, so that the
     # process's one-time costs (code-object loads, kernel attributes, first launches) are not inside the first seed's clock
     w_env = HipVecEnv(env_id, envs, seed=0, env_id_offset=rank * envs, return_numpy=False, **cfg)
@@ -733,18 +860,36 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
         t0 = time.perf_counter()
         t_first, t_both, best, it, streak, n_grad = None, None, -1e30, 0, 0, 0
         finished = False
+        pending, t_eval, t_learn0, it_learn0 = [], 0.0, None, 0
         while True:
-            go = torch.tensor([1.0 if (time.perf_counter() - t0 < budget_s and not finished) else 0.0], device=env.device)
             if world > 1:                               # rank 0's clock: every rank leaves on the same iteration
+                go = torch.tensor([1.0 if (time.perf_counter() - t0 < budget_s and not finished) else 0.0], device=env.device)
                 parallel.broadcast_(go, 0)
-            if go.item() == 0:
+                if go.item() == 0:
+                    break
+            elif finished or time.perf_counter() - t0 >= budget_s:
                 break
-            res = sac.train_step()
+            # ONE rank: a vector step is two graph replays (collector; 16 gradient steps) and no read-back (lazy): the host only waits
+            # when it is more than 4 vector steps ahead of the device, and at the evaluations (every `eval_every` steps, inside the clock)
+            res = sac.train_step(lazy=(world == 1))
+            if n_grad == 0 and res.get('updates'):      # first learning step: the clock of the steady-state vector step starts here
+                torch.cuda.synchronize()
+                t_learn0, it_learn0 = time.perf_counter(), it
             n_grad += int(res.get('updates', 0))
             it += 1
+            if world == 1:
+                e = torch.cuda.Event()
+                e.record()
+                pending.append(e)
+                if len(pending) > 4:
+                    pending.pop(0).synchronize()
             if it % eval_every == 0:
+                torch.cuda.synchronize()
+                te = time.perf_counter()
                 e = evaluate(det, eval_env)
                 torch.cuda.synchronize()
+                pending.clear()
+                t_eval += time.perf_counter() - te
                 el = time.perf_counter() - t0
                 best = max(best, e['ep_return'])
                 streak = streak + 1 if e['ep_return'] >= target else 0
@@ -755,13 +900,42 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
                     finished = True                     # (leaves at the top of the next iteration, together with the other ranks)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        if t_learn0 is not None and it > it_learn0:     # learning vector steps only, evaluations taken out
+            evals_learning = it // eval_every - it_learn0 // eval_every
+            vstep_ms.append(1e3 * (time.perf_counter() - t_learn0 - t_eval * evals_learning / max(1, it // eval_every)) / (it - it_learn0))
         first.append(t_first); both.append(t_both); best_all.append(best); steps_all.append(sac.total_steps); grads_all.append(n_grad)
         rate.append(sac.total_steps / wall)
         fused = bool(getattr(sac.agent, 'use_fused', False))
+        dp_path, dp_err = getattr(sac.agent, 'dp_path', None), getattr(sac.agent, 'dp_capture_error', None)
         env.close()
     eval_env.close()
     ok1, ok2 = [t for t in first if t is not None], [t for t in both if t is not None]
-    return {'task': 'quadrotor_3D_track_disturbed ' + ('(randomized_inertial_prop ON: additive draws per episode, training AND evaluation envs, '
+    # ---- the gradient step against the float32 matrix peak: algorithmic flops per minibatch row of one SACAgent.update
+    # (sac_utils.py:143-170): actor forward on obs and on next_obs, both Q forward + d q / d a at (obs, a), the actor's backward
+    # (forward recomputed + data + weight gradients), both target Q forward, both Q forward + data + weight gradients
+    nobs, nu, hd = spec.obs_dim, spec.nu, 128
+    a_f, q_f = mlp_flops(nobs, hd, 2 * nu), mlp_flops(nobs + nu, hd, 1)
+    flops_step = batch * (2 * a_f + 2 * 2 * q_f + 3 * a_f + 2 * q_f + 2 * 3 * q_f)
+    ks, ks_src = learner_kernel_sum(f'sac/{batch}/{updates_per_step}')
+    step_us = ks['gradient_step_us'] if ks else None
+    vs_ms = statistics.median(vstep_ms) if vstep_ms else None
+    sac_roofline = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': F32_MFMA_PEAK_TFLOPS, 'flops_per_gradient_step': flops_step,
+                    'gradient_steps_per_vector_step': updates_per_step, 'gradient_step_us_rocprof': step_us,
+                    'kernel_sum_ms_per_vector_step': ks['kernel_sum_ms_per_vector_step'] if ks else None, 'wall_ms_per_vector_step': vs_ms,
+                    'frac_of_f32_mfma_peak': (updates_per_step * flops_step / (vs_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if vs_ms else None,
+                    'frac_on_kernel_time': (flops_step / (step_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS) if step_us else None,
+                    'gap_frac': ((vs_ms - ks['kernel_sum_ms_per_vector_step']) / vs_ms) if (vs_ms and ks) else None, 'kernel_sum_source': ks_src,
+                    'what': 'wall = learning vector steps only (after warm-up), evaluations taken out, median over seeds'}
+    per_rank = {}
+    if world > 1:
+        import torch.distributed as dist
+        mine = {'rank': rank, 'dp_path': dp_path, 'dp_capture_error': dp_err, 'vector_step_ms': vs_ms}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        ms = [r['vector_step_ms'] for r in rows if r and r.get('vector_step_ms')]
+        per_rank = {'ranks': rows, 'vector_step_ms_max_over_ranks': max(ms) if ms else None,
+                    'vector_step_ms_skew_max_minus_min': (max(ms) - min(ms)) if ms else None}
+    return {**per_rank, 'roofline': sac_roofline, 'task': 'quadrotor_3D_track_disturbed ' + ('(randomized_inertial_prop ON: additive draws per episode, training AND evaluation envs, '
                     f'{ {k: (v["low"], v["high"]) for k, v in param_rand.items()} })' if param_rand else '(randomized_inertial_prop off)'),
             'target_return': target,
             'target_source': 'shipped sac_model_quadrotor_3D_track.pt under this protocol',
@@ -896,7 +1070,7 @@ def main():
                                  + ('; per rank: barrier + synchronize, clock, K steps, synchronize, clock, barrier; MAX over ranks' if world > 1 else ''),
                        'timed_region_samples_ms': [round(1e3 * s, 4) for s in (min(samples), elapsed, max(samples))]},
             'roofline': roofline_of(args.task, args.dtype, N, period_us, driver_step_us=1e6 * elapsed / done_steps,
-                                    geometry=launch_geometry(N, bool(hb.env.specialized))),
+                                    geometry=launch_geometry(N, bool(hb.env.specialized), args.task)),
         }
     full = not args.no_secondary and args.task == 'quadrotor_2D_track' and args.dtype == 'f32'
     # The learning legs run collectives (N > 1: RCCL).  A rank that dies or hangs inside one must not cost the run its line:
@@ -949,6 +1123,12 @@ def main():
             if world == 1 and args.ppo_envs >= 65536:           # the same batch with FULL epochs (round 3's configuration), same protocol and target
                 res['full_epochs'] = ppo_leg(torch, dist, world, rank, args.ppo_seeds, args.ppo_seconds, envs=args.ppo_envs, minibatch=65024,
                                              mb_per_epoch=None, target=res['target_return'])
+                # `median_s` is the UPSTREAM-semantics figure (full shuffled epochs, ppo_utils.py:113-146) so that rounds stay comparable;
+                # the partial-epoch configuration's clock has its own name
+                res['median_s_partial_epochs'] = res.pop('median_s')
+                res['median_s'] = res['full_epochs']['median_s']
+                res['median_s_semantics'] = ('median_s = full_epochs.median_s (upstream PPO epochs); median_s_partial_epochs = this object\'s own '
+                                             'configuration (3 partial epochs x 16 minibatches per iteration)')
         except Exception as exc:                                    # noqa: BLE001
             import traceback
             res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
@@ -964,9 +1144,35 @@ def main():
             res = {'error': repr(exc)[:300], 'trace': traceback.format_exc()[-600:]}
         if rank == 0:
             out['sac'] = res
+    probe = None
+    if full and world > 1 and backend == 'nccl':            # every rank: the all-reduce of the learners' buckets on the REAL group
+        try:
+            from safe_control_gym_amd import parallel
+            probe = parallel.allreduce_probe((4 * 36742, 4 * 61451))
+        except Exception as exc:                                    # noqa: BLE001
+            probe = {'error': repr(exc)[:300]}
     watchdog.cancel()
     if rank == 0 and full:
         out['multi_gpu'] = multi_gpu_readiness(torch, dist, world)
+        if probe is not None:
+            probe['note'] = f'{world} ranks over RCCL, in-place fp32 SUM, microseconds per collective (eager; 50 per HIP-graph replay)'
+            out['multi_gpu']['allreduce_us'] = probe
+            out['multi_gpu']['measured_with_more_than_one_gpu'] = True
+        # the learning legs' rooflines, flattened into the object the driver's parser keeps (depth 2)
+        rf = out['roofline']
+        pr = (out.get('ppo') or {}).get('roofline') or {}
+        pi = (out.get('ppo') or {}).get('iteration_ms') or {}
+        sr = (out.get('sac') or {}).get('roofline') or {}
+        rf['learners'] = {'peak_TFLOPs_f32_mfma': F32_MFMA_PEAK_TFLOPS,
+                          'ppo_flops_per_iteration': pr.get('flops_per_iteration'), 'ppo_wall_ms_per_iteration': pi.get('wall_per_iteration'),
+                          'ppo_device_ms_per_iteration': pi.get('device_steady_state'), 'ppo_kernel_sum_ms_per_iteration': pi.get('kernel_sum'),
+                          'ppo_wall_over_kernel_sum': pi.get('wall_over_kernel_sum'), 'ppo_frac_of_peak_on_wall': pr.get('frac_of_f32_mfma_peak'),
+                          'ppo_frac_of_peak_on_kernel_time': pr.get('frac_on_kernel_time'),
+                          'ppo_median_s_partial_epochs': (out.get('ppo') or {}).get('median_s_partial_epochs'),
+                          'ppo_median_s_full_epochs': (out.get('ppo') or {}).get('median_s'),
+                          'sac_flops_per_gradient_step': sr.get('flops_per_gradient_step'), 'sac_gradient_step_us': sr.get('gradient_step_us_rocprof'),
+                          'sac_wall_ms_per_vector_step': sr.get('wall_ms_per_vector_step'), 'sac_frac_of_peak_on_wall': sr.get('frac_of_f32_mfma_peak'),
+                          'sac_frac_of_peak_on_kernel_time': sr.get('frac_on_kernel_time'), 'sac_median_s': (out.get('sac') or {}).get('median_s')}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.task, hb.cfg, hb.env_id, args.cpu_seconds, N)

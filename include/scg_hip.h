@@ -245,9 +245,10 @@ int scg_step(scg_env* env, const void* d_action, const void* d_adv_action, const
 
 /* The same control step for the env range [first_env, first_env + n_envs) only (first_env a multiple of 64).  All
  * array arguments are the FULL [N]-sized arrays; only the rows of that range are read and written.  Envs are
- * independent (dummy_vec_env.py:29-41 is a serial loop over them), so a caller may advance disjoint ranges of one
- * handle from different streams concurrently: at 65 536 envs a launch is a latency chain (dispatch, loads, one wave's
- * instruction stream, store drain) and sub-shard launches on 2-4 streams overlap one range's chain with another's. */
+ * independent (dummy_vec_env.py:29-41 is a serial loop over them), so disjoint ranges of one handle may be advanced by
+ * separate calls, in any order, from any streams.  (Measured on ROCm 7.2 / MI355X: sub-shard launches on 2-4 streams do NOT
+ * overlap — the queues are drained one kernel at a time and the launch floor is paid per range; tools/README.md.  The
+ * entry point is for callers that own only part of a handle's envs, not a throughput device.) */
 int scg_step_range(scg_env* env, int first_env, int n_envs, const void* d_action, const void* d_adv_action,
                    const scg_step_out* out, void* stream);
 
@@ -318,9 +319,21 @@ int scg_get_params(scg_env* env, double* h_params, int first_env, int n, void* s
  *   <= split_max_envs   two independent waves per 64 envs, each the whole control step for half of the outputs (shards that leave
  *                       SIMDs empty: up to half a wave per SIMD; default 32 768 or env SCG_SPLIT_MAX_ENVS);
  *   >= wide_min_envs    256-thread workgroups (the largest shards; default 8 388 608 or env SCG_WIDE_MIN_ENVS);
+ *   wsback_min_envs .. wsback_max_envs (Quadrotor systems; default 131 072 .. 524 288 or env SCG_WSBACK_MIN_ENVS / SCG_WSBACK_MAX_ENVS,
+ *                       scg_set_step_wsback): one-wave workgroups with the handle's WORKSPACE arrays stored write-back — the next
+ *                       launch's wave of the same env group reads them from the same XCD's L2 (-4 .. -9 % per launch there);
  *   otherwise, and the generic library always: one wave per 64 envs in one-wave workgroups.
- * A negative argument leaves that threshold unchanged; 0 switches the split launch off, INT_MAX the wide one. */
+ * A negative argument leaves that threshold unchanged; 0 switches the split launch off, INT_MAX the wide one;
+ * scg_set_step_wsback(env, 1, 0) (an empty range) switches the write-back launch off. */
 int scg_set_step_launch(scg_env* env, int split_max_envs, int wide_min_envs);
+int scg_set_step_wsback(scg_env* env, int wsback_min_envs, int wsback_max_envs);
+/* Version of the Philox WORD LAYOUT of the reset draws (which bits of which block feed which initial-state / parameter / offset
+ * variable).  Seeded runs and checkpoints reproduce only within one version:
+ *   1  rounds 1-4: one 32-bit word per one-word draw, four per block;
+ *   2  round 5 on: six 21-bit fields per block for the compact (uniform / one-word) draws (csrc/scg_rng.h, oracle/rng.py).
+ * Checkpoints carry it (HipVecEnv.get_env_random_state) and a load under another version warns. */
+#define SCG_RNG_LAYOUT_VERSION 2
+int scg_rng_layout_version(void);
 /* BenchmarkEnv.seed (benchmark_env.py:193-214): new Philox key for subsequent draws. */
 int scg_set_seed(scg_env* env, uint64_t seed);
 /* ctrl_step_counter / episode index per env (benchmark_env.py:329-330). */

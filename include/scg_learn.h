@@ -97,6 +97,11 @@ int scg_ppo_step(const scg_ppo_grad_args* args, float* d_m, float* d_v, float lr
 /* d_out[i] = pi(i) for i < count, pi a keyed pseudo-random permutation of [0, n) (count <= n): the shuffled row indices of
  * one epoch's minibatches (SubsetRandomSampler + BatchSampler(drop_last=True), ppo_utils.py:358-371), one launch. */
 int scg_random_permutation(int32_t* d_out, int n, int count, uint64_t key, void* stream);
+/* The same with the key taken from DEVICE memory: d_key_state [2] = {base key, epochs drawn so far}, key = base +
+ * 0x9E3779B97F4A7C15 * (drawn + epoch_offset + 1) (mod 2^64) — the sequence scg_random_permutation gives a host that counts its
+ * epochs.  A caller that captures its epochs in a HIP graph advances `drawn` on the stream after them (one add), and every replay
+ * shuffles afresh; nothing about the shuffle is baked into the graph. */
+int scg_random_permutation_keyed(int32_t* d_out, int n, int count, const uint64_t* d_key_state, uint32_t epoch_offset, void* stream);
 
 const char* scg_learn_last_error(void);
 const char* scg_learn_source_hash_tag(void);

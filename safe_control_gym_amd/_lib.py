@@ -110,7 +110,7 @@ class RolloutOut(C.Structure):
 
 EXPORTS = ['scg_dims', 'scg_workspace_bytes', 'scg_create', 'scg_destroy', 'scg_reset', 'scg_step', 'scg_step_range', 'scg_step_sequence', 'scg_rollout_policy',
            'scg_rollout_random', 'scg_set_state', 'scg_get_state', 'scg_set_params', 'scg_get_params',
-           'scg_set_counters', 'scg_get_counters', 'scg_set_seed', 'scg_set_step_launch', 'scg_gae', 'scg_prior_model', 'scg_last_error', 'scg_abi_version',
+           'scg_set_counters', 'scg_get_counters', 'scg_set_seed', 'scg_set_step_launch', 'scg_set_step_wsback', 'scg_rng_layout_version', 'scg_gae', 'scg_prior_model', 'scg_last_error', 'scg_abi_version',
            'scg_sizeof_config', 'scg_sizeof_step_out', 'scg_spec_source', 'scg_spec_hash', 'scg_source_hash']
 
 
@@ -215,6 +215,7 @@ def _bind(path):
     L.scg_source_hash.restype = c_u64
     L.scg_set_seed.argtypes = [c_vp, c_u64]
     L.scg_set_step_launch.argtypes = [c_vp, C.c_int, C.c_int]
+    L.scg_set_step_wsback.argtypes = [c_vp, C.c_int, C.c_int]
     return L
 
 

@@ -620,13 +620,18 @@ __device__ __forceinline__ T planar_pitch(T th) {
 // ------------------------------------------------------------------ the environment
 // DIST: any passive disturbance or adversary configured (host-selected kernel variant).
 // STAUX: cache policy of every store this code issues (its own workspace arrays and the slots it is handed), see Slot.
-template <int SYS, typename T, bool DIST, int STAUX = SCG_ST_AUX>
+// WSAUX: cache policy of the stores to the handle's own WORKSPACE arrays (raw state, counters, per-env parameters, disturbance offsets,
+// the stale out-of-bounds byte).  They are read back by the NEXT launch's wave of the same env group, which the dispatcher places on the
+// same XCD: written back (0) they stay in that XCD's L2 instead of crossing to the memory side and back — which pays where a launch is
+// several waves per SIMD and already bandwidth-bound (Quadrotor shards of 131 072 .. 524 288 envs: -4 .. -9 % per launch,
+// profiles/r05_ab_s122_s123_workspace_write_back.txt) and costs where it is one latency chain (65 536 envs: +1.7 %).
+template <int SYS, typename T, bool DIST, int STAUX = SCG_ST_AUX, int WSAUX = STAUX>
 struct EnvOps {
     using D = Dims<SYS>;
     using E = Env<SYS, T>;
     template <typename V>
-    __device__ static __forceinline__ Slot<V, STAUX> ws_slot(__amdgpu_buffer_rsrc_t r, uint32_t soff, int lane_index) {
-        return slot_in<V>(r, soff, lane_index).template with<STAUX>();
+    __device__ static __forceinline__ Slot<V, WSAUX> ws_slot(__amdgpu_buffer_rsrc_t r, uint32_t soff, int lane_index) {
+        return slot_in<V>(r, soff, lane_index).template with<WSAUX>();
     }
     // speculative reset draws inside the integrator (PreDraw): specialised float builds whose reset is exactly the compact
     // initial-state draw (-DSCG_NO_PREDRAW switches it off: A/B measurements).  CartPole only since round 4: its 50-substep loop is a
@@ -1741,7 +1746,7 @@ SCG_BOX_UNROLL
             }
             if (!tracking) {
                 // stale `self.out_of_bounds` on goal_reached steps (see oracle/envs.py::_stale_oob)
-                const Slot<uint8_t, STAUX> attr = ws_slot<uint8_t>(make_rsrc(P.i.ws), P.i.oob_off, env_index);
+                const auto attr = ws_slot<uint8_t>(make_rsrc(P.i.ws), P.i.oob_off, env_index);
                 const bool prev = attr.load() != 0;
                 oob = goal ? prev : oob;
                 attr.store(oob ? 1 : 0);

@@ -250,19 +250,28 @@ __device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* 
 //   ROLE_SCORE  reward, done, flags, mse, noisy action, the constraint rows, the episode statistics (read-modify-write);
 //   ROLE_STATE  observation, terminal observation, auto-reset (Philox draws), env.state, the workspace state and counters.
 // The serial tail behind the integrator (51 % of the wave's lifetime at 65 536 envs, profiles/r04_timeline_*) is cut in two and the
-// halves run side by side on the SIMD's two wave slots; the price is the second read of state + action (+40 B per env-step from the
-// memory side).  Neither role reads anything the other writes in the same launch.
+// halves run side by side; the price is the second read of state + action (+40 B per env-step).
+// ORDERING (round 6; the round-5 launch had the two roles in independent workgroups and relied on dispatch order): ROLE_STATE
+// overwrites what ROLE_SCORE reads — the workspace state, counters, per-env parameters and disturbance offsets (Ops::reset /
+// Ops::store).  The two waves of a group are therefore the two waves of ONE 128-thread workgroup (wave 0 SCORE, wave 1 STATE) and
+// meet at one hardware barrier: SCORE arrives at its end — every value it loaded has been consumed by then, i.e. its reads are done
+// — and STATE waits there before its first workspace store (pair_barrier below).  No store of STATE can precede a load of SCORE.
 enum : int { ROLE_ALL = 0, ROLE_SCORE = 1, ROLE_STATE = 2 };
 
+// One s_barrier without the s_waitcnt a __syncthreads() carries: the SCORE wave's outstanding STORES (other arrays) need not land
+// before the STATE wave may write the workspace; the "memory" clobber keeps the compiler from moving memory operations across it.
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 // BLK: threads per workgroup of the kernel that inlines this body (BLOCK, or WIDE_BLOCK for step_wide_kernel).
-template <int SYS, typename T, bool DIST, bool ONE, int ROLE, int BLK = BLOCK>
+// WSWB: the workspace arrays are stored write-back (EnvOps' WSAUX = 0) instead of write-through — step_wsback_kernel.
+template <int SYS, typename T, bool DIST, bool ONE, int ROLE, int BLK = BLOCK, bool WSWB = false>
 __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, const InstParams<T>& I,
                                           const T* __restrict__ action, const T* __restrict__ adv,
                                           const typename OutTabOf<ONE>::type& O, const int wg) {
-    using Ops = EnvOps<SYS, T, DIST>;
+    using Ops = EnvOps<SYS, T, DIST, SCG_ST_AUX, WSWB ? 0 : SCG_ST_AUX>;
     using D = Dims<SYS>;
     constexpr bool SCORE = ROLE != ROLE_STATE, STATE = ROLE != ROLE_SCORE;
-    const int tid = (int)threadIdx.x;
+    const int tid = ROLE == ROLE_ALL ? (int)threadIdx.x : ((int)threadIdx.x & 63);   // (split launch: lane of either wave of the pair)
     const int i = I.env_first + wg * BLK + tid;
     const int N = I.num_envs;
     const bool live = i < I.env_end;
@@ -379,7 +388,7 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         const T nxt[4] = {r.done ? (T)0 : ep[0], r.done ? (T)0 : ep[1], r.done ? (T)0 : ep[2], r.done ? (T)0 : ep[3]};
         Q.ep_stats.template store_row<4>(nxt);
     }
-    if constexpr (!STATE) { SCG_TL(6); SCG_TL(7); return; }
+    if constexpr (!STATE) { SCG_TL(6); SCG_TL(7); pair_barrier(); return; }       // (every load of this wave has been consumed)
     // observation of the step: goes to terminal_observation where the env is about to auto-reset, else it is the
     // returned obs (two write_obs call sites only: the disturbance code is inlined into each)
 #ifdef SCG_EXP_NO_RESET
@@ -394,6 +403,7 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         int nrow = Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, pre_ext ? ext_pre : nullptr, row);
         if (r.done && Q.terminal_obs) Ops::store_obs_row(P, row, nrow, Q.terminal_obs);   // (also the non-auto-reset case)
         SCG_TL(6);
+        if constexpr (ROLE == ROLE_STATE) pair_barrier();      // the SCORE wave's reads precede the workspace stores below
         if (do_reset) {
             Ops::reset(P, i, e, key, st);           // auto-reset (dummy_vec_env.py:33-38)
             nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row);
@@ -417,6 +427,7 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         if (r.done && Q.terminal_obs)
             Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, Q.terminal_obs, nullptr);
         SCG_TL(6);
+        if constexpr (ROLE == ROLE_STATE) pair_barrier();
         if (do_reset) {
             Ops::reset(P, i, e, key, st);
             Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs, nullptr);
@@ -450,17 +461,26 @@ __global__ __launch_bounds__(WIDE_BLOCK) void step_wide_kernel(const CfgParams<T
     step_body<SYS, T, DIST, ONE, ROLE_ALL, WIDE_BLOCK>(Cg, I, action, adv, O, (int)blockIdx.x);
 }
 
-// Split launch: 2 x (env groups rounded up to a multiple of 8) workgroups.  Workgroup b serves env group 8 (b / 16) + b % 8 in
-// role (b / 8) % 2: the two waves of a group are eight workgroups apart, i.e. (with the observed round-robin placement) on the same
-// XCD, so that the second read of the group's state can hit that XCD's L2; correctness does not depend on placement.
+// Mid-size shards (SCG_WSBACK_MIN_ENVS <= envs <= SCG_WSBACK_MAX_ENVS, Quadrotor systems): the same one-wave workgroups with the
+// workspace arrays written BACK (see EnvOps' WSAUX) — everything the caller sees is still written through.
 template <int SYS, typename T, bool DIST, bool ONE>
-__global__ __launch_bounds__(BLOCK) void step_split_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                           const T* __restrict__ action, const T* __restrict__ adv,
-                                                           const typename OutTabOf<ONE>::type O) {
-    const int b = (int)blockIdx.x;
-    const int wg = ((b >> 4) << 3) | (b & 7);
-    if ((b >> 3) & 1) step_body<SYS, T, DIST, ONE, ROLE_STATE>(Cg, I, action, adv, O, wg);
-    else step_body<SYS, T, DIST, ONE, ROLE_SCORE>(Cg, I, action, adv, O, wg);
+__global__ __launch_bounds__(BLOCK) void step_wsback_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
+                                                            const T* __restrict__ action, const T* __restrict__ adv,
+                                                            const typename OutTabOf<ONE>::type O) {
+    step_body<SYS, T, DIST, ONE, ROLE_ALL, BLOCK, true>(Cg, I, action, adv, O, (int)blockIdx.x);
+}
+
+// Split launch: one 128-thread workgroup per 64 envs — wave 0 in ROLE_SCORE, wave 1 in ROLE_STATE (same CU: the second read of the
+// group's state and action hits that CU's vector cache), ordered by pair_barrier (see the ROLE comment above).  A tail group's dead
+// lanes return in both waves alike; a wave with any live lane reaches its barrier.
+constexpr int SPLIT_BLOCK = 128;
+template <int SYS, typename T, bool DIST, bool ONE>
+__global__ __launch_bounds__(SPLIT_BLOCK) void step_split_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
+                                                               const T* __restrict__ action, const T* __restrict__ adv,
+                                                               const typename OutTabOf<ONE>::type O) {
+    const int wg = (int)blockIdx.x;
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) step_body<SYS, T, DIST, ONE, ROLE_STATE, 64>(Cg, I, action, adv, O, wg);
+    else step_body<SYS, T, DIST, ONE, ROLE_SCORE, 64>(Cg, I, action, adv, O, wg);
 }
 #endif
 

@@ -74,11 +74,17 @@ struct scg_env {
     bool has_dist;
     // step-launch geometry of the specialised builds by shard size (scg_set_step_launch): <= split_max: two waves per 64 envs, each
     // the whole step for half of the outputs; >= wide_min: 256-thread workgroups
-    int split_max, wide_min;
+    int split_max, wide_min, wsback_min, wsback_max;
 };
 
 // Step-launch geometry by shard size, measured on MI355X (profiles/r05_step_kernel_ab.md); the environment variables of the same names
 // override the built-in thresholds at scg_create, scg_set_step_launch per handle.
+#ifndef SCG_WSBACK_MIN_ENVS
+#define SCG_WSBACK_MIN_ENVS 131072      // Quadrotor shards of 131 072 .. 524 288 envs: workspace arrays written back (step_wsback_kernel)
+#endif
+#ifndef SCG_WSBACK_MAX_ENVS
+#define SCG_WSBACK_MAX_ENVS 524288
+#endif
 #ifndef SCG_SPLIT_MAX_ENVS
 #define SCG_SPLIT_MAX_ENVS 32768          // <= half a wave per SIMD: two independent waves per 64 envs (step_split_kernel)
 #endif
@@ -568,6 +574,8 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
     e->split_max = launch_default("SCG_SPLIT_MAX_ENVS", SCG_SPLIT_MAX_ENVS);
+    e->wsback_min = launch_default("SCG_WSBACK_MIN_ENVS", SCG_WSBACK_MIN_ENVS);
+    e->wsback_max = launch_default("SCG_WSBACK_MAX_ENVS", SCG_WSBACK_MAX_ENVS);
     e->wide_min = launch_default("SCG_WIDE_MIN_ENVS", SCG_WIDE_MIN_ENVS);
     e->has_dist = cfg->n_dist[0] > 0 || cfg->n_dist[1] > 0 || cfg->n_dist[2] > 0 || cfg->adversary_channel >= 0;
     hipError_t err = hipMemset(d_workspace, 0, L.total);
@@ -674,14 +682,25 @@ static int launch_step(scg_env* env, int first, int count, const void* action, c
     // two waves per 64 envs, each producing half of the outputs (step_split_kernel, scg_env_kernels.h).  Larger shards are
     // bandwidth-bound and keep one wave per 64 envs.  Same results bit for bit (tests/test_gpu_env_parity.py).
     if (count <= env->split_max) {
-        const int grid2 = 2 * ((grid + 7) / 8 * 8);
+        const int grid = (count + 63) / 64;
         if (one_base) {
-            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, true><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
+            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, true><<<dim3(grid), dim3(SPLIT_BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
         } else {
-            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, false><<<dim3(grid2), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, false><<<dim3(grid), dim3(SPLIT_BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
         }
         HIP_TRY(hipGetLastError());
         return SCG_OK;
+    }
+    if constexpr (SCG_SPEC_SYS != SCG_CARTPOLE) {        // (CartPole's 50-substep chain gains nothing from it: 13.3 -> 13.9 us at 262 144 envs)
+        if (count >= env->wsback_min && count <= env->wsback_max && count < env->wide_min) {
+            if (one_base) {
+                DISPATCH_SYS(env, T, (step_wsback_kernel<S, T, DD, true><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
+            } else {
+                DISPATCH_SYS(env, T, (step_wsback_kernel<S, T, DD, false><<<dim3(grid), dim3(BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
+            }
+            HIP_TRY(hipGetLastError());
+            return SCG_OK;
+        }
     }
     if (count >= env->wide_min) {
         const int grid_w = (count + WIDE_BLOCK - 1) / WIDE_BLOCK;
@@ -891,6 +910,13 @@ extern "C" int scg_get_params(scg_env* env, double* h_params, int first_env, int
     }
     return env->dtype == SCG_F64 ? copy_soa<double>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream)
                                  : copy_soa<float>(env, env->d_param, env->np, h_params, nullptr, first_env, n, (hipStream_t)stream);
+}
+extern "C" int scg_rng_layout_version(void) { return SCG_RNG_LAYOUT_VERSION; }
+extern "C" int scg_set_step_wsback(scg_env* env, int wsback_min_envs, int wsback_max_envs) {
+    if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
+    if (wsback_min_envs >= 0) env->wsback_min = wsback_min_envs;
+    if (wsback_max_envs >= 0) env->wsback_max = wsback_max_envs;
+    return SCG_OK;
 }
 extern "C" int scg_set_step_launch(scg_env* env, int split_max_envs, int wide_min_envs) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");

@@ -729,10 +729,19 @@ __device__ __forceinline__ uint32_t perm_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
 }
+// KEYED: the 64-bit key is derived on the device from a two-word state {base key, epochs drawn so far} the caller keeps in device
+// memory — key = base + 0x9E3779B97F4A7C15 (drawn + epoch_offset + 1) — so that a launch captured in a HIP graph shuffles
+// differently at every replay (the caller advances `drawn` with a stream-ordered add after its epochs).
+template <bool KEYED>
 __global__ __launch_bounds__(256) void permutation_kernel(int32_t* __restrict__ out, uint32_t n, uint32_t count, int half,
-                                                           uint32_t k0, uint32_t k1) {
+                                                           uint32_t k0, uint32_t k1, const uint64_t* __restrict__ key_state,
+                                                           uint32_t epoch_offset) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    if constexpr (KEYED) {
+        const uint64_t key = key_state[0] + 0x9E3779B97F4A7C15ull * (key_state[1] + (uint64_t)epoch_offset + 1ull);
+        k0 = (uint32_t)key; k1 = (uint32_t)(key >> 32);
+    }
     const uint32_t mask = (1u << half) - 1u;
     uint32_t x = i;
     do {
@@ -756,8 +765,19 @@ extern "C" int scg_random_permutation(int32_t* d_out, int n, int count, uint64_t
     int bits = 1;
     while (bits < 31 && (1u << bits) < (uint32_t)n) ++bits;
     const int half = (bits + 1) / 2;
-    permutation_kernel<<<dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-        d_out, (uint32_t)n, (uint32_t)count, half, (uint32_t)key, (uint32_t)(key >> 32));
+    permutation_kernel<false><<<dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+        d_out, (uint32_t)n, (uint32_t)count, half, (uint32_t)key, (uint32_t)(key >> 32), nullptr, 0u);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int scg_random_permutation_keyed(int32_t* d_out, int n, int count, const uint64_t* d_key_state, uint32_t epoch_offset, void* stream) {
+    if (!d_out || !d_key_state || n <= 0 || count < 0 || count > n) return fail(-1, "scg_random_permutation_keyed: bad argument");
+    if (count == 0) return 0;
+    int bits = 1;
+    while (bits < 31 && (1u << bits) < (uint32_t)n) ++bits;
+    const int half = (bits + 1) / 2;
+    permutation_kernel<true><<<dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+        d_out, (uint32_t)n, (uint32_t)count, half, 0u, 0u, d_key_state, epoch_offset);
     HIP_TRY(hipGetLastError());
     return 0;
 }

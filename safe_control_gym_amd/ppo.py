@@ -187,6 +187,7 @@ class PPOAgent:
         from safe_control_gym_amd import _learn
         self.obs_dim, self.act_dim = obs_dim, act_dim
         self._perm_key, self._perm_count = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, 0
+        self._perm_dev = None               # device mirror {base key, epochs drawn} (scg_random_permutation_keyed), made on first use
         self.use_fused = (self.use_graphs and bool(cfg.extra.get('fused_update', True))
                           and _learn.supported(obs_dim, cfg.hidden_dim, act_dim, cfg.activation))
         self._fused = None
@@ -293,7 +294,9 @@ class PPOAgent:
         configuration).  The first epoch that sees a (permutation bank, n_mb) pair runs eagerly (it warms the communicator up for this
         message size), the second captures; a capture that fails falls back to the eager loop for good (recorded in `dp_path`)."""
         graphs = F.setdefault('dp_graphs', {})
-        key = (bank, n_mb)
+        cfg = self.cfg              # (every value the captured launches carry BY VALUE is part of the key: a changed cfg re-captures)
+        key = (bank, n_mb, world, float(cfg.actor_lr), float(cfg.critic_lr), float(cfg.target_kl), float(cfg.clip_param),
+               float(cfg.entropy_coef), bool(cfg.use_clipped_value), bool(self._fused_step_ok))
         state = graphs.get(key)
         want = parallel.collectives_capturable() and self.cfg.extra.get('graph_collectives', True)
         if not want or state == 'eager':
@@ -307,13 +310,17 @@ class PPOAgent:
             try:
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: with several ranks ProcessGroupNCCL's watchdog THREAD queries events while this thread captures; under
+                # the default (global) mode such a call from another thread invalidates the capture
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._dp_minibatches(F, perm, n_mb, world)
                 graphs[key] = state = g
             except Exception as exc:                                  # noqa: BLE001  (no capture support in this build: stay eager)
                 graphs[key] = 'eager'
                 self.dp_capture_error = repr(exc)[:200]
                 self.dp_path = 'eager (capture failed)'
+                import warnings
+                warnings.warn(f'PPO data-parallel epoch: HIP-graph capture failed, staying on the eager loop ({self.dp_capture_error})')
                 return self._dp_minibatches(F, perm, n_mb, world)
         state.replay()
         self.dp_path = f'one graph replay per epoch ({n_mb} x (grad, reduce, all-reduce, adam))'
@@ -340,7 +347,24 @@ class PPOAgent:
         cap = self.cfg.extra.get('minibatches_per_epoch')
         return max(1, min(n_mb, int(cap))) if cap else n_mb
 
-    def _update_fused(self, data, generator=None):
+    def _perm_state(self):
+        """{base key, epochs drawn so far} in device memory: what scg_random_permutation_keyed derives each epoch's key from, so that
+        an update captured in a HIP graph shuffles afresh at every replay.  Mirrors (self._perm_key, self._perm_count)."""
+        vals = [self._perm_key - (1 << 64) if self._perm_key >= (1 << 63) else self._perm_key, self._perm_count]
+        if self._perm_dev is None:
+            self._perm_dev = torch.tensor(vals, dtype=torch.int64, device=self.device)
+        return self._perm_dev
+
+    def _sync_perm_state(self):
+        """(after load_state_dict: in place — captured graphs alias the tensor)"""
+        if self._perm_dev is not None:
+            vals = [self._perm_key - (1 << 64) if self._perm_key >= (1 << 63) else self._perm_key, self._perm_count]
+            self._perm_dev.copy_(torch.tensor(vals, dtype=torch.int64))
+
+    def _update_fused(self, data, generator=None, lazy=False):
+        """lazy=True: enqueue only — nothing is read back; the statistics stay in the device tensor returned as 'stats_dev'
+        (sums over the update's minibatches of policy / value / entropy loss, approx-KL, actor steps taken; valid until the next
+        update's kernels run).  Every launch of this function is capturable in a HIP graph (PPO._iteration_graph)."""
         cfg = self.cfg
         M = data['obs'].shape[0]
         mb = min(cfg.mini_batch_size, M)
@@ -354,10 +378,11 @@ class PPOAgent:
         n_mb = self._capped(n_mb)
         for k, v in data.items():
             assert v.dtype == torch.float32 and v.is_contiguous(), k
-        if self._fused is None or self._fused['key'] != (M, mb):
+        fkey = (M, mb, float(cfg.clip_param), float(cfg.entropy_coef), bool(cfg.use_clipped_value))   # (what the argument block carries by value)
+        if self._fused is None or self._fused['key'] != fkey:
             static = {k: (v if k in ('obs', 'act', 'logp', 'v') else torch.empty_like(v)) for k, v in data.items()}
             self._fused = self._build_fused(static, mb)
-            self._fused['key'] = (M, mb)
+            self._fused['key'] = fkey
         F = self._fused
         from safe_control_gym_amd import _learn
         if 'perm' not in F or F['perm'].shape[1] != n_mb * mb:
@@ -368,24 +393,25 @@ class PPOAgent:
                 F['data'][k].copy_(v)
         F['stats_acc'].zero_()
         world = parallel.world_size()
+        key_state = self._perm_state()
         with torch.cuda.device(self.device):
-            for _ in range(cfg.opt_epochs):
+            for ep in range(cfg.opt_epochs):
                 if generator is not None:       # (tests: torch's own shuffle, reproducible against the PyTorch update)
                     perm = torch.randperm(M, device=self.device, generator=generator)[:n_mb * mb].to(torch.int32).view(n_mb, mb)
-                else:                           # one launch: keyed Feistel permutation of range(M) (csrc/scg_learn.hip)
-                    perm = F['perm'][self._perm_count % 2]          # double-buffered: the previous epoch's launches may still read theirs
-                    self._perm_count += 1
-                    key = (self._perm_key + 0x9E3779B97F4A7C15 * self._perm_count) & 0xFFFFFFFFFFFFFFFF
-                    _learn.check(F['lib'], F['lib'].scg_random_permutation(perm.data_ptr(), M, n_mb * mb, key,
-                                                                           F['C'].c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+                else:
+                    # one launch: keyed Feistel permutation of range(M) (csrc/scg_learn.hip), the key derived ON THE DEVICE from
+                    # {base key, epochs drawn} + this epoch's offset.  Two index buffers, alternating by epoch (bank = ep % 2 — a
+                    # property of the launch sequence, not of a host counter: the sequence may be a captured graph).
+                    perm = F['perm'][ep % 2]
+                    _learn.check(F['lib'], F['lib'].scg_random_permutation_keyed(perm.data_ptr(), M, n_mb * mb, key_state.data_ptr(), ep,
+                                                                                 F['C'].c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
                     perm = perm.view(n_mb, mb)
                 if world > 1 or cfg.extra.get('force_data_parallel'):   # gradients of both networks + approx_kl: one collective per step
                     # (force_data_parallel: the data-parallel path on ONE rank — tests and the 1-GPU measurement of its fixed cost)
-                    bank = ((self._perm_count - 1) % 2) if generator is None else None      # (the bank `perm` was just written to)
-                    if bank is None:
+                    if generator is not None:
                         self._dp_minibatches(F, perm, n_mb, world)
                     else:
-                        self._dp_epoch(F, perm, bank, n_mb, world)
+                        self._dp_epoch(F, perm, ep % 2, n_mb, world)
                 else:
                     for j in range(n_mb):
                         F['args'].d_idx = perm[j].data_ptr()
@@ -395,12 +421,22 @@ class PPOAgent:
                             self._fused_grad(F)
                             self._fused_adam(F)
                 F['keep'] = perm                                    # (the index rows must outlive the queued launches)
+            if generator is None:                                   # the epochs drawn, on the stream (and its host mirror)
+                key_state[1:2].add_(cfg.opt_epochs)
+                self._perm_count += cfg.opt_epochs
             if self._flat.get('bank'):                              # an odd number of fused steps: the counts are in the scratch bank
                 self._flat['steps'].copy_(self._flat['steps_b'])
                 self._flat['bank'] = 0
-        st = (F['stats_acc'] / (cfg.opt_epochs * n_mb)).tolist()
+        if lazy:
+            return {'stats_dev': F['stats_acc'], 'minibatches': cfg.opt_epochs * n_mb}
+        return self.stats_of(F['stats_acc'], cfg.opt_epochs * n_mb)
+
+    @staticmethod
+    def stats_of(stats_dev, minibatches):
+        """The reference's averaged loss statistics (ppo_utils.py:140-146) from an update's device sums — the one host read."""
+        st = (stats_dev / minibatches).tolist()
         return {'policy_loss': st[0], 'value_loss': st[1], 'entropy_loss': st[2], 'approx_kl': st[3],
-                'actor_steps': int(round(st[4] * cfg.opt_epochs * n_mb)), 'minibatches': cfg.opt_epochs * n_mb}
+                'actor_steps': int(round(st[4] * minibatches)), 'minibatches': minibatches}
 
     def _build_graphs(self, data, mb):
         cfg = self.cfg
@@ -503,6 +539,7 @@ class PPOAgent:
             self.critic_opt.load_state_dict(sd['critic_opt'])
         if 'perm_state' in sd:
             self._perm_key, self._perm_count = int(sd['perm_state'][0]), int(sd['perm_state'][1])
+            self._sync_perm_state()
         if 'flat_adam' in sd and self._flat is not None:
             for k, t in sd['flat_adam'].items():
                 self._flat[k].copy_(t.to(self.device))      # in place: captured graphs alias these buffers
@@ -513,17 +550,21 @@ class PPOAgent:
             raise ValueError('checkpoint carries torch.optim state only (saved with cuda_graphs off); load it with '
                              "extra={'cuda_graphs': False} or re-save — the flat Adam moments would silently restart from zero")
 
-    def update(self, data, generator=None, perms=None):
+    def fused_update_serves(self, n_rows):
+        """Whether update() takes the MFMA learner for a rollout of n_rows samples (32-row tiles: minibatch sizes it cannot serve
+        EXACTLY take the graphed PyTorch update — same result as the reference's minibatching — instead of being rounded down)."""
+        mb0 = min(self.cfg.mini_batch_size, n_rows)
+        return bool(self.use_fused and self.ac.actor.action_modifier is None and mb0 >= 32 and mb0 % 32 == 0)
+
+    def update(self, data, generator=None, perms=None, lazy=False):
         """`data`: dict of flat [M, .] tensors (obs, act, logp, adv, ret, v).  Epochs x shuffled minibatches, drop last
         (ppo_utils.py:113-146, :358-371).  Returns the reference's averaged loss statistics.
-        perms (tests): one index permutation of range(M) per epoch instead of torch.randperm (eager path)."""
+        perms (tests): one index permutation of range(M) per epoch instead of torch.randperm (eager path).
+        lazy (fused path only): enqueue without reading anything back — see _update_fused."""
         if perms is not None:
             assert not self.use_graphs, 'explicit permutations are an eager-path (test) facility'
-        mb0 = min(self.cfg.mini_batch_size, data['obs'].shape[0])
-        # the MFMA learner works on 32-row tiles: minibatch sizes it cannot serve EXACTLY take the graphed PyTorch update
-        # (same result as the reference's minibatching) instead of being silently rounded down
-        if self.use_fused and self.ac.actor.action_modifier is None and mb0 >= 32 and mb0 % 32 == 0:
-            return self._update_fused(data, generator)
+        if self.fused_update_serves(data['obs'].shape[0]):
+            return self._update_fused(data, generator, lazy=lazy)
         if self.use_graphs:
             return self._update_graphed(data, generator)
         cfg = self.cfg
@@ -695,7 +736,7 @@ class PPO:
                                               out.data_ptr(), row_mask.data_ptr() if row_mask is not None else None, st))
 
     @torch.no_grad()
-    def _collect_fused(self):
+    def _collect_fused(self, count_steps=True):
         """One launch for the T control steps (policy inside), two batched critic passes, scg_gae."""
         cfg, T, N = self.cfg, self.T, self.N
         self.env.rollout_policy(self._policy_struct(), T, self.obs, self.act, self.logp, self.rew, self.done, self.flags,
@@ -716,7 +757,8 @@ class PPO:
         tot = self._episode_acc.sum(0)
         self.ep_count += tot[0]; self.ep_return_sum += tot[1]; self.ep_length_sum += tot[2]; self.ep_violation_sum += tot[3]
         self._episode_acc.zero_()
-        self.total_steps += T * N * parallel.world_size()
+        if count_steps:
+            self.total_steps += T * N * parallel.world_size()
         return ret, adv, moments
 
     def _build_rollout_graph(self):
@@ -737,40 +779,116 @@ class PPO:
         return g, out
 
     # ---- returns / advantages / update (ppo.py:286-303)
-    def train_step(self):
-        t0 = time.perf_counter()
-        if self._fused_rollout:
-            ret, adv, moments = self._collect_fused()
-        elif self._graph_rollout:
-            if self._rollout_graph is None or self._rollout_epoch != getattr(self.env, 'seed_epoch', 0):
-                # capture records the launches without running them (re-captured after env.seed(): the key is a kernel argument)
-                self._rollout_graph, self._rollout_out = self._build_rollout_graph()
-                self._rollout_epoch = getattr(self.env, 'seed_epoch', 0)
-            self._rollout_graph.replay()
-            self.total_steps += self.T * self.N * parallel.world_size()
-            ret, adv, moments = self._rollout_out
-            moments = moments.clone()
-        else:
-            self.collect()
-            ret, adv, moments = self._returns_body(dense=False)
+    def _normalised(self, adv, moments):
+        """Global advantage normalisation (ppo.py:300): population std, +1e-6; the moments are summed over the ranks."""
         with torch.no_grad():
-            # global advantage normalisation (ppo.py:300): population std, +1e-6
             parallel.all_reduce_sum_(moments)
             mean = moments[0] / moments[2]
             std = torch.sqrt(torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0))
-            adv = (adv - mean) / (std + 1e-6)
+            return (adv - mean) / (std + 1e-6)
+
+    def _rollout_data(self, ret, adv):
         M = self.T * self.N
-        data = {'obs': self.obs[:self.T].reshape(M, self.obs_dim), 'act': self.act.reshape(M, self.act_dim),
+        return {'obs': self.obs[:self.T].reshape(M, self.obs_dim), 'act': self.act.reshape(M, self.act_dim),
                 'logp': self.logp.reshape(M), 'adv': adv.reshape(M), 'ret': ret.reshape(M), 'v': self.v.reshape(M)}
-        if self.agent.use_graphs:               # (this stream only: an evaluation running on a side stream is not waited for)
-            torch.cuda.current_stream(self.device).synchronize()
-        t1 = time.perf_counter()
-        res = self.agent.update(data)
-        if not self._fused_rollout:             # (the fused collector re-derives obs[0] from the simulator state)
-            self.obs[0].copy_(self.obs[self.T])
+
+    def _iteration_body(self):
+        """One whole iteration as device work only — fused collection, bootstrap values, scg_gae, advantage normalisation, the
+        update's epochs (keyed permutations, gradient kernels, reduction + gated Adam) — with no host read anywhere: the sequence
+        PPO._iteration_graph captures.  Returns the update's lazy statistics."""
+        ret, adv, moments = self._collect_fused(count_steps=False)
+        return self.agent.update(self._rollout_data(ret, self._normalised(adv, moments)), lazy=True)
+
+    def _iteration_key(self):
+        """Everything an iteration's launches carry BY VALUE (kernel arguments at capture time): a change re-captures."""
+        c = self.cfg
+        return (getattr(self.env, 'seed_epoch', 0), self.T, self.N, c.opt_epochs, c.mini_batch_size, c.extra.get('minibatches_per_epoch'),
+                float(c.actor_lr), float(c.critic_lr), float(c.target_kl), float(c.clip_param), float(c.entropy_coef),
+                bool(c.use_clipped_value), float(c.gamma), float(c.gae_lambda), bool(c.use_gae), bool(self.agent._fused_step_ok))
+
+    def _iteration_graph_ok(self):
+        """One HIP-graph replay per iteration: the fused collector + the fused update on ONE rank (several ranks keep their
+        per-epoch graphs with the all-reduces inside, PPOAgent._dp_epoch).  extra['iteration_graph'] = False keeps the per-launch
+        enqueue (A/B, tests: same launches, same results bit for bit)."""
+        a = self.agent
+        return bool(self._fused_rollout and a.fused_update_serves(self.T * self.N) and parallel.world_size() == 1
+                    and not self.cfg.extra.get('force_data_parallel') and self.cfg.extra.get('iteration_graph', True))
+
+    def _run_iteration(self):
+        """The iteration body, eagerly the first time (libraries load, buffers are built, kernel attributes are set), captured the
+        second time, replayed from then on.  Host bookkeeping (step / epoch counters) follows every run."""
+        key = self._iteration_key()
+        st = getattr(self, '_iter_graph', None)
+        if st is None or st['key'] != key:
+            res = self._iteration_body()                    # (also after a key change: the eager run rebuilds what depends on it)
+            self._iter_graph = {'key': key, 'graph': None, 'res': None}
         else:
-            self._obs_row = self.T              # the CURRENT observation is the last row the collector wrote (checkpoint 'obs')
-        res.update({'step': self.total_steps, 'collect_time': t1 - t0, 'elapsed_time': time.perf_counter() - t0})
+            if st['graph'] is None:
+                count = self.agent._perm_count              # capture RECORDS the launches (nothing runs): undo its host bookkeeping
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    st['res'] = self._iteration_body()
+                self.agent._perm_count = count
+                st['graph'] = g
+            st['graph'].replay()
+            self.agent._perm_count += self.cfg.opt_epochs
+            res = dict(st['res'])
+        self.total_steps += self.T * self.N * parallel.world_size()
+        self._obs_row = self.T
+        return res
+
+    def train_step(self, lazy=False):
+        """One PPO iteration (ppo.py:259-303).  lazy=True (fused collector + fused update): the iteration is ENQUEUED and the call
+        returns without waiting for it — no synchronisation, no host read; the result carries the update's statistics as a device
+        tensor ('stats_dev', see PPOAgent.stats_of) and three HIP events ('events': start, collection done, update done) whose
+        elapsed times give the iteration's device time once they have completed.  The default reads the statistics back, as the
+        reference's train_step returns floats."""
+        t0 = time.perf_counter()
+        dev_timing = self.device.type == 'cuda'
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if dev_timing else None
+        if ev:
+            ev[0].record()
+        if self._iteration_graph_ok():
+            res = self._run_iteration()
+            ev[1] = None                                     # (one replay: no boundary between collection and update to mark)
+        else:
+            if self._fused_rollout:
+                ret, adv, moments = self._collect_fused()
+            elif self._graph_rollout:
+                if self._rollout_graph is None or self._rollout_epoch != getattr(self.env, 'seed_epoch', 0):
+                    # capture records the launches without running them (re-captured after env.seed(): the key is a kernel argument)
+                    self._rollout_graph, self._rollout_out = self._build_rollout_graph()
+                    self._rollout_epoch = getattr(self.env, 'seed_epoch', 0)
+                self._rollout_graph.replay()
+                self.total_steps += self.T * self.N * parallel.world_size()
+                ret, adv, moments = self._rollout_out
+                moments = moments.clone()
+            else:
+                self.collect()
+                ret, adv, moments = self._returns_body(dense=False)
+            data = self._rollout_data(ret, self._normalised(adv, moments))
+            if ev:
+                ev[1].record()                              # (an event, not a synchronize(): the stream keeps running into the update)
+            res = self.agent.update(data, lazy=lazy and self.agent.fused_update_serves(self.T * self.N))
+            if not self._fused_rollout:             # (the fused collector re-derives obs[0] from the simulator state)
+                self.obs[0].copy_(self.obs[self.T])
+            else:
+                self._obs_row = self.T              # the CURRENT observation is the last row the collector wrote (checkpoint 'obs')
+        if ev:
+            ev[2].record()
+        res['step'] = self.total_steps
+        if lazy and 'stats_dev' in res:
+            res['events'] = ev
+            return res
+        if 'stats_dev' in res:
+            res = dict(PPOAgent.stats_of(res['stats_dev'], res['minibatches']), step=self.total_steps)
+        if ev:
+            ev[2].synchronize()
+            res['collect_time'] = 1e-3 * ev[0].elapsed_time(ev[1]) if ev[1] is not None else None
+            res['device_time'] = 1e-3 * ev[0].elapsed_time(ev[2])
+        else:
+            res['collect_time'] = None
+        res['elapsed_time'] = time.perf_counter() - t0
         return res
 
     # ---- checkpoint / resume (ppo.py:112-148: same keys; the env's "random state" is the whole simulator workspace)

@@ -304,10 +304,14 @@ class SACAgent:
         g.div_(world)
         self._fused_step(F, _sac.FINISH)
 
-    def _update_fused(self, buffer, batch_size, n_updates):
+    def _update_fused(self, buffer, batch_size, n_updates, lazy=False):
+        """lazy=True: enqueue only — the loss sums stay on the device ('stats_dev': policy, critic, entropy loss summed over the
+        n_updates steps; valid until the next update's kernels run), nothing is read back and the call does not wait for the GPU."""
         if batch_size % 32:
             raise ValueError('the fused SAC update needs train_batch_size to be a multiple of 32')
-        key = (id(buffer), batch_size)
+        c = self.cfg                # (every value the argument block — and with it the captured graphs — carries BY VALUE: a changed cfg rebuilds)
+        key = (id(buffer), batch_size, float(c.gamma), float(c.tau), float(c.actor_lr), float(c.critic_lr), float(c.entropy_lr),
+               bool(c.use_entropy_tuning), float(c.target_entropy) if getattr(c, 'target_entropy', None) is not None else None)
         if self._fused is None or self._fused['key'] != key:
             self._fused = dict(self._fused_args(buffer, batch_size), key=key, graphs={})
         F = self._fused
@@ -327,23 +331,24 @@ class SACAgent:
                         try:
                             torch.cuda.synchronize(dev)
                             g = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(g):
+                            # (thread_local: ProcessGroupNCCL's watchdog thread must not invalidate this thread's capture)
+                            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                                 for _ in range(n_updates):
                                     self._fused_step_dp(F)
                             F['graphs'][key] = state = g
                         except Exception as exc:                    # noqa: BLE001
                             F['graphs'][key] = state = 'eager'
                             self.dp_capture_error = repr(exc)[:200]
+                            import warnings
+                            warnings.warn(f'SAC data-parallel update: HIP-graph capture failed, staying on the eager loop ({self.dp_capture_error})')
                     if isinstance(state, torch.cuda.CUDAGraph):
                         state.replay()
                         self.dp_path = f'one graph replay per vector step ({n_updates} gradient steps, {2 * n_updates} all-reduces)'
-                        st = (F['acc'] / n_updates).tolist()
-                        return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
+                        return self._fused_stats(F, n_updates, lazy)
                 self.dp_path = 'eager'
                 for _ in range(n_updates):
                     self._fused_step_dp(F)
-            st = (F['acc'] / n_updates).tolist()
-            return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
+            return self._fused_stats(F, n_updates, lazy)
         g = F['graphs'].get(n_updates)
         if g is None:                               # n_updates steps as one HIP graph (9 launches each: host-launch bound otherwise)
             with torch.cuda.device(dev):
@@ -353,6 +358,12 @@ class SACAgent:
                         self._fused_step(F)
             F['graphs'][n_updates] = g
         g.replay()
+        return self._fused_stats(F, n_updates, lazy)
+
+    @staticmethod
+    def _fused_stats(F, n_updates, lazy):
+        if lazy:
+            return {'stats_dev': F['acc'], 'stats_updates': n_updates}
         st = (F['acc'] / n_updates).tolist()
         return {'policy_loss': st[0], 'critic_loss': st[1], 'entropy_loss': st[2]}
 
@@ -522,10 +533,11 @@ class SACAgent:
         return {'policy_loss': policy_loss.detach(), 'critic_loss': critic_loss.detach(), 'entropy_loss': entropy_loss.detach()}
 
 
-    def update_from_buffer(self, buffer, batch_size, n_updates):
-        """n_updates gradient steps on fresh uniform samples; replays one captured graph per step when enabled."""
+    def update_from_buffer(self, buffer, batch_size, n_updates, lazy=False):
+        """n_updates gradient steps on fresh uniform samples; replays one captured graph per step when enabled.
+        lazy (fused path): see _update_fused."""
         if self.use_fused:
-            return self._update_fused(buffer, batch_size, n_updates)
+            return self._update_fused(buffer, batch_size, n_updates, lazy=lazy)
         if not self.use_graphs:
             acc = None
             for _ in range(n_updates):
@@ -644,7 +656,9 @@ class SAC:
             st['g'] = g
         st['g'].replay()
 
-    def train_step(self):
+    def train_step(self, lazy=False):
+        """One vectorised env step (+ the gradient steps it owes).  lazy=True: the fused update's statistics are not read back
+        ('stats_dev' instead of floats) — with the graph-replayed collector the call then never waits for the GPU."""
         cfg = self.cfg
         t0 = time.perf_counter()
         self._collect(self.total_steps < cfg.warm_up_steps)
@@ -658,7 +672,7 @@ class SAC:
             # vectorised step that is N updates per step — `updates_per_step` caps it (documented deviation knob)
             n_updates = int(cfg.extra.get('updates_per_step', self._since_update))
             self._since_update = 0
-            results = self.agent.update_from_buffer(self.buffer, cfg.train_batch_size, n_updates)
+            results = self.agent.update_from_buffer(self.buffer, cfg.train_batch_size, n_updates, lazy=lazy)
             results['updates'] = n_updates
         results.update({'step': self.total_steps, 'elapsed_time': time.perf_counter() - t0})
         return results

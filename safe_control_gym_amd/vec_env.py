@@ -150,7 +150,7 @@ class LazyInfoList(Sequence):
             h.update(fin_return=fin[:, 0], fin_length=fin[:, 1], fin_violation=fin[:, 2], fin_mse=fin[:, 3])
             h['c_values'] = o.c_values.t().cpu().numpy() if o.c_values is not None else None
             if not self._is_reset:      # ctrl_step_counter of the running episodes (benchmark_env.py:466); a reset's is 0 by definition
-                h['step'] = self._step_snapshot if self._step_snapshot is not None else self._venv.get_counters()[0]
+                h['step'] = self._step_snapshot if self._step_snapshot is not None else self._venv.get_step_counters()
             self._host = h
         return self._host
 
@@ -445,7 +445,7 @@ class HipVecEnv(VecEnv):
         out = self.step_tensors(self._actions, self._adv)
         self._adv = None
         if self.return_numpy:
-            info = {'n': LazyInfoList(self, out, is_reset=False, step_snapshot=self.get_counters()[0])}
+            info = {'n': LazyInfoList(self, out, is_reset=False, step_snapshot=self.get_step_counters())}
             return (out.obs.cpu().numpy().astype(np.float64), out.reward.cpu().numpy().astype(np.float64),
                     out.done.cpu().numpy().astype(bool), info)
         info = {'n': LazyInfoList(self, out, is_reset=False)}
@@ -489,6 +489,13 @@ class HipVecEnv(VecEnv):
         params = np.asarray(params, dtype=np.float64)
         self._host_io(self._lib.scg_set_params, len(self.spec.param_labels), first, params.shape[0], params)
 
+    def get_step_counters(self):
+        """ctrl_step_counter of every env (the one array: what step_wait snapshots for info['n'][i]['current_step'])."""
+        step = np.empty(self.num_envs, dtype=np.int32)
+        with torch.cuda.device(self.device):
+            self._chk(self._lib.scg_get_counters(self._h, step.ctypes.data_as(C.POINTER(C.c_int32)), None, 0, self.num_envs, self._stream()))
+        return step
+
     def get_counters(self):
         step = np.zeros(self.num_envs, dtype=np.int32)
         ep = np.zeros(self.num_envs, dtype=np.uint32)
@@ -497,13 +504,16 @@ class HipVecEnv(VecEnv):
                                                ep.ctypes.data_as(C.POINTER(C.c_uint32)), 0, self.num_envs, self._stream()))
         return step, ep
 
-    def set_step_launch(self, split_max=None, wide_min=None):
-        """Tuning knobs of the specialised libraries (scg_set_step_launch): which launch geometry scg_step uses by shard size —
-        `split_max`: two independent waves per 64 envs (each produces half of the outputs) up to this many envs; `wide_min`:
-        256-thread workgroups from this many.  None keeps a threshold; (0, 2**31 - 1) = the plain one-wave-per-64-envs launch always.
-        Results are identical either way."""
+    def set_step_launch(self, split_max=None, wide_min=None, wsback=None):
+        """Tuning knobs of the specialised libraries (scg_set_step_launch / scg_set_step_wsback): which launch geometry scg_step uses
+        by shard size — `split_max`: two waves per 64 envs (each produces half of the outputs) up to this many envs; `wide_min`:
+        256-thread workgroups from this many; `wsback` = (min, max): the range of shard sizes whose workspace arrays are stored
+        write-back (Quadrotor systems), (1, 0) = never.  None keeps a threshold; (0, 2**31 - 1, (1, 0)) = the plain
+        one-wave-per-64-envs launch always.  Results are identical either way."""
         f = lambda v: -1 if v is None else int(v)       # noqa: E731
         self._chk(self._lib.scg_set_step_launch(self._h, f(split_max), f(wide_min)))
+        if wsback is not None:
+            self._chk(self._lib.scg_set_step_wsback(self._h, int(wsback[0]), int(wsback[1])))
 
     def set_counters(self, step=None, episode=None):
         sp = None if step is None else np.ascontiguousarray(step, dtype=np.int32)
@@ -549,7 +559,8 @@ class HipVecEnv(VecEnv):
     def get_env_random_state(self):
         step, ep = self.get_counters()
         return [{'seed': self.seed_value, 'env_id_offset': self.env_id_offset, 'step': step, 'episode': ep,
-                 'workspace': self._ws_view().cpu(), 'ep_stats': self.ep_stats.cpu()}]
+                 'workspace': self._ws_view().cpu(), 'ep_stats': self.ep_stats.cpu(),
+                 'rng_layout_version': int(self._lib.scg_rng_layout_version())}]      # (include/scg_hip.h: SCG_RNG_LAYOUT_VERSION)
 
     def _ws_view(self):
         """The bytes the kernels really use: [_ws_ptr, _ws_ptr + scg_workspace_bytes) — NOT the padded allocation, whose
@@ -561,6 +572,11 @@ class HipVecEnv(VecEnv):
         st = worker_random_states[0]
         if st['seed'] != self.seed_value or st['env_id_offset'] != self.env_id_offset:
             raise ValueError('random state belongs to a different seed / env shard')
+        have, want = st.get('rng_layout_version', 1), int(self._lib.scg_rng_layout_version())
+        if have != want:                # (checkpoints written before round 6 carry no version: rounds 1-4 used layout 1)
+            import warnings
+            warnings.warn(f'env random state was saved under Philox word layout {have}, this build draws with layout {want} '
+                          f'(include/scg_hip.h: SCG_RNG_LAYOUT_VERSION): the resumed run will not reproduce the original one\'s resets')
         ws = st['workspace'].to(self.device)
         if ws.numel() != self._ws_bytes:
             if ws.numel() == self.workspace.numel():            # checkpoint of an older build: whole padded allocation

@@ -220,6 +220,47 @@ def test_ppo_checkpoint_resume_in_fused_mode(tmp_path):
         e.close()
 
 
+def test_ppo_iteration_graph_equals_per_launch_enqueue_and_never_waits():
+    """One HIP-graph replay per iteration (PPO._run_iteration: fused collection, GAE, normalisation, the update's keyed permutations and
+    optimiser steps — device-keyed, nothing about an iteration is baked into the graph) gives bit for bit what the same launches
+    enqueued one by one give, iteration after iteration; train_step(lazy=True) returns device statistics + events and reads nothing back."""
+    from safe_control_gym_amd.ppo import PPO, PPOAgent, PPOConfig
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, tc = load_task('quadrotor_2D_track')
+
+    def make(graph):
+        env = HipVecEnv(env_id, 2048, seed=8, return_numpy=False, policy=(128, 'tanh'), **tc)
+        cfg = PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, opt_epochs=3, mini_batch_size=4096, rollout_steps=16,
+                        actor_lr=1e-3, critic_lr=1e-3, target_kl=0.03, extra={'minibatches_per_epoch': 3, 'iteration_graph': graph})
+        return env, PPO(env, cfg, seed=8)
+
+    env_a, a = make(True)
+    env_b, b = make(False)
+    assert a._iteration_graph_ok() and not b._iteration_graph_ok()
+    flat = lambda p: torch.cat([q.detach().reshape(-1) for q in p.agent.ac.parameters()])      # noqa: E731
+    for it in range(6):
+        ra, rb = a.train_step(lazy=True), b.train_step(lazy=True)
+        assert 'stats_dev' in ra and 'policy_loss' not in ra and len(ra['events']) == 3
+        sa, sb = PPOAgent.stats_of(ra['stats_dev'], ra['minibatches']), PPOAgent.stats_of(rb['stats_dev'], rb['minibatches'])
+        assert sa == sb, (it, sa, sb)
+        assert torch.equal(flat(a), flat(b)), it
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.agent._flat['steps'], b.agent._flat['steps'])
+        assert a.agent._perm_count == b.agent._perm_count == 3 * (it + 1)
+        assert a.total_steps == b.total_steps == (it + 1) * 16 * 2048
+    assert a._iter_graph['graph'] is not None                # iterations 2.. were replays
+    assert int(a.agent._perm_dev[1]) == a.agent._perm_count     # the device mirror of the epochs drawn
+    # the default (non-lazy) call returns the reference's float statistics from the same replay
+    ra, rb = a.train_step(), b.train_step()
+    assert ra['policy_loss'] == rb['policy_loss'] and ra['approx_kl'] == rb['approx_kl'] and ra['device_time'] > 0
+    # a changed hyper-parameter is not silently ignored by the captured graph: it re-captures
+    a.cfg.actor_lr = b.cfg.actor_lr = 5e-4
+    for _ in range(3):
+        a.train_step(lazy=True); b.train_step(lazy=True)
+    assert torch.equal(flat(a), flat(b))
+    env_a.close(); env_b.close()
+
+
 def test_ppo_with_running_normalisers_graphed_and_eager():
     """norm_obs / norm_reward (ppo.yaml keys): the running statistics live on the device and update inside the captured
     rollout graph; same bookkeeping as the eager path."""
