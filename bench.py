@@ -49,7 +49,6 @@ TRAFFIC_FILE = 'r05_hbm_traffic.json'
 SEQ_K, SEQ_K_ALL = 32, 8        # control steps per launch of the two scg_step_sequence workloads (sequence_leg, tools/seq_profile.py)
 SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
 # scg_kernels.hip defaults (scg_set_step_launch): which launch geometry of the step kernel a shard of N envs takes
-LAUNCH_SPLIT_MAX = int(os.environ.get('SCG_SPLIT_MAX_ENVS', 32768))
 LAUNCH_WIDE_MIN = int(os.environ.get('SCG_WIDE_MIN_ENVS', 8388608))
 LAUNCH_WSBACK = (int(os.environ.get('SCG_WSBACK_MIN_ENVS', 131072)), int(os.environ.get('SCG_WSBACK_MAX_ENVS', 524288)))
 
@@ -57,8 +56,6 @@ LAUNCH_WSBACK = (int(os.environ.get('SCG_WSBACK_MIN_ENVS', 131072)), int(os.envi
 def launch_geometry(n, specialised, task='quadrotor_2D_track'):
     if not specialised:
         return 'step_kernel (generic library: 256-thread workgroups, parameters staged in LDS)'
-    if n <= LAUNCH_SPLIT_MAX:
-        return 'step_split_kernel (the two waves of a 128-thread workgroup per 64 envs, each half of the outputs, one barrier)'
     if LAUNCH_WSBACK[0] <= n <= LAUNCH_WSBACK[1] and n < LAUNCH_WIDE_MIN and not task.startswith('cartpole'):
         return 'step_wsback_kernel (one wave per 64 envs, workspace arrays stored write-back)'
     if n >= LAUNCH_WIDE_MIN:

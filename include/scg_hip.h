@@ -316,15 +316,14 @@ int scg_set_params(scg_env* env, const double* h_params, int first_env, int n, v
 int scg_get_params(scg_env* env, double* h_params, int first_env, int n, void* stream);
 /* Tuning knobs (no reference counterpart; results are identical bit for bit whichever launch runs).  Config-specialised libraries pick
  * the geometry of scg_step's launch by the size of the shard:
- *   <= split_max_envs   two independent waves per 64 envs, each the whole control step for half of the outputs (shards that leave
- *                       SIMDs empty: up to half a wave per SIMD; default 32 768 or env SCG_SPLIT_MAX_ENVS);
  *   >= wide_min_envs    256-thread workgroups (the largest shards; default 8 388 608 or env SCG_WIDE_MIN_ENVS);
  *   wsback_min_envs .. wsback_max_envs (Quadrotor systems; default 131 072 .. 524 288 or env SCG_WSBACK_MIN_ENVS / SCG_WSBACK_MAX_ENVS,
  *                       scg_set_step_wsback): one-wave workgroups with the handle's WORKSPACE arrays stored write-back — the next
- *                       launch's wave of the same env group reads them from the same XCD's L2 (-4 .. -9 % per launch there);
+ *                       launch's wave of the same env group reads them from the same XCD's L2 (-3 .. -9 % per launch there);
  *   otherwise, and the generic library always: one wave per 64 envs in one-wave workgroups.
- * A negative argument leaves that threshold unchanged; 0 switches the split launch off, INT_MAX the wide one;
- * scg_set_step_wsback(env, 1, 0) (an empty range) switches the write-back launch off. */
+ * A negative argument leaves a threshold unchanged; INT_MAX switches the wide launch off; scg_set_step_wsback(env, 1, 0) (an empty
+ * range) the write-back launch.  split_max_envs is accepted and IGNORED: the two-waves-per-64-envs launch of rounds 5-6 was removed
+ * (correctly ordered it is slower than the one-wave launch: csrc/scg_env_kernels.h). */
 int scg_set_step_launch(scg_env* env, int split_max_envs, int wide_min_envs);
 int scg_set_step_wsback(scg_env* env, int wsback_min_envs, int wsback_max_envs);
 /* Version of the Philox WORD LAYOUT of the reset draws (which bits of which block feed which initial-state / parameter / offset

@@ -1,7 +1,7 @@
 /* scg_sac.h — C ABI of libscg_sac_<obs>_<hidden>_<act_dim>_<activation>.so: ONE gradient step of the reference's
  * SACAgent.update (/root/reference/safe_control_gym/controllers/sac/sac_utils.py:110-170) on MI355X, fused.
  *
- * What one scg_sac_update call enqueues (8 kernels, no host synchronisation, exact float32, matrix products on
+ * What one scg_sac_update call enqueues (8 kernels; no host synchronisation, exact float32, matrix products on
  * v_mfma_f32_32x32x2_f32, every reduction in a fixed order: the step is bitwise reproducible):
  *   sample     batch rows ~ U[0, *d_ring_size) of the device replay ring (SACBuffer.sample, sac_utils.py:399-413)
  *   actor fwd  a, log pi = actor(obs) with the reparameterised tanh-Gaussian (sac_utils.py:185-222; log-prob correction
@@ -88,6 +88,29 @@ int scg_sac_update(const scg_sac_args* args, void* stream);
  * d_act_out[m][act_dim] = low + 0.5 (tanh(mu(obs)) + 1)(high - low).  Evaluation / acting without PyTorch kernels. */
 int scg_sac_act(const float* d_params, const scg_mlp_layout* actor, const float* act_low, const float* act_high, const float* d_obs,
                 int m, float* d_act_out, void* stream);
+
+/* ---- the collector's two device-side pieces (SAC.train_step, /root/reference/safe_control_gym/controllers/sac/sac.py:273-311)
+ * A SAMPLED action per observation (MLPActorCritic.act(obs), sac_utils.py:258-262 with deterministic = False):
+ * a = low + 0.5 (tanh(mu + exp(clamp(log_std, -20, 2)) eps) + 1)(high - low), eps ~ N(0, 1) from Philox4x32-10 keyed by `seed` with
+ * counter = (*d_counter, row, stream 3) — or the caller's d_eps_in [m][act_dim] (tests).  uniform != 0: the warm-up's
+ * action_space.sample(), a ~ U[low, high) per dimension (sac.py:276-277; d_params / actor / d_obs unused).  One launch. */
+int scg_sac_sample(const float* d_params, const scg_mlp_layout* actor, const float* act_low, const float* act_high, const float* d_obs,
+                   int m, uint64_t seed, const uint32_t* d_counter, int uniform, const float* d_eps_in, float* d_act_out, void* stream);
+/* One vectorised env step into the replay ring (SACBuffer.push, sac_utils.py:340-370, with sac.py:287-305's time-limit fix-up): rows
+ * pos .. pos + n - 1 (mod capacity) <- (d_cur_obs, d_act, d_reward, next observation = d_terminal_obs where the episode was
+ * TRUNCATED by the time limit (done and flags bit 0) else d_next_obs, mask = 1 where truncated else 1 - done); d_cur_obs <- d_next_obs
+ * (the persistent current-observation batch of the collector); then *d_pos, *d_size_f, *d_size_i32 advance (every one a device
+ * scalar: the whole step is capturable in a HIP graph) and *d_counter (the sample noise's counter word, nullable) is incremented. */
+typedef struct {
+    float* d_obs; float* d_act; float* d_rew; float* d_next_obs; float* d_mask;     /* ring arrays of `capacity` rows */
+    int32_t capacity;
+    int64_t* d_pos;                 /* write position */
+    float* d_size_f;                /* rows valid, as float (nullable) */
+    int32_t* d_size_i32;            /* rows valid (nullable; what scg_sac_args.d_ring_size reads) */
+    uint32_t* d_counter;            /* nullable */
+} scg_sac_ring;
+int scg_sac_push(const scg_sac_ring* ring, float* d_cur_obs, const float* d_act, const float* d_reward, const float* d_next_obs,
+                 const float* d_terminal_obs, const uint8_t* d_done, const uint8_t* d_flags, int n, void* stream);
 
 const char* scg_sac_last_error(void);
 const char* scg_sac_source_hash_tag(void);

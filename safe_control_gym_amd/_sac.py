@@ -25,6 +25,11 @@ class SacArgs(C.Structure):
                 ('d_workspace', C.c_void_p), ('d_stats', C.c_void_p), ('d_stats_acc', C.c_void_p), ('phases', C.c_int32)]
 
 
+class SacRing(C.Structure):
+    _fields_ = [('d_obs', C.c_void_p), ('d_act', C.c_void_p), ('d_rew', C.c_void_p), ('d_next_obs', C.c_void_p), ('d_mask', C.c_void_p),
+                ('capacity', C.c_int32), ('d_pos', C.c_void_p), ('d_size_f', C.c_void_p), ('d_size_i32', C.c_void_p), ('d_counter', C.c_void_p)]
+
+
 ACTOR_GRAD, CRITIC_GRAD, FINISH, ALL = 1, 2, 4, 7
 
 
@@ -81,6 +86,9 @@ def lib(obs_dim, hidden, act_dim, activation):
     D.scg_sac_update.argtypes = [C.POINTER(SacArgs), C.c_void_p]
     D.scg_sac_act.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p,
                               C.c_void_p]
+    D.scg_sac_sample.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_uint64,
+                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    D.scg_sac_push.argtypes = [C.POINTER(SacRing), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     shape = [C.c_int32() for _ in range(4)]
     D.scg_sac_shape(*[C.byref(v) for v in shape])
     if tuple(v.value for v in shape) != (obs_dim, hidden, act_dim, ACTS[activation]):

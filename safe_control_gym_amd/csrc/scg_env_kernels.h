@@ -242,36 +242,19 @@ __device__ __forceinline__ void fence_kernargs(const InstParams<T>& I, const T* 
     fence_out<T>(O);
 }
 
-// Output ownership of a step wave.  ROLE_ALL: one wave produces every output of its 64 envs (the kernel of every round so far).
-// Split launch (step_split_kernel, shards of <= SCG_SPLIT_MAX_ENVS envs — the one-wave-per-SIMD regime, where the launch is ONE
-// serial instruction chain per wave and half the SIMD's issue slots are idle): TWO waves per 64 envs.  Both load the state and
-// the action and integrate the control step — the same instruction sequence on the same inputs, bit-identical results — and each
-// then produces its own half of the outputs:
-//   ROLE_SCORE  reward, done, flags, mse, noisy action, the constraint rows, the episode statistics (read-modify-write);
-//   ROLE_STATE  observation, terminal observation, auto-reset (Philox draws), env.state, the workspace state and counters.
-// The serial tail behind the integrator (51 % of the wave's lifetime at 65 536 envs, profiles/r04_timeline_*) is cut in two and the
-// halves run side by side; the price is the second read of state + action (+40 B per env-step).
-// ORDERING (round 6; the round-5 launch had the two roles in independent workgroups and relied on dispatch order): ROLE_STATE
-// overwrites what ROLE_SCORE reads — the workspace state, counters, per-env parameters and disturbance offsets (Ops::reset /
-// Ops::store).  The two waves of a group are therefore the two waves of ONE 128-thread workgroup (wave 0 SCORE, wave 1 STATE) and
-// meet at one hardware barrier: SCORE arrives at its end — every value it loaded has been consumed by then, i.e. its reads are done
-// — and STATE waits there before its first workspace store (pair_barrier below).  No store of STATE can precede a load of SCORE.
-enum : int { ROLE_ALL = 0, ROLE_SCORE = 1, ROLE_STATE = 2 };
-
-// One s_barrier without the s_waitcnt a __syncthreads() carries: the SCORE wave's outstanding STORES (other arrays) need not land
-// before the STATE wave may write the workspace; the "memory" clobber keeps the compiler from moving memory operations across it.
-__device__ __forceinline__ void pair_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
+// (Rounds 5-6 carried a SPLIT launch here — two waves per 64 envs, one producing reward / done / constraint rows / statistics, the other
+//  observation / auto-reset / state.  As independent workgroups it won 5-7.5 % on shards <= 32 768 envs but relied on dispatch order:
+//  the state wave overwrites the workspace the score wave reads.  Ordered properly — the two waves in one workgroup behind one
+//  s_barrier — it LOSES: 3.37 vs 3.22 us at 16 384 envs, 3.80 vs 3.40 us at 32 768 (profiles/r06_split_wsback_ab.txt).  Removed.)
 // BLK: threads per workgroup of the kernel that inlines this body (BLOCK, or WIDE_BLOCK for step_wide_kernel).
 // WSWB: the workspace arrays are stored write-back (EnvOps' WSAUX = 0) instead of write-through — step_wsback_kernel.
-template <int SYS, typename T, bool DIST, bool ONE, int ROLE, int BLK = BLOCK, bool WSWB = false>
+template <int SYS, typename T, bool DIST, bool ONE, int BLK = BLOCK, bool WSWB = false>
 __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, const InstParams<T>& I,
                                           const T* __restrict__ action, const T* __restrict__ adv,
                                           const typename OutTabOf<ONE>::type& O, const int wg) {
     using Ops = EnvOps<SYS, T, DIST, SCG_ST_AUX, WSWB ? 0 : SCG_ST_AUX>;
     using D = Dims<SYS>;
-    constexpr bool SCORE = ROLE != ROLE_STATE, STATE = ROLE != ROLE_SCORE;
-    const int tid = ROLE == ROLE_ALL ? (int)threadIdx.x : ((int)threadIdx.x & 63);   // (split launch: lane of either wave of the pair)
+    const int tid = (int)threadIdx.x;
     const int i = I.env_first + wg * BLK + tid;
     const int N = I.num_envs;
     const bool live = i < I.env_end;
@@ -310,7 +293,7 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         for (int j = 0; j < D::NU; ++j) act[j] = action[(size_t)i * D::NU + j];     // caller's tensor: plain global load
         // unconditional load (an unbound accumulator reads a valid dummy address): a branch would split the
         // requests over two dependent rounds
-        if constexpr (SCORE) (Q.ep_stats ? Q.ep_stats : slot_in<T>(make_rsrc(I.ws), I.state_off, 0, 4)).template load_row<4>(ep);
+        (Q.ep_stats ? Q.ep_stats : slot_in<T>(make_rsrc(I.ws), I.state_off, 0, 4)).template load_row<4>(ep);
     }
 #ifndef SCG_SPEC
     const CfgParams<T>* cl;
@@ -329,8 +312,8 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
     SCG_TL(2);
     // ---- memory round 3 (overlapped with the integrator): reference rows of X_GOAL for this step
     const bool pre_rows = P.c.task == SCG_TASK_TRAJ_TRACKING;
-    const bool pre_ref = pre_rows && SCORE;             // the reference row feeds reward / mse only when tracking (ROLE_STATE: unused)
-    const bool pre_ext = pre_rows && STATE && P.c.cost == SCG_COST_RL_REWARD && P.c.obs_goal_horizon == 1;
+    const bool pre_ref = pre_rows;                      // the reference row feeds reward / mse only when tracking
+    const bool pre_ext = pre_rows && P.c.cost == SCG_COST_RL_REWARD && P.c.obs_goal_horizon == 1;
     T ref_pre[D::NX], ext_pre[D::NX], ext_reset[D::NX];
     if (pre_rows) {
         const int last = P.c.goal_rows - 1;
@@ -364,11 +347,9 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         }
     }
     T st[D::NX], noisy[D::NU];
-    if constexpr (!SCORE) Q.c_values.soff = SCG_NO_OFF;                 // (the rows are evaluated for `done`, stored by ROLE_SCORE)
     typename Ops::StepResult r = Ops::step(P, goal, e, act, advp, key, i, st, noisy, Q.c_values, (size_t)N,
                                            pre_ref ? ref_pre : nullptr, pre_ext ? ext_pre : nullptr,
                                            pre_ext ? ext_reset : nullptr);
-    if constexpr (SCORE) {
     Q.reward.store(r.reward);           // obs / reward / done / flags are always bound (checked by scg_step)
     Q.done.store(r.done ? 1 : 0);
     Q.flags.store(r.flags);
@@ -377,9 +358,8 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
 #pragma unroll
         for (int j = 0; j < D::NU; ++j) Q.noisy_action.store(noisy[j], (size_t)j * N);
     }
-    }
     // columnar VecRecordEpisodeStatistics (record_episode_statistics.py:139-166)
-    if (SCORE && Q.ep_stats) {
+    if (Q.ep_stats) {
         ep[0] += r.reward;
         ep[1] += (T)1;
         ep[2] += (r.flags & FLAG_VIOLATION) ? (T)1 : (T)0;
@@ -388,7 +368,6 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         const T nxt[4] = {r.done ? (T)0 : ep[0], r.done ? (T)0 : ep[1], r.done ? (T)0 : ep[2], r.done ? (T)0 : ep[3]};
         Q.ep_stats.template store_row<4>(nxt);
     }
-    if constexpr (!STATE) { SCG_TL(6); SCG_TL(7); pair_barrier(); return; }       // (every load of this wave has been consumed)
     // observation of the step: goes to terminal_observation where the env is about to auto-reset, else it is the
     // returned obs (two write_obs call sites only: the disturbance code is inlined into each)
 #ifdef SCG_EXP_NO_RESET
@@ -403,7 +382,6 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         int nrow = Ops::obs_row(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, pre_ext ? ext_pre : nullptr, row);
         if (r.done && Q.terminal_obs) Ops::store_obs_row(P, row, nrow, Q.terminal_obs);   // (also the non-auto-reset case)
         SCG_TL(6);
-        if constexpr (ROLE == ROLE_STATE) pair_barrier();      // the SCORE wave's reads precede the workspace stores below
         if (do_reset) {
             Ops::reset(P, i, e, key, st);           // auto-reset (dummy_vec_env.py:33-38)
             nrow = Ops::obs_row(P, goal, st, e, key, 1, 0u, 0, i, pre_ext ? ext_reset : nullptr, row);
@@ -427,7 +405,6 @@ __device__ __forceinline__ void step_body(const CfgParams<T>* __restrict__ Cg, c
         if (r.done && Q.terminal_obs)
             Ops::write_obs(P, goal, st, e, key, c0 + 2, (uint32_t)(c0 + 1), c0, i, Q.terminal_obs, nullptr);
         SCG_TL(6);
-        if constexpr (ROLE == ROLE_STATE) pair_barrier();
         if (do_reset) {
             Ops::reset(P, i, e, key, st);
             Ops::write_obs(P, goal, st, e, key, 1, 0u, 0, i, Q.obs, nullptr);
@@ -445,7 +422,7 @@ template <int SYS, typename T, bool DIST, bool ONE>
 __global__ __launch_bounds__(BLOCK) void step_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                      const T* __restrict__ action, const T* __restrict__ adv,
                                                      const typename OutTabOf<ONE>::type O) {
-    step_body<SYS, T, DIST, ONE, ROLE_ALL>(Cg, I, action, adv, O, (int)blockIdx.x);
+    step_body<SYS, T, DIST, ONE>(Cg, I, action, adv, O, (int)blockIdx.x);
 }
 
 #ifdef SCG_SPEC
@@ -458,7 +435,7 @@ template <int SYS, typename T, bool DIST, bool ONE>
 __global__ __launch_bounds__(WIDE_BLOCK) void step_wide_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                                const T* __restrict__ action, const T* __restrict__ adv,
                                                                const typename OutTabOf<ONE>::type O) {
-    step_body<SYS, T, DIST, ONE, ROLE_ALL, WIDE_BLOCK>(Cg, I, action, adv, O, (int)blockIdx.x);
+    step_body<SYS, T, DIST, ONE, WIDE_BLOCK>(Cg, I, action, adv, O, (int)blockIdx.x);
 }
 
 // Mid-size shards (SCG_WSBACK_MIN_ENVS <= envs <= SCG_WSBACK_MAX_ENVS, Quadrotor systems): the same one-wave workgroups with the
@@ -467,21 +444,9 @@ template <int SYS, typename T, bool DIST, bool ONE>
 __global__ __launch_bounds__(BLOCK) void step_wsback_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
                                                             const T* __restrict__ action, const T* __restrict__ adv,
                                                             const typename OutTabOf<ONE>::type O) {
-    step_body<SYS, T, DIST, ONE, ROLE_ALL, BLOCK, true>(Cg, I, action, adv, O, (int)blockIdx.x);
+    step_body<SYS, T, DIST, ONE, BLOCK, true>(Cg, I, action, adv, O, (int)blockIdx.x);
 }
 
-// Split launch: one 128-thread workgroup per 64 envs — wave 0 in ROLE_SCORE, wave 1 in ROLE_STATE (same CU: the second read of the
-// group's state and action hits that CU's vector cache), ordered by pair_barrier (see the ROLE comment above).  A tail group's dead
-// lanes return in both waves alike; a wave with any live lane reaches its barrier.
-constexpr int SPLIT_BLOCK = 128;
-template <int SYS, typename T, bool DIST, bool ONE>
-__global__ __launch_bounds__(SPLIT_BLOCK) void step_split_kernel(const CfgParams<T>* __restrict__ Cg, const InstParams<T> I,
-                                                               const T* __restrict__ action, const T* __restrict__ adv,
-                                                               const typename OutTabOf<ONE>::type O) {
-    const int wg = (int)blockIdx.x;
-    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) step_body<SYS, T, DIST, ONE, ROLE_STATE, 64>(Cg, I, action, adv, O, wg);
-    else step_body<SYS, T, DIST, ONE, ROLE_SCORE, 64>(Cg, I, action, adv, O, wg);
-}
 #endif
 
 // Output slots of the K-steps-per-launch kernels: write-back stores (SCG_SEQ_ST_AUX, see Slot in scg_env_core.h).

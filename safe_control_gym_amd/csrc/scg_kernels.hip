@@ -72,21 +72,18 @@ struct scg_env {
     uint8_t* d_oob;
     bool has_reset;
     bool has_dist;
-    // step-launch geometry of the specialised builds by shard size (scg_set_step_launch): <= split_max: two waves per 64 envs, each
-    // the whole step for half of the outputs; >= wide_min: 256-thread workgroups
-    int split_max, wide_min, wsback_min, wsback_max;
+    // step-launch geometry of the specialised builds by shard size (scg_set_step_launch / scg_set_step_wsback): >= wide_min: 256-thread
+    // workgroups; wsback_min .. wsback_max: workspace arrays written back
+    int wide_min, wsback_min, wsback_max;
 };
 
-// Step-launch geometry by shard size, measured on MI355X (profiles/r05_step_kernel_ab.md); the environment variables of the same names
+// Step-launch geometry by shard size, measured on MI355X (profiles/r05_step_kernel_ab.md, profiles/r06_split_wsback_ab.txt); the environment variables of the same names
 // override the built-in thresholds at scg_create, scg_set_step_launch per handle.
 #ifndef SCG_WSBACK_MIN_ENVS
 #define SCG_WSBACK_MIN_ENVS 131072      // Quadrotor shards of 131 072 .. 524 288 envs: workspace arrays written back (step_wsback_kernel)
 #endif
 #ifndef SCG_WSBACK_MAX_ENVS
 #define SCG_WSBACK_MAX_ENVS 524288
-#endif
-#ifndef SCG_SPLIT_MAX_ENVS
-#define SCG_SPLIT_MAX_ENVS 32768          // <= half a wave per SIMD: two independent waves per 64 envs (step_split_kernel)
 #endif
 #ifndef SCG_WIDE_MIN_ENVS
 #define SCG_WIDE_MIN_ENVS 8388608         // the largest shards: 256-thread workgroups (step_wide_kernel)
@@ -573,7 +570,6 @@ extern "C" int scg_create(const scg_config* cfg, const double* h_x_goal, int dev
     e->d_state = w + L.state; e->d_param = w + L.param; e->d_step = (int32_t*)(w + L.step);
     e->d_episode = (uint32_t*)(w + L.episode); e->d_dist_offset = (int32_t*)(w + L.offsets); e->d_oob = w + L.oob;
     e->d_params = nullptr; e->d_goal = nullptr; e->d_cfg = nullptr; e->has_reset = false;
-    e->split_max = launch_default("SCG_SPLIT_MAX_ENVS", SCG_SPLIT_MAX_ENVS);
     e->wsback_min = launch_default("SCG_WSBACK_MIN_ENVS", SCG_WSBACK_MIN_ENVS);
     e->wsback_max = launch_default("SCG_WSBACK_MAX_ENVS", SCG_WSBACK_MAX_ENVS);
     e->wide_min = launch_default("SCG_WIDE_MIN_ENVS", SCG_WIDE_MIN_ENVS);
@@ -678,19 +674,6 @@ static int launch_step(scg_env* env, int first, int count, const void* action, c
     InstParams<T> I = inst_of<T>(env);
     I.env_first = first; I.env_end = first + count;
 #ifdef SCG_SPEC
-    // Shards that leave SIMD wave slots empty (<= SCG_SPLIT_MAX_ENVS envs; 65 536 envs = one wave per SIMD) take the split launch:
-    // two waves per 64 envs, each producing half of the outputs (step_split_kernel, scg_env_kernels.h).  Larger shards are
-    // bandwidth-bound and keep one wave per 64 envs.  Same results bit for bit (tests/test_gpu_env_parity.py).
-    if (count <= env->split_max) {
-        const int grid = (count + 63) / 64;
-        if (one_base) {
-            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, true><<<dim3(grid), dim3(SPLIT_BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O1)));
-        } else {
-            DISPATCH_SYS(env, T, (step_split_kernel<S, T, DD, false><<<dim3(grid), dim3(SPLIT_BLOCK), env->lds_bytes, st>>>(C, I, (const T*)action, (const T*)adv, O)));
-        }
-        HIP_TRY(hipGetLastError());
-        return SCG_OK;
-    }
     if constexpr (SCG_SPEC_SYS != SCG_CARTPOLE) {        // (CartPole's 50-substep chain gains nothing from it: 13.3 -> 13.9 us at 262 144 envs)
         if (count >= env->wsback_min && count <= env->wsback_max && count < env->wide_min) {
             if (one_base) {
@@ -920,7 +903,7 @@ extern "C" int scg_set_step_wsback(scg_env* env, int wsback_min_envs, int wsback
 }
 extern "C" int scg_set_step_launch(scg_env* env, int split_max_envs, int wide_min_envs) {
     if (!env) return fail(SCG_ERR_INVALID, "env is NULL");
-    if (split_max_envs >= 0) env->split_max = split_max_envs;
+    (void)split_max_envs;       // (the split launch of rounds 5-6 is gone — see scg_env_kernels.h; the argument is accepted and ignored)
     if (wide_min_envs >= 0) env->wide_min = wide_min_envs;
     return SCG_OK;
 }

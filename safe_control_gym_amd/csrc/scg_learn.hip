@@ -190,6 +190,12 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     const int c = lane & 31, h = lane >> 5;
     const MlpWeights w = weights_of(A.params, ACTOR ? A.actor : A.critic);
     SCG_L_STAMP(0);
+    // The first tile's row index is requested BEFORE the weight image is filled: index -> row gather is two dependent memory round
+    // trips, and the first of them otherwise starts behind the fill's barrier (one tile per wave at the shipped minibatch size: every
+    // call paid it on its critical path).  (The rows themselves requested up here as well cost 40 more spilled registers: not kept.)
+    const int n_tiles = A.batch / 32;
+    const int tile0 = blockIdx.x * WAVES + wave;
+    const int s_pre = tile0 < n_tiles ? A.idx[tile0 * 32 + c] : 0;
     mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid);
     for (int k = tid; k < G::END; k += blockDim.x) gl[k] = 0.0f;
     if constexpr (private_dw1()) {
@@ -222,18 +228,17 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) dW2[t][r][q] = 0.0f;
 
-    const int n_tiles = A.batch / 32;
-    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+    for (int tile = tile0; tile < n_tiles; tile += gridDim.x * WAVES) {
 #ifdef SCG_L_TIMING
         unsigned long long tst[10];
 #endif
         SCG_L_TSTAMP(0);
-        const int s = A.idx[tile * 32 + c];
         float x[L1Q];
-        load_x<L1Q>(A.obs, s, h, x);
         // the per-sample scalars of the loss are requested here, a forward pass ahead of their use (asked for where they are
         // used, their round trip to memory was 2.3 us of a 37 us tile)
         float s_act[NOUT], s_a = 0.0f, s_b = 0.0f;
+        const int s = tile == tile0 ? s_pre : A.idx[tile * 32 + c];
+        load_x<L1Q>(A.obs, s, h, x);
         if constexpr (ACTOR) {
 #pragma unroll
             for (int a = 0; a < NOUT; ++a) s_act[a] = A.act[(size_t)s * NOUT + a];
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
     const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
     float s = 0.0f;
     if (k < words) {
-#pragma unroll 8
+#pragma unroll 16
         for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
     }
     part[grp][kl] = s;
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const StepArgs S) 
     }
     float s = 0.0f;
     if (k < words) {
-#pragma unroll 8
+#pragma unroll 16
         for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
     }
     part[grp][kl_] = s;

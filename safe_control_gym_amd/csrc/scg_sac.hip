@@ -173,6 +173,91 @@ __global__ __launch_bounds__(64 * WAVES, 1) void actor_act_kernel(const float* _
     }
 }
 
+// ================================================================== collector (SAC.train_step's env-facing half, sac.py:273-311)
+// A SAMPLED action of the policy for a batch of observations (MLPActorCritic.act(obs), sac_utils.py:258-262, deterministic = False):
+// a = low + 0.5 (tanh(mu + exp(clamp(log_std, -20, 2)) eps) + 1)(high - low), eps ~ N(0, 1) from Philox (counter word = *counter,
+// row, stream 3) or the caller's (tests).  One launch in place of ~12 PyTorch kernels (three GEMMs, activations, clamp, exp, randn, ...).
+__global__ __launch_bounds__(64 * WAVES, 1) void actor_sample_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
+                                                                      const float* __restrict__ obs, int m, float4 low, float4 high,
+                                                                      uint32_t k0, uint32_t k1, const uint32_t* __restrict__ counter,
+                                                                      const float* __restrict__ eps_in, float* __restrict__ a_out) {
+    using L = MlpLds<NOBS, HID, NA>;
+    extern __shared__ __align__(16) float lds[];
+    mlp_fill_lds<NOBS, HID, NA>(lds, weights_of(params, lay), threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const float lo[4] = {low.x, low.y, low.z, low.w}, hi[4] = {high.x, high.y, high.z, high.w};
+    const uint32_t cnt = counter ? *counter : 0u;
+    const int n_tiles = (m + 31) / 32;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        int s = tile * 32 + c;
+        const bool live = s < m;
+        s = live ? s : m - 1;
+        float x[L::L1Q];
+        load_x2<L::L1Q, NOBS, 0>(obs + (size_t)s * NOBS, nullptr, h, x);
+        f32x16 h1[NT], h2[NT];
+        float out[NA], eps[4];
+        mlp_forward_tile<NOBS, HID, NA, ACT, 20, MLP_ACT_NONE>(lds, x, h1, h2, out, lane);
+        if (eps_in) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)s * NU + j];
+        } else {
+            normal4(cnt, (uint32_t)s, 3u, k0, k1, eps);
+        }
+        if (live && h == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const float ls = fminf(fmaxf(out[NU + j], -20.0f), 2.0f);
+                const float u = __builtin_fmaf(expf(ls), eps[j], out[j]);
+                a_out[(size_t)s * NU + j] = lo[j] + 0.5f * (tanhf(u) + 1.0f) * (hi[j] - lo[j]);
+            }
+        }
+    }
+}
+// warm-up actions: action_space.sample() per env (sac.py:276-277), a ~ U[low, high) per dimension
+__global__ __launch_bounds__(256) void uniform_action_kernel(int m, float4 low, float4 high, uint32_t k0, uint32_t k1,
+                                                              const uint32_t* __restrict__ counter, float* __restrict__ a_out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m) return;
+    const float lo[4] = {low.x, low.y, low.z, low.w}, hi[4] = {high.x, high.y, high.z, high.w};
+    const U4 w = philox4x32_10(U4{counter ? *counter : 0u, (uint32_t)s, 4u, 0x5ac1u}, k0, k1);
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < NU; ++j) a_out[(size_t)s * NU + j] = lo[j] + (hi[j] - lo[j]) * u01<float>(ww[j]);
+}
+
+// One vectorised env step into the replay ring (SACBuffer.push with the time-limit fix-up of sac.py:287-305): row pos + i (mod capacity)
+// <- (obs the action was taken at, action, reward, next observation — the TERMINAL observation where the episode was truncated by the
+// time limit —, mask = 1 if truncated else 1 - done); the persistent current-observation batch becomes the step's observation.
+// One thread per (env, observation element).  The write position is read here by everybody and advanced by ring_advance_kernel.
+struct RingArgs {
+    float* obs; float* act; float* rew; float* next_obs; float* mask; int capacity;
+    long long* pos; float* size_f; int32_t* size_i; uint32_t* counter;
+};
+__global__ __launch_bounds__(256) void ring_push_kernel(const RingArgs R, float* __restrict__ cur_obs, const float* __restrict__ act,
+                                                         const float* __restrict__ rew, const float* __restrict__ next,
+                                                         const float* __restrict__ term, const uint8_t* __restrict__ done,
+                                                         const uint8_t* __restrict__ flags, int n) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * NOBS) return;
+    const int i = gid / NOBS, e = gid - i * NOBS;
+    const size_t slot = (size_t)((*R.pos + i) % R.capacity);
+    const bool dn = done[i] != 0, trunc = dn && (flags[i] & 1);
+    const float nv = next[gid];
+    R.obs[slot * NOBS + e] = cur_obs[gid];
+    R.next_obs[slot * NOBS + e] = trunc ? term[gid] : nv;
+    cur_obs[gid] = nv;
+    if (e < NU) R.act[slot * NU + e] = act[(size_t)i * NU + e];
+    if (e == 0) { R.rew[slot] = rew[i]; R.mask[slot] = trunc ? 1.0f : (dn ? 0.0f : 1.0f); }
+}
+__global__ void ring_advance_kernel(const RingArgs R, int n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *R.pos = (*R.pos + n) % R.capacity;
+    if (R.size_f) *R.size_f = fminf(*R.size_f + (float)n, (float)R.capacity);
+    if (R.size_i) *R.size_i = min(*R.size_i + n, R.capacity);
+    if (R.counter) *R.counter += 1u;
+}
+
 // ================================================================== wide tiles
 // A batch of 4096 is only 128 tiles.  The NT waves of a workgroup SHARE one tile: wave w owns the hidden features
 // [32 w, 32 w + 32) of both layers, the activations cross an LDS exchange between the layers, and every wave's dependent MFMA
@@ -187,12 +272,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void actor_act_kernel(const float* _
 // Partial gradient vectors: one per workgroup, word order of Part<> (dW2 in the accumulator's [tile][lane][q] order).
 namespace wide {
 constexpr int XW = 20, XT = 64 * XW;                    // an exchanged tile: 16 words per lane, padded to 20 (conflict-free 16-byte access)
+// LDS of a wide-tile kernel = [Small<NOUT> of each network it evaluates][Xch]: the per-network constants and ONE set of exchange
+// buffers shared by the networks a workgroup walks through one after the other (workgroup barrier in between).
 template <int NOUT>
-struct Lds {
+struct Small {
     static constexpr int W3 = 0;                                        // [NOUT][H]
     static constexpr int B1 = W3 + NOUT * HID, B2 = B1 + HID, B3 = B2 + HID;   // b3: [8]
     static constexpr int W1A = B3 + 8;                                  // [4][H]    W1's action columns (Q networks, dq/da)
-    static constexpr int H1X = W1A + 4 * HID;                           // [NT][XT]  h1 tiles, accumulator layout (lane = sample)
+    static constexpr int END = W1A + 4 * HID;
+    static_assert(NOUT <= 8 && (END % 4) == 0, "layout");
+};
+struct Xch {
+    static constexpr int H1X = 0;                                       // [NT][XT]  h1 tiles, accumulator layout (lane = sample)
     static constexpr int RED = H1X + NT * XT;                           // [NT][8][32] per-wave partial outputs
     static constexpr int FWD_END = RED + NT * 8 * 32;
     static constexpr int DZX = FWD_END;                                 // [NT][XT]  dz2 tiles, accumulator layout
@@ -201,13 +292,12 @@ struct Lds {
     static constexpr int WAVE = DIN + NT * 4 * 32;                      // per wave: scr | xs | dout_l
     static constexpr int WAVE_WORDS = TR_WORDS + 34 * 32 + 8 * 32;
     static constexpr int END = WAVE + NT * WAVE_WORDS;
-    static_assert(NOUT <= 8 && (H1X % 4) == 0, "layout");
 };
 
 // W3 and the biases of one network -> LDS (all threads; caller barriers)
 template <int NOUT>
-__device__ __forceinline__ void fill_small(float* lds, const MlpWeights& w, int tid) {
-    using S = Lds<NOUT>;
+__device__ __forceinline__ void fill_small(float* lds, const MlpWeights& w, int tid) {           // lds = the network's Small<NOUT> block
+    using S = Small<NOUT>;
     for (int k = tid; k < NOUT * HID; k += 64 * NT) lds[S::W3 + k] = w.W3[k];
     for (int k = tid; k < HID; k += 64 * NT) { lds[S::B1 + k] = w.b1[k]; lds[S::B2 + k] = w.b2[k]; }
     if (tid < 8) lds[S::B3 + tid] = tid < NOUT ? w.b3[tid] : 0.0f;
@@ -267,15 +357,16 @@ __device__ __forceinline__ void get_tile(const float* slot, float* t) {
 // Forward pass of the workgroup's tile: h1, h2 = this wave's feature tile of each hidden layer (accumulator layout), out = the
 // network outputs of this lane's sample (every wave, both lane halves).  Two workgroup barriers.
 template <int NIN, int NOUT, int ACT2>
-__device__ __forceinline__ void forward(float* lds, const float* a1, const float (&a2)[NT][16], const float* x, int wave, int lane,
+__device__ __forceinline__ void forward(const float* sm, float* xch, const float* a1, const float (&a2)[NT][16], const float* x, int wave, int lane,
                                         f32x16& h1, f32x16& h2, float* out) {
-    using S = Lds<NOUT>;
+    using S = Small<NOUT>;
+    using X = Xch;
     constexpr int L1Q = 4 * ((NIN + 7) / 8);
     const int c = lane & 31, h = lane >> 5;
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + S::B1 + 32 * wave + 8 * g + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sm + S::B1 + 32 * wave + 8 * g + 4 * h);
         acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
     }
 #pragma unroll
@@ -283,17 +374,17 @@ __device__ __forceinline__ void forward(float* lds, const float* a1, const float
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT>(acc[q]);
     h1 = acc;
-    put_tile(lds + S::H1X + wave * XT + lane * XW, h1);
+    put_tile(xch + X::H1X + wave * XT + lane * XW, h1);
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + S::B2 + 32 * wave + 8 * g + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sm + S::B2 + 32 * wave + 8 * g + 4 * h);
         acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
     }
 #pragma unroll
     for (int tau = 0; tau < NT; ++tau) {
         float hb[16];
-        get_tile(lds + S::H1X + tau * XT + lane * XW, hb);
+        get_tile(xch + X::H1X + tau * XT + lane * XW, hb);
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc = mfma32(a2[tau][q], hb[q], acc);
     }
@@ -305,19 +396,19 @@ __device__ __forceinline__ void forward(float* lds, const float* a1, const float
         float s = 0.0f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(lds + S::W3 + o * HID + 32 * wave + 8 * g + 4 * h);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(sm + S::W3 + o * HID + 32 * wave + 8 * g + 4 * h);
             s = __builtin_fmaf(w.x, h2[4 * g], s); s = __builtin_fmaf(w.y, h2[4 * g + 1], s);
             s = __builtin_fmaf(w.z, h2[4 * g + 2], s); s = __builtin_fmaf(w.w, h2[4 * g + 3], s);
         }
         s += __shfl_xor(s, 32, 64);
-        if (h == 0) lds[S::RED + (wave * 8 + o) * 32 + c] = s;
+        if (h == 0) xch[X::RED + (wave * 8 + o) * 32 + c] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-        float s = lds[S::B3 + o];
+        float s = sm[S::B3 + o];
 #pragma unroll
-        for (int w = 0; w < NT; ++w) s += lds[S::RED + (w * 8 + o) * 32 + c];
+        for (int w = 0; w < NT; ++w) s += xch[X::RED + (w * 8 + o) * 32 + c];
         out[o] = s;
     }
 }
@@ -327,12 +418,13 @@ __device__ __forceinline__ void forward(float* lds, const float* a1, const float
 // partial vector P;  DIN: din[j] = d loss / d input[NIN - NU + j] of this lane's sample (every wave).  One workgroup barrier
 // (two with DIN); the caller barriers before the next tile's forward().
 template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN>
-__device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], f32x16& h1, f32x16& h2,
+__device__ __forceinline__ void backward(const float* sm, float* xch, const float (&bt)[NT][16], f32x16& h1, f32x16& h2,
                                          const float* dout, int wave, int lane, float* P, bool first, float* din) {
-    using S = Lds<NOUT>;
+    using S = Small<NOUT>;
+    using X = Xch;
     using G = Part<NIN, NOUT>;
     const int c = lane & 31, h = lane >> 5;
-    float* const wl = lds + S::WAVE + wave * S::WAVE_WORDS;
+    float* const wl = xch + X::WAVE + wave * X::WAVE_WORDS;
     float* const scr = wl; float* const xs = wl + TR_WORDS; float* const dout_l = xs + 34 * 32;
     float zt[16];                                                       // dz2^T of the own tile (WGRAD)
     if constexpr (WGRAD) {
@@ -371,14 +463,14 @@ __device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], 
         float dh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + S::W3 + o * HID + 32 * wave + 8 * g + 4 * h);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(sm + S::W3 + o * HID + 32 * wave + 8 * g + 4 * h);
             dh[0] = __builtin_fmaf(wv.x, dout[o], dh[0]); dh[1] = __builtin_fmaf(wv.y, dout[o], dh[1]);
             dh[2] = __builtin_fmaf(wv.z, dout[o], dh[2]); dh[3] = __builtin_fmaf(wv.w, dout[o], dh[3]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) h2[4 * g + r] = dh[r] * mlp_dact<ACT2>(h2[4 * g + r]);
     }
-    put_tile(lds + S::DZX + wave * XT + lane * XW, h2);
+    put_tile(xch + X::DZX + wave * XT + lane * XW, h2);
     if constexpr (WGRAD) {
         tile_transpose(scr, h2, zt, lane);                              // dz2[out 32 wave + c][sample row(q, h)]
         float sb = 0.0f;
@@ -387,7 +479,7 @@ __device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], 
         sb += __shfl_xor(sb, 32, 64);
         if (h == 0) padd(P + G::DB2 + 32 * wave + c, sb, first);
         tile_transpose_inplace(scr, h1, lane);                          // h1[in 32 wave + c][sample row(q, h)]
-        put_tile(lds + S::H1T + wave * XT + lane * XW, h1);
+        put_tile(xch + X::H1T + wave * XT + lane * XW, h1);
     }
     __syncthreads();
     // data gradient of the own input tile: dh1[32 wave + .] = sum over rho of W2[32 rho + ., 32 wave + .]^T dz2[rho]
@@ -397,7 +489,7 @@ __device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], 
 #pragma unroll
     for (int rho = 0; rho < NT; ++rho) {
         float za[16];
-        get_tile(lds + S::DZX + rho * XT + lane * XW, za);
+        get_tile(xch + X::DZX + rho * XT + lane * XW, za);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if constexpr (WGRAD) acc = mfma32(za[q], bt[rho][q], acc);  // transposed: [sample row(q', h)][feature 32 wave + c]
@@ -414,19 +506,19 @@ __device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], 
             float s = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(lds + S::W1A + j * HID + 32 * wave + 8 * g + 4 * h);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(sm + S::W1A + j * HID + 32 * wave + 8 * g + 4 * h);
                 s = __builtin_fmaf(wv.x, acc[4 * g], s); s = __builtin_fmaf(wv.y, acc[4 * g + 1], s);
                 s = __builtin_fmaf(wv.z, acc[4 * g + 2], s); s = __builtin_fmaf(wv.w, acc[4 * g + 3], s);
             }
             s += __shfl_xor(s, 32, 64);
-            if (h == 0) lds[S::DIN + (wave * 4 + j) * 32 + c] = s;
+            if (h == 0) xch[X::DIN + (wave * 4 + j) * 32 + c] = s;
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             float s = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NT; ++w) s += lds[S::DIN + (w * 4 + j) * 32 + c];
+            for (int w = 0; w < NT; ++w) s += xch[X::DIN + (w * 4 + j) * 32 + c];
             din[j] = s;
         }
     }
@@ -459,7 +551,7 @@ __device__ __forceinline__ void backward(float* lds, const float (&bt)[NT][16], 
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             float ta[16];
-            get_tile(lds + S::H1T + tau * XT + lane * XW, ta);
+            get_tile(xch + X::H1T + tau * XT + lane * XW, ta);
             f32x16 d2;
 #pragma unroll
             for (int q = 0; q < 16; ++q) d2[q] = 0.0f;
@@ -506,6 +598,7 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_fwd_kernel(const float* __re
     load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
     load_a2(w.W2, wave, lane, a2);
     fill_small<NA>(lds, w, threadIdx.x);
+    float* const xch = lds + Small<NA>::END;
     if (la_out && blockIdx.x == 0 && threadIdx.x == 0) *la_out = *Cm.log_alpha;
     __syncthreads();
     const int n_tiles = Cm.batch / 32;
@@ -524,7 +617,7 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_fwd_kernel(const float* __re
         load_x2<L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
         f32x16 h1, h2;
         float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp;
-        forward<NOBS, NA, MLP_ACT_NONE>(lds, a1, a2, x, wave, lane, h1, h2, out);
+        forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
         if (wave == 0) {
             if (eps_in) {
 #pragma unroll
@@ -552,7 +645,7 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
                                                         const Common Cm, const float* __restrict__ a_in, const float* __restrict__ qt,
                                                         const float* __restrict__ logp_next, float* __restrict__ q_out,
                                                         float* __restrict__ dqda, float* __restrict__ partials) {
-    using S = Lds<1>;
+    using S = Small<1>;
     using G = Part<NQ, 1>;
     constexpr int L1Q = 4 * ((NQ + 7) / 8);
     extern __shared__ __align__(16) float lds[];
@@ -569,7 +662,8 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
     }
     __syncthreads();
     const int n_tiles = Cm.batch / 32, B = Cm.batch;
-    float* const xs = lds + S::WAVE + wave * S::WAVE_WORDS + TR_WORDS;
+    float* const xch = lds + S::END;
+    float* const xs = xch + Xch::WAVE + wave * Xch::WAVE_WORDS + TR_WORDS;
     float* const P = partials ? partials + ((size_t)y * Cm.n_part + blockIdx.x) * PSTRIDE : nullptr;
     const float alpha = MODE == 2 ? expf(*Cm.log_alpha) : 0.0f;
     const float inv_b = 1.0f / (float)B;
@@ -583,13 +677,13 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
         else load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
         f32x16 h1, h2;
         float out[1];
-        forward<NQ, 1, ACT>(lds, a1, a2, x, wave, lane, h1, h2, out);
+        forward<NQ, 1, ACT>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
         if constexpr (MODE == 0) {
             if (wave == 0 && h == 0) q_out[(size_t)y * B + r] = out[0];
         } else if constexpr (MODE == 1) {
             const float dout[1] = {1.0f};
             float din[NU];
-            backward<NQ, 1, ACT, false, true>(lds, bt, h1, h2, dout, wave, lane, nullptr, true, din);
+            backward<NQ, 1, ACT, false, true>(lds, xch, bt, h1, h2, dout, wave, lane, nullptr, true, din);
             if (wave == 0 && h == 0) {
                 q_out[(size_t)y * B + r] = out[0];
 #pragma unroll
@@ -601,7 +695,7 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
             const float e = out[0] - target;
             const float dout[1] = {2.0f * e * inv_b};
             if (wave == 0 && h == 0) st += e * e * inv_b;
-            backward<NQ, 1, ACT, true, false>(lds, bt, h1, h2, dout, wave, lane, P, first, nullptr);
+            backward<NQ, 1, ACT, true, false>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr);
             first = false;
         }
         __syncthreads();                                                // the exchange buffers are free for the next tile
@@ -619,7 +713,7 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
 __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
                                                                  const float* __restrict__ eps_all, const float* __restrict__ qpi,
                                                                  const float* __restrict__ dqda, float* __restrict__ partials) {
-    using S = Lds<NA>;
+    using S = Small<NA>;
     using G = Part<NOBS, NA>;
     constexpr int L1Q = 4 * ((NOBS + 7) / 8);
     extern __shared__ __align__(16) float lds[];
@@ -632,7 +726,8 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __r
     fill_small<NA>(lds, w, threadIdx.x);
     __syncthreads();
     const int n_tiles = Cm.batch / 32, B = Cm.batch;
-    float* const xs = lds + S::WAVE + wave * S::WAVE_WORDS + TR_WORDS;
+    float* const xch = lds + S::END;
+    float* const xs = xch + Xch::WAVE + wave * Xch::WAVE_WORDS + TR_WORDS;
     float* const P = partials + (size_t)blockIdx.x * PSTRIDE;
     const float alpha = expf(*Cm.log_alpha), inv_b = 1.0f / (float)B;
     float st_loss = 0.0f, st_logp = 0.0f;
@@ -644,7 +739,7 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __r
         cache_x<NOBS, L1Q>(xs, x, c, h);
         f32x16 h1, h2;
         float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp, dout[NA];
-        forward<NOBS, NA, MLP_ACT_NONE>(lds, a1, a2, x, wave, lane, h1, h2, out);
+        forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
 #pragma unroll
         for (int j = 0; j < NU; ++j) eps[j] = eps_all[(size_t)r * NU + j];
         squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
@@ -660,7 +755,7 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __r
             dout[NU + j] = pass * (du * sig[j] * eps[j] - inv_b * alpha);
         }
         if (wave == 0 && h == 0) { st_loss += (alpha * logp - fminf(q1, q2)) * inv_b; st_logp += logp * inv_b; }
-        backward<NOBS, NA, MLP_ACT_NONE, true, false>(lds, bt, h1, h2, dout, wave, lane, P, first, nullptr);
+        backward<NOBS, NA, MLP_ACT_NONE, true, false>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr);
         first = false;
         __syncthreads();
     }
@@ -670,6 +765,7 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __r
         if (lane == 0) { P[G::STAT] = st_loss; P[G::STAT + 1] = st_logp; }
     }
 }
+
 }  // namespace wide
 
 // Sum of the waves' partials -> flat gradient (torch parameter order); blockIdx.y = network of the launch.
@@ -695,8 +791,18 @@ struct ReduceArgs {
     // p != nullptr (single-GPU path): the element's torch.optim.Adam step and its soft update follow its sum at once — each
     // parameter is written by exactly one thread of one launch, so the separate adam_kernel launch and the trip of the
     // gradient through memory go away.  Data-parallel callers leave p null, all-reduce grad and run adam_kernel.
-    float* p; float* m; float* v; float lr; const float* steps; int step_slot; float* target; float tau;
+    float* p; float* m; float* v; float lr; const float* steps; float* steps_rw; int step_slot; float* target; float tau;
     int alpha_on; float lr_alpha;
+    // Single-GPU bookkeeping folded into the reductions (no finish_kernel launch; no device-scope fence either — every word below is
+    // touched by ONE thread of a launch in which nobody else reads it):
+    //   bump_critic  (actor's launch)    the statistics word's owner pre-increments steps[1], which only the CRITICS' launch reads
+    //   t_add        what a launch adds to steps[step_slot] to get Adam's t: 1, or 0 where the count was pre-incremented
+    //   fin          (critics' launch)   the owner of network 0's statistics word also sums network 1's (same fixed order as that
+    //                                    network's own block), advances steps[0], steps[2] and the Philox counter (read by other
+    //                                    launches only) and writes the step's loss statistics
+    int bump_critic; float t_add;
+    struct Fin { float* steps; uint32_t* counter; float* stats; float* stats_acc; const float* actor_stat; const float* log_alpha_before;
+                 int alpha_on; float target_entropy; } fin;
 };
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float t);
 template <int NIN, int NOUT>
@@ -712,6 +818,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
         for (int g = grp; g < R.n_part; g += 4) s += R.partials[((size_t)net * R.n_part + g) * PSTRIDE + k];
     }
     part[grp][kl] = s;
+    __shared__ float other[512];                            // (n_part <= 512, n_part_of)
+    constexpr int KS = Part<NIN, NOUT>::STAT;
+    const bool fin_block = R.fin.steps && net == 0 && blockIdx.x == KS / 64;
+    if (fin_block) {                                        // network 1's statistics word of every partial: one load per thread
+        for (int g = threadIdx.x; g < R.n_part; g += 256) other[g] = R.partials[((size_t)R.n_part + g) * PSTRIDE + KS];
+    }
     __syncthreads();
     if (grp != 0 || k >= words) return;
     s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
@@ -719,11 +831,30 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     if (d >= 0) {
         R.grad[d] = s;
         if (R.p) {
-            adam_one(R.p[d], s, R.m[d], R.v[d], R.lr, R.steps[R.step_slot] + 1.0f);
+            adam_one(R.p[d], s, R.m[d], R.v[d], R.lr, R.steps[R.step_slot] + R.t_add);
             if (R.target) R.target[d] = (1.0f - R.tau) * R.target[d] + R.tau * R.p[d];
         }
     } else if (d == -2) {
         R.stat_out[2 * net] = s;
+        if (R.bump_critic) R.steps_rw[1] += 1.0f;
+        if (fin_block) {                                    // what finish_kernel does on the data-parallel path
+            const ReduceArgs::Fin& F = R.fin;
+            F.steps[0] += 1.0f;
+            if (F.alpha_on) F.steps[2] += 1.0f;
+            *F.counter += 1u;
+            const float pl = F.actor_stat[0], ml = F.actor_stat[1];
+            float o4[4];                                    // summed exactly as network 1's own block sums its word
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o = 0.0f;
+                for (int g = q; g < R.n_part; g += 4) o += other[g];
+                o4[q] = o;
+            }
+            const float cl = s + ((o4[0] + o4[1]) + (o4[2] + o4[3]));
+            const float el = F.alpha_on ? -(*F.log_alpha_before) * (ml + F.target_entropy) : 0.0f;
+            F.stats[0] = pl; F.stats[1] = cl; F.stats[2] = el; F.stats[3] = ml;
+            if (F.stats_acc) { F.stats_acc[0] += pl; F.stats_acc[1] += cl; F.stats_acc[2] += el; F.stats_acc[3] += ml; }
+        }
     } else if (d == -3) {
         R.stat_out[2 * net + 1] = s;
         // entropy_loss = -mean(log_alpha (log pi + target_entropy)) (sac_utils.py:124-126); in the gradient vector so that a
@@ -810,8 +941,8 @@ static int set_lds(K kernel, size_t bytes) {
 }
 
 static size_t lds_actor_bytes() { return (MlpLds<NOBS, HID, NA>::END + WAVES * (32 * ((NOBS + 3) / 4 * 4) + NA * 32 + TR_WORDS)) * sizeof(float); }
-static size_t wide_lds_actor() { return wide::Lds<NA>::END * sizeof(float); }
-static size_t wide_lds_q() { return wide::Lds<1>::END * sizeof(float); }
+static size_t wide_lds_actor() { return (wide::Small<NA>::END + wide::Xch::END) * sizeof(float); }
+static size_t wide_lds_q() { return (wide::Small<1>::END + wide::Xch::END) * sizeof(float); }
 
 // One-time kernel attributes (dynamic LDS above 64 KB).  Call once before capturing scg_sac_update into a HIP graph: the
 // attribute calls are not stream operations.  scg_sac_update calls it itself otherwise.
@@ -822,7 +953,7 @@ extern "C" int scg_sac_prepare(void) {
     const size_t lds_a = lds_actor_bytes();
     if (lds_a > 160 * 1024 || wide_lds_actor() > 160 * 1024 || wide_lds_q() > 160 * 1024)
         return fail(-1, "scg_sac: network image does not fit the LDS");
-    if (set_lds(actor_act_kernel, lds_a)) return -2;
+    if (set_lds(actor_act_kernel, lds_a) || set_lds(actor_sample_kernel, MlpLds<NOBS, HID, NA>::END * sizeof(float))) return -2;
     if (set_lds(wide::actor_fwd_kernel, wide_lds_actor()) || set_lds(wide::actor_grad_kernel, wide_lds_actor()) ||
         set_lds(wide::q_kernel<0>, wide_lds_q()) || set_lds(wide::q_kernel<1>, wide_lds_q()) || set_lds(wide::q_kernel<2>, wide_lds_q())) return -2;
     once.commit(dev);
@@ -852,9 +983,16 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     // by one, an all-reduce of d_grad between them) get the gradient only and step in adam_kernel
     const bool fuse = phases == SCG_SAC_ALL;
     auto optimiser = [&](ReduceArgs& R, float lr, int step_slot) {
+        R.bump_critic = 0; R.t_add = 1.0f; R.steps_rw = nullptr;
+        R.fin = ReduceArgs::Fin{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0f};
         if (!fuse) { R.p = nullptr; R.m = R.v = R.target = nullptr; R.steps = nullptr; R.lr = R.tau = R.lr_alpha = 0.0f; R.step_slot = 0; R.alpha_on = 0; return; }
-        R.p = a->d_params; R.m = a->d_m; R.v = a->d_v; R.lr = lr; R.steps = a->d_steps; R.step_slot = step_slot;
+        R.p = a->d_params; R.m = a->d_m; R.v = a->d_v; R.lr = lr; R.steps = a->d_steps; R.steps_rw = a->d_steps; R.step_slot = step_slot;
         R.target = a->d_target; R.tau = a->tau; R.alpha_on = a->use_entropy_tuning; R.lr_alpha = a->entropy_lr;
+        if (step_slot == 0) R.bump_critic = 1;              // actor's launch: pre-increment the critics' count (read by their launch only)
+        else {                                              // critics' launch: the count is already this step's; + the step's bookkeeping
+            R.t_add = 0.0f;
+            R.fin = ReduceArgs::Fin{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
+        }
     };
     if (phases & SCG_SAC_ACTOR_GRAD) {
     // 1. minibatch rows (kept in idx), log_alpha as the policy loss sees it (entropy_loss is reported with that value);
@@ -902,12 +1040,46 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
                    0, a->n_params, 0.0f, 0.0f, stat, a->d_target, a->n_params, a->tau};
         adam_kernel<<<dim3((a->n_params + 255) / 256), dim3(256), 0, st>>>(A);
     }
-    // 9. step counters, loss statistics
-    {
+    // 9. step counters, loss statistics (data-parallel path; the fused single-GPU step did them inside the critics' reduction)
+    if (!fuse) {
         FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
         finish_kernel<<<dim3(1), dim3(64), 0, st>>>(F);
     }
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int scg_sac_sample(const float* d_params, const scg_mlp_layout* actor, const float* act_low, const float* act_high, const float* d_obs,
+                              int m, uint64_t seed, const uint32_t* d_counter, int uniform, const float* d_eps_in, float* d_act_out, void* stream) {
+    if (!act_low || !act_high || !d_act_out || m <= 0 || (!uniform && (!d_params || !actor || !d_obs))) return fail(-1, "scg_sac_sample: bad argument");
+    float lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    for (int j = 0; j < NU; ++j) { lo[j] = act_low[j]; hi[j] = act_high[j]; }
+    const float4 l4 = make_float4(lo[0], lo[1], lo[2], lo[3]), h4 = make_float4(hi[0], hi[1], hi[2], hi[3]);
+    if (uniform) {
+        uniform_action_kernel<<<dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(m, l4, h4, (uint32_t)seed, (uint32_t)(seed >> 32), d_counter, d_act_out);
+    } else {
+        const size_t lds_a = MlpLds<NOBS, HID, NA>::END * sizeof(float);
+        if (int rc = scg_sac_prepare()) return rc;
+        const int grid = std::min(256, (m + 127) / 128);
+        actor_sample_kernel<<<dim3(grid), dim3(64 * WAVES), lds_a, (hipStream_t)stream>>>(d_params, *actor, d_obs, m, l4, h4, (uint32_t)seed,
+                                                                                            (uint32_t)(seed >> 32), d_counter, d_eps_in, d_act_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int scg_sac_push(const scg_sac_ring* ring, float* d_cur_obs, const float* d_act, const float* d_reward, const float* d_next_obs,
+                            const float* d_terminal_obs, const uint8_t* d_done, const uint8_t* d_flags, int n, void* stream) {
+    if (!ring || !ring->d_obs || !ring->d_act || !ring->d_rew || !ring->d_next_obs || !ring->d_mask || !ring->d_pos || !d_cur_obs || !d_act ||
+        !d_reward || !d_next_obs || !d_terminal_obs || !d_done || !d_flags)
+        return fail(-1, "scg_sac_push: NULL argument");
+    if (n <= 0 || ring->capacity < n) return fail(-1, "scg_sac_push: replay capacity smaller than one vectorised step");
+    const RingArgs R{ring->d_obs, ring->d_act, ring->d_rew, ring->d_next_obs, ring->d_mask, ring->capacity, (long long*)ring->d_pos, ring->d_size_f,
+                     ring->d_size_i32, ring->d_counter};
+    const int total = n * NOBS;
+    ring_push_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(R, d_cur_obs, d_act, d_reward, d_next_obs, d_terminal_obs, d_done, d_flags, n);
+    ring_advance_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(R, n);
     HIP_TRY(hipGetLastError());
     return 0;
 }

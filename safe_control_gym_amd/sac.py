@@ -601,8 +601,16 @@ class SAC:
         self.obs = self.obs_normalizer(env.reset_tensors()).clone()         # sac.py:103-104; persistent storage (captured graphs alias it)
         self.total_steps = 0
         self._since_update = 0
-        self._graph_collect = self.device.type == 'cuda' and bool(cfg.extra.get('cuda_graphs', True))
+        self._graph_collect = self.device.type == 'cuda' and bool(cfg.extra.get('graph_collect', cfg.extra.get('cuda_graphs', True)))
         self._collect_graphs = {}
+        # fused collector (csrc/scg_sac.hip: scg_sac_sample, scg_sac_push): the policy's sampled action in ONE launch on the flat
+        # parameter vector (in-kernel Philox noise) and the time-limit fix-up + five ring writes + position bookkeeping in two, in place
+        # of ~40 PyTorch kernels per vector step.  Needs the fused agent and no running normalisers; extra['fused_collect'] = False
+        # keeps the PyTorch collector (A/B, tests) — chosen here, visibly.
+        self._fused_collect = bool(self.agent.use_fused and not self._normalise and cfg.extra.get('fused_collect', True))
+        if self._fused_collect:
+            self._act = torch.zeros(self.N, self.act_dim, device=self.device)
+            self._collect_counter = torch.zeros(1, dtype=torch.int32, device=self.device)       # counter word of the action noise
 
     # ---- one vectorised env step into the replay ring (sac.py:273-311)
     @torch.no_grad()
@@ -610,6 +618,8 @@ class SAC:
         """Static-shape device operations only: action (uniform during warm-up, else a sample of the policy), env step kernel,
         time-limit fix-up, normalisers, ring push, the next observation into the persistent `self.obs`."""
         env = self.env
+        if self._fused_collect:
+            return self._collect_body_fused(warm)
         if warm:                                        # action_space.sample() per env (sac.py:276-277)
             act = self.low + (self.high - self.low) * torch.rand(self.N, self.act_dim, device=self.device)
         else:
@@ -631,6 +641,34 @@ class SAC:
         mask = torch.where(trunc, torch.ones_like(out.reward), 1.0 - done.to(torch.float32))
         self.buffer.push_device(self.obs, act, rew, next_obs, mask)
         self.obs.copy_(obs_n)
+
+    def _collect_body_fused(self, warm):
+        """The same vector step as three library calls / four launches: scg_sac_sample (uniform warm-up action or a sample of the policy),
+        the env step kernel, scg_sac_push (fix-up, ring rows, current observation, position / size / noise counter)."""
+        import ctypes as C
+        from safe_control_gym_amd import _sac
+        ag, buf = self.agent, self.buffer
+        fl = ag._flat
+        D = _sac.lib(self.obs_dim, self.cfg.hidden_dim, self.act_dim, self.cfg.activation)
+        if '_act_bounds' not in fl:
+            fl['_act_bounds'] = ((C.c_float * 4)(*(fl['low'] + [0.0] * (4 - self.act_dim))), (C.c_float * 4)(*(fl['high'] + [0.0] * (4 - self.act_dim))))
+        lo, hi = fl['_act_bounds']
+        p = lambda t: t.data_ptr()                      # noqa: E731
+        ring = getattr(self, '_ring', None)
+        if ring is None or self._ring_of is not buf:
+            ring = self._ring = _sac.SacRing(d_obs=p(buf.obs), d_act=p(buf.act), d_rew=p(buf.rew), d_next_obs=p(buf.next_obs), d_mask=p(buf.mask),
+                                             capacity=buf.capacity, d_pos=p(buf.pos_t), d_size_f=p(buf.size_t), d_size_i32=p(buf.size_i32),
+                                             d_counter=p(self._collect_counter))
+            self._ring_of = buf
+        if self.N > buf.capacity:
+            raise ValueError('replay capacity smaller than one vectorised step')
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _sac.check(D, D.scg_sac_sample(p(fl['p']), C.byref(fl['actor']), lo, hi, p(self.obs), self.N, fl['seed'], p(self._collect_counter),
+                                           int(bool(warm)), None, p(self._act), st))
+            out = self.env.step_tensors(self._act)
+            _sac.check(D, D.scg_sac_push(C.byref(ring), p(self.obs), p(self._act), p(out.reward), p(out.obs), p(out.terminal_obs), p(out.done),
+                                         p(out.flags), self.N, st))
 
     def _collect(self, warm):
         """Eager, or (GPU, cfg.extra['cuda_graphs'] not off) ONE HIP-graph replay per vector step: the eager collector is ~45 small
@@ -689,6 +727,8 @@ class SAC:
         if getattr(self.reward_normalizer, 'ret', None) is not None:
             state['reward_normalizer_ret'] = self.reward_normalizer.ret.cpu()
         if training:
+            if self._fused_collect:             # counter word of the fused collector's action noise (scg_sac_sample)
+                state['collect_counter'] = int(self._collect_counter.item())
             state.update({'total_steps': self.total_steps, 'since_update': self._since_update, 'obs': self.obs.cpu(),
                           'random_state': {'torch': torch.get_rng_state(),
                                            'torch_cuda': torch.cuda.get_rng_state(self.device) if self.device.type == 'cuda' else None},
@@ -717,6 +757,8 @@ class SAC:
             self._since_update = int(state.get('since_update', 0))
             if 'obs' in state:
                 self.obs.copy_(state['obs'].to(self.device))              # in place: the collector's graphs alias this tensor
+            if self._fused_collect and 'collect_counter' in state:
+                self._collect_counter.fill_(int(state['collect_counter']))
             if 'env_random_state' in state:
                 self.env.set_env_random_state(state['env_random_state'])
             rs = state.get('random_state')

@@ -506,10 +506,10 @@ class HipVecEnv(VecEnv):
 
     def set_step_launch(self, split_max=None, wide_min=None, wsback=None):
         """Tuning knobs of the specialised libraries (scg_set_step_launch / scg_set_step_wsback): which launch geometry scg_step uses
-        by shard size — `split_max`: two waves per 64 envs (each produces half of the outputs) up to this many envs; `wide_min`:
-        256-thread workgroups from this many; `wsback` = (min, max): the range of shard sizes whose workspace arrays are stored
-        write-back (Quadrotor systems), (1, 0) = never.  None keeps a threshold; (0, 2**31 - 1, (1, 0)) = the plain
-        one-wave-per-64-envs launch always.  Results are identical either way."""
+        by shard size — `wide_min`: 256-thread workgroups from this many envs; `wsback` = (min, max): the range of shard sizes whose
+        workspace arrays are stored write-back (Quadrotor systems), (1, 0) = never.  None keeps a threshold; (None, 2**31 - 1, (1, 0)) =
+        the plain one-wave-per-64-envs launch always.  `split_max` is accepted and ignored (the split launch of rounds 5-6 was removed).
+        Results are identical either way."""
         f = lambda v: -1 if v is None else int(v)       # noqa: E731
         self._chk(self._lib.scg_set_step_launch(self._h, f(split_max), f(wide_min)))
         if wsback is not None:

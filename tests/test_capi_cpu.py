@@ -231,14 +231,14 @@ def test_bench_names_the_launch_geometry_and_gates_the_chain_model_on_the_source
     import json
     import bench
     from safe_control_gym_amd import _lib
-    assert 'step_split_kernel' in bench.launch_geometry(16384, True) and 'step_split_kernel' in bench.launch_geometry(32768, True)
+    assert bench.launch_geometry(16384, True).startswith('step_kernel (one wave per 64 envs')          # (no split launch any more)
     assert bench.launch_geometry(65536, True).startswith('step_kernel (one wave per 64 envs')
     assert 'step_wide_kernel' in bench.launch_geometry(16777216, True) and 'step_wide_kernel' not in bench.launch_geometry(4194304, True)
     assert 'generic library' in bench.launch_geometry(65536, False)
     assert 'step_wsback_kernel' in bench.launch_geometry(262144, True) and 'step_wsback_kernel' in bench.launch_geometry(131072, True)
     assert 'step_wsback_kernel' not in bench.launch_geometry(262144, True, 'cartpole_stab') and 'step_wsback_kernel' not in bench.launch_geometry(1048576, True)
     src = open(os.path.join(ROOT, 'safe_control_gym_amd', 'csrc', 'scg_kernels.hip')).read()
-    assert f'#define SCG_SPLIT_MAX_ENVS {bench.LAUNCH_SPLIT_MAX}' in src and f'#define SCG_WIDE_MIN_ENVS {bench.LAUNCH_WIDE_MIN}' in src
+    assert 'SCG_SPLIT_MAX_ENVS' not in src and f'#define SCG_WIDE_MIN_ENVS {bench.LAUNCH_WIDE_MIN}' in src
     assert f'#define SCG_WSBACK_MIN_ENVS {bench.LAUNCH_WSBACK[0]}' in src and f'#define SCG_WSBACK_MAX_ENVS {bench.LAUNCH_WSBACK[1]}' in src
     os.makedirs(tmp_path / 'profiles')
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))

@@ -445,7 +445,7 @@ def test_async_evaluator_matches_blocking_evaluation_and_overlaps_training():
         e.close()
 
 
-@pytest.mark.parametrize('norm', [False, True], ids=['plain', 'normalised'])
+@pytest.mark.parametrize('norm', [False, True, 'fused'], ids=['plain', 'normalised', 'fused'])
 def test_sac_graph_collector_equals_the_eager_collector(norm):
     """SAC.train_step's collector as ONE HIP-graph replay per vector step (policy / uniform action, env step kernel, time-limit fix-up,
     normalisers, device-side ring push) against the same body run eagerly: warm-up and policy phases (two eager steps, then capture +
@@ -454,17 +454,20 @@ def test_sac_graph_collector_equals_the_eager_collector(norm):
     statistics must agree."""
     from safe_control_gym_amd.sac import SAC, SACConfig
     N = 256
+    fused, norm = norm == 'fused', norm is True
 
     def run(graphs):
         env = _env('quadrotor_2D_track', N, episode_len_sec=0.12)               # 6-step episodes
-        extra = {'cuda_graphs': graphs}
+        # plain / normalised: the PyTorch collector (fused_collect off), everything eager vs graphs; fused: the library collector
+        # (scg_sac_sample / scg_sac_push, in-kernel Philox noise) replayed as a graph vs enqueued call by call
+        extra = {'graph_collect': graphs} if fused else {'cuda_graphs': graphs, 'fused_collect': False}
         if norm:
             extra.update(norm_obs=True, norm_reward=True, clip_obs=5.0)
         cfg = SACConfig(hidden_dim=32, activation='relu', warm_up_steps=5 * N, train_interval=10 ** 9, train_batch_size=64,
                         max_buffer_size=9 * N, extra=extra)
         torch.manual_seed(123)
         sac = SAC(env, cfg, seed=7)
-        assert sac._graph_collect == graphs
+        assert sac._graph_collect == graphs and sac._fused_collect == fused
         for _ in range(12):                                                     # 5 warm-up + 7 policy steps; 12 N pushes into 9 N slots
             assert 'updates' not in sac.train_step()
         torch.cuda.synchronize()

@@ -287,3 +287,100 @@ def test_adam_state_travels_between_the_fused_and_the_torch_layout():
     fused.update_from_buffer(buf, 256, 3); again.update_from_buffer(buf, 256, 3)
     torch.cuda.synchronize()
     assert torch.equal(again._flat['p'], fused._flat['p'])
+
+
+def test_fused_collector_pieces_equal_the_torch_collector():
+    """scg_sac_sample / scg_sac_push (the collector's device-side pieces, SAC._collect_body_fused) against the PyTorch collector they
+    replace: (1) the sampled action with the SAME noise equals MLPActor.forward's; the in-kernel noise is N(0, 1) and differs from
+    step to step; the warm-up action is U[low, high); (2) one vector step pushed by the kernel == DeviceReplay.push_device of the
+    fixed-up batch (terminal observation and mask 1 where truncated), across a ring wrap, incl. position / size words and the current
+    observation; (3) SAC.train_step on the fused collector fills the ring consistently with the env's own outputs."""
+    import ctypes as C
+    from safe_control_gym_amd import _sac
+    from safe_control_gym_amd.sac import SAC, DeviceReplay, SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    nobs, nu, H = 24, 4, 128
+    low, high = torch.tensor([-1.0, -0.5, 0.0, 0.1], device=dev), torch.tensor([1.0, 0.5, 2.0, 0.3], device=dev)
+    torch.manual_seed(3)
+    ag = SACAgent(nobs, nu, low, high, SACConfig(hidden_dim=H, activation='relu'), dev)
+    assert ag.use_fused
+    fl = ag._flat
+    D = _sac.lib(nobs, H, nu, 'relu')
+    lo, hi = (C.c_float * 4)(*low.tolist()), (C.c_float * 4)(*high.tolist())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    m = 1000                                                    # (ragged last tile)
+    obs = torch.randn(m, nobs, device=dev)
+    eps = torch.randn(m, nu, device=dev)
+    out = torch.empty(m, nu, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    _sac.check(D, D.scg_sac_sample(fl['p'].data_ptr(), C.byref(fl['actor']), lo, hi, obs.data_ptr(), m, 77, cnt.data_ptr(), 0, eps.data_ptr(), out.data_ptr(), st))
+    a = ag.ac.actor
+    with torch.no_grad():
+        h = a.net(obs)
+        u = a.mu_layer(h) + torch.clamp(a.log_std_layer(h), -20, 2).exp() * eps
+        ref = low + 0.5 * (torch.tanh(u) + 1.0) * (high - low)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6)
+    # in-kernel noise: implied eps = (atanh(2 (a - low) / (high - low) - 1) - mu) / sigma is standard normal, fresh per counter value
+    big = torch.randn(65536, nobs, device=dev) * 0.1
+    outs = []
+    for c in (0, 1):
+        cnt.fill_(c)
+        o = torch.empty(65536, nu, device=dev)
+        _sac.check(D, D.scg_sac_sample(fl['p'].data_ptr(), C.byref(fl['actor']), lo, hi, big.data_ptr(), 65536, 77, cnt.data_ptr(), 0, None, o.data_ptr(), st))
+        outs.append(o)
+    with torch.no_grad():
+        h = a.net(big)
+        mu, sg = a.mu_layer(h), torch.clamp(a.log_std_layer(h), -20, 2).exp()
+        e0 = (torch.atanh((2 * (outs[0] - low) / (high - low) - 1).clamp(-1 + 1e-6, 1 - 1e-6)) - mu) / sg
+    assert abs(float(e0.mean())) < 0.01 and abs(float(e0.std()) - 1.0) < 0.01 and abs(float((e0 ** 3).mean())) < 0.05
+    assert float((outs[0] - outs[1]).abs().mean()) > 1e-3      # another counter word, other draws
+    uo = torch.empty(65536, nu, device=dev)
+    _sac.check(D, D.scg_sac_sample(None, None, lo, hi, None, 65536, 77, cnt.data_ptr(), 1, None, uo.data_ptr(), st))
+    assert bool((uo >= low).all()) and bool((uo < high + 1e-6).all())
+    torch.testing.assert_close(uo.mean(0), 0.5 * (low + high), rtol=0, atol=0.01 * float((high - low).max()))
+    # ---- (2) ring push
+    n, cap = 300, 700
+    b_k, b_t = DeviceReplay(cap, nobs, nu, dev), DeviceReplay(cap, nobs, nu, dev)
+    cur_k = torch.randn(n, nobs, device=dev)
+    cur_t = cur_k.clone()
+    ring = _sac.SacRing(d_obs=b_k.obs.data_ptr(), d_act=b_k.act.data_ptr(), d_rew=b_k.rew.data_ptr(), d_next_obs=b_k.next_obs.data_ptr(),
+                        d_mask=b_k.mask.data_ptr(), capacity=cap, d_pos=b_k.pos_t.data_ptr(), d_size_f=b_k.size_t.data_ptr(),
+                        d_size_i32=b_k.size_i32.data_ptr(), d_counter=cnt.data_ptr())
+    cnt.zero_()
+    g = torch.Generator(device='cpu').manual_seed(4)
+    for step in range(4):                                       # 1200 rows into 700 slots: wraps
+        act = torch.randn(n, nu, generator=g).to(dev)
+        rew, nxt, term = torch.randn(n, generator=g).to(dev), torch.randn(n, nobs, generator=g).to(dev), torch.randn(n, nobs, generator=g).to(dev)
+        done = (torch.rand(n, generator=g) < 0.3).to(torch.uint8).to(dev)
+        flags = (torch.randint(0, 4, (n,), generator=g)).to(torch.uint8).to(dev)          # bit 0 = truncated
+        _sac.check(D, D.scg_sac_push(C.byref(ring), cur_k.data_ptr(), act.data_ptr(), rew.data_ptr(), nxt.data_ptr(), term.data_ptr(),
+                                     done.data_ptr(), flags.data_ptr(), n, st))
+        trunc = (flags & 1).bool() & done.bool()
+        b_t.push_device(cur_t, act, rew, torch.where(trunc[:, None], term, nxt), torch.where(trunc, torch.ones_like(rew), 1.0 - done.float()))
+        cur_t.copy_(nxt)
+    for k in ('obs', 'act', 'rew', 'next_obs', 'mask'):
+        assert torch.equal(getattr(b_k, k), getattr(b_t, k)), k
+    assert torch.equal(cur_k, cur_t) and int(b_k.pos_t) == int(b_t.pos_t) == (4 * n) % cap and int(b_k.size_i32) == cap and float(b_k.size_t) == cap
+    assert int(cnt) == 4
+    # ---- (3) the collector inside SAC.train_step: warm-up and policy phases, graph replays, truncations
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, tc = load_task('quadrotor_3D_track')
+    env = HipVecEnv(env_id, 256, seed=5, return_numpy=False, **dict(tc, episode_len_sec=0.2))
+    sac = SAC(env, SACConfig(hidden_dim=128, activation='relu', warm_up_steps=4 * 256, train_interval=10 ** 9, max_buffer_size=64 * 256), seed=5)
+    assert sac._fused_collect
+    prev = sac.obs.clone()
+    for t in range(12):
+        sac.train_step()
+        torch.cuda.synchronize()
+        rows = slice(t * 256, (t + 1) * 256)
+        assert torch.equal(sac.buffer.obs[rows], prev) and torch.equal(sac.obs, env.out.obs)
+        assert torch.equal(sac.buffer.act[rows], sac._act) and torch.equal(sac.buffer.rew[rows, 0], env.out.reward)
+        tr = (env.out.flags & 1).bool() & env.out.done.bool()
+        assert torch.equal(sac.buffer.next_obs[rows], torch.where(tr[:, None], env.out.terminal_obs, env.out.obs))
+        assert torch.equal(sac.buffer.mask[rows, 0], torch.where(tr, torch.ones_like(env.out.reward), 1.0 - env.out.done.float()))
+        lo3, hi3 = sac.low, sac.high
+        assert bool((sac._act >= lo3 - 1e-6).all()) and bool((sac._act <= hi3 + 1e-6).all())
+        prev = sac.obs.clone()
+    assert int(sac._collect_counter) == 12 and sac.buffer.size == 12 * 256 == int(sac.buffer.size_i32)
+    env.close()

@@ -1,6 +1,5 @@
-"""Launch geometries of scg_step in the specialised libraries (include/scg_hip.h: scg_set_step_launch) — the split launch (the two
-waves of a 128-thread workgroup per 64 envs, each producing half of the outputs, ordered by one barrier) the wide launch (256-thread workgroups) and the write-back-workspace launch — must give bit
-for bit what the one-wave-per-64-envs launch gives: every output of scg_step, the episode statistics, the simulator state and
+"""Launch geometries of scg_step in the specialised libraries (include/scg_hip.h: scg_set_step_launch, scg_set_step_wsback) — the
+wide launch (256-thread workgroups) and the write-back-workspace launch — must give bit for bit what the one-wave-per-64-envs launch gives: every output of scg_step, the episode statistics, the simulator state and
 counters, across auto-resets, ragged tails and group counts that are not a multiple of the launch's packet, for every shipped
 task, float32 and float64."""
 import numpy as np
@@ -17,7 +16,7 @@ CASES = [('quadrotor_2D_track', {}), ('cartpole_stab', {}), ('quadrotor_3D_track
 
 
 NEVER = 2 ** 31 - 1
-MODES = {'split': (NEVER, NEVER, (1, 0)), 'wide': (0, 0, (1, 0)), 'wsback': (0, NEVER, (0, NEVER))}
+MODES = {'wide': (None, 0, (1, 0)), 'wsback': (None, NEVER, (0, NEVER))}
 
 
 @pytest.mark.parametrize('mode', list(MODES))
@@ -35,7 +34,7 @@ def test_launch_geometry_equals_single_wave_launch(task, over, dtype, n, mode):
     cfg = dict(cfg, **over)
     a, b = [HipVecEnv(env_id, n, seed=4, dtype=dtype, return_numpy=False, specialize=True, **cfg) for _ in range(2)]
     a.set_step_launch(*MODES[mode])
-    b.set_step_launch(0, NEVER, (1, 0))             # one wave per 64 envs, one-wave workgroups, everything written through
+    b.set_step_launch(None, NEVER, (1, 0))          # one wave per 64 envs, one-wave workgroups, everything written through
     g = torch.Generator(device='cpu').manual_seed(11)
     oa, ob = a.reset_tensors(), b.reset_tensors()
     assert torch.equal(oa, ob)
@@ -61,49 +60,12 @@ def test_launch_geometry_equals_single_wave_launch(task, over, dtype, n, mode):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize('task', ['quadrotor_2D_track', 'quadrotor_3D_track_disturbed'])
-def test_split_launch_under_contention(task):
-    """The split launch's SCORE wave reads what its STATE wave overwrites (workspace state, counters, parameters, disturbance
-    offsets); the two are ordered by a workgroup barrier (csrc/scg_env_kernels.h: pair_barrier), not by dispatch order.  Shard of
-    the size the default takes the split launch at, a second stream saturating the chip with other work while it steps — a delayed
-    SCORE wave must still see the pre-step state: every output equals the one-wave launch run on an idle chip."""
-    from safe_control_gym_amd.registration import load_task
-    from safe_control_gym_amd.vec_env import HipVecEnv
-    env_id, cfg = load_task(task)
-    cfg = dict(cfg, episode_len_sec=0.4)            # many auto-resets: the stores the race was about
-    n, T = 32768, 120
-    a, b = [HipVecEnv(env_id, n, seed=9, return_numpy=False, specialize=True, **cfg) for _ in range(2)]
-    a.set_step_launch(NEVER, NEVER, (1, 0))
-    b.set_step_launch(0, NEVER, (1, 0))
-    g = torch.Generator(device='cpu').manual_seed(5)
-    acts = (torch.rand(T, n, a.spec.nu, generator=g) * 2 - 1).to(a.device)
-    assert torch.equal(a.reset_tensors(), b.reset_tensors())
-    ref = []
-    for t in range(T):                              # idle chip, one-wave launch
-        y = b.step_tensors(acts[t])
-        ref.append({k: getattr(y, k).clone() for k in ('obs', 'reward', 'done', 'flags', 'c_values', 'mse')})
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    m = torch.randn(4096, 4096, device=a.device)
-    stop = T
-    with torch.cuda.stream(side):                   # ~T x 0.2 ms of matrix work queued next to the steps
-        for _ in range(stop):
-            m = torch.tanh(m @ m) * 0.01
-    for t in range(T):
-        x = a.step_tensors(acts[t])
-        for k, v in ref[t].items():
-            assert torch.equal(getattr(x, k), v), (k, t)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(a.get_raw_state(), b.get_raw_state())
-    a.close(); b.close()
-
-
 def test_launch_thresholds_are_a_per_handle_setting():
     from safe_control_gym_amd.registration import load_task
     from safe_control_gym_amd.vec_env import HipVecEnv
     env_id, cfg = load_task('quadrotor_2D_track')
     env = HipVecEnv(env_id, 128, seed=0, return_numpy=False, specialize=False, **cfg)     # generic library: accepted, no effect
-    env.set_step_launch(4096, 0)
+    env.set_step_launch(4096, 0)                    # (split_max: accepted, ignored)
     env.set_step_launch(wide_min=1 << 20)           # None = unchanged
     env.reset_tensors()
     out = env.step_tensors(torch.zeros(128, 2, device=env.device))

@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 D = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'prof6')
-SAC_KERNELS = ('actor_fwd_kernel', 'actor_grad_kernel', 'q_kernel', 'reduce_kernel', 'finish_kernel', 'sac_')
+SAC_KERNELS = ('wide::', 'reduce_kernel<', 'finish_kernel', 'adam_kernel', 'sac_step')       # (the fused gradient step's launches, scg_sac.hip)
 
 
 def line_of(path):
@@ -61,7 +61,7 @@ for mode in ('ppo', 'sac'):
         e['optimiser_step_us'] = sum(float(r['AverageNs']) for r in step) * 1e-3
         e['frac_of_f32_mfma_peak_on_kernel_time'] = traced['flops_per_iteration'] / (e['kernel_sum_ms_per_iteration'] * 1e-3) / 157.3e12
     else:
-        sac_rows = [r for r in rows if any(k in r['Name'] for k in SAC_KERNELS) and 'scg' in r['Name']]
+        sac_rows = [r for r in rows if any(k in r['Name'] for k in SAC_KERNELS) and 'at::native' not in r['Name']]
         g_ns = sum(float(r['TotalDurationNs']) for r in sac_rows)
         n_g, n_v = traced['gradient_steps_executed'], traced['vector_steps_executed']
         step_us = g_ns * 1e-3 / n_g

@@ -27,8 +27,8 @@ def configs():
     for task in ('quadrotor_2D_track', 'cartpole_stab', 'quadrotor_3D_track'):
         env_id, c = load_task(task)
         out.append((env_id, dict(c, randomized_init=True)))
-    # tests/test_gpu_split_step.py
-    from tests.test_gpu_split_step import CASES as SPLIT_CASES
+    # tests/test_gpu_step_launch.py
+    from tests.test_gpu_step_launch import CASES as SPLIT_CASES
     for task, over in SPLIT_CASES:
         env_id, c = load_task(task)
         out.append((env_id, dict(c, **over, _no_rk4=True)))

@@ -31,8 +31,9 @@ def kernel_of(workload):
 
 
 def is_kernel(kname, name):
-    """`kname` in a rocprof kernel name; 'step_kernel' also names the split launch of the same step (step_split_kernel, round 5)."""
-    return kname in name or (kname == 'step_kernel' and 'step_split_kernel' in name)
+    """`kname` in a rocprof kernel name; 'step_kernel' also names the other launch geometries of the same step (step_wsback_kernel,
+    step_wide_kernel; round 5's step_split_kernel)."""
+    return kname in name or (kname == 'step_kernel' and any(k in name for k in ('step_split_kernel', 'step_wsback_kernel', 'step_wide_kernel')))
 
 
 def second_half_mean(rows, counter, kname):
@@ -70,7 +71,7 @@ for d in sorted(glob.glob(f'{SRC}/kt_*')):
             w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
         for r in keep:
             if is_kernel(kname, r['Name']):
-                entry['kernel_launched'] = 'step_split_kernel' if 'step_split_kernel' in r['Name'] else kname
+                entry['kernel_launched'] = next((k for k in ('step_split_kernel', 'step_wsback_kernel', 'step_wide_kernel') if k in r['Name']), kname)
                 entry['rocprof_avg_launch_us'] = float(r['AverageNs']) * 1e-3
                 entry['rocprof_calls'] = int(r['Calls'])
                 print(work, dt, N, kname, 'calls', r['Calls'], 'avg ns', r['AverageNs'], 'pct', r['Percentage'])
