@@ -16,7 +16,7 @@ configs' env kernels: cartpole_stab incl. the fused random-action rollout of con
 HBM roofline at this N), `fused_rollout` (K steps per launch with the PPO actor in the loop), `ppo` (budgeted wall-clock-to-reward runs at
 BASELINE config #3's batch: 3 partial epochs x 16 minibatches of 16 256 per iteration, with `ppo.full_epochs` and `ppo.envs_16384` beside
 it), `sac` (config #5's env; `sac.param_randomised` = with flyable parameter disturbances, target re-measured under them), `cpu_baseline`.
-`roofline.traffic`, `roofline.valu_issue`, `f64.traffic`, `sequence.*.traffic*` are quoted from profiles/r05_hbm_traffic.json (rocprofv3
+`roofline.traffic`, `roofline.valu_issue`, `f64.traffic`, `sequence.*.traffic*` are quoted from profiles/r06_hbm_traffic.json (rocprofv3
 --pmc passes) only while that file names the hash of the kernel sources in this tree.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU with
@@ -45,7 +45,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 # HBM traffic / executed-instruction counts come from committed rocprofv3 --pmc passes (tools/profile_round5.sh ->
 # tools/profile_post.py).  They describe ONE build of the kernels: the file carries the hash of the kernel sources it was measured
 # on, and a line printed from other sources drops the number (traffic: null, with the reason) instead of quoting a stale one.
-TRAFFIC_FILE = 'r05_hbm_traffic.json'
+TRAFFIC_FILE = 'r06_hbm_traffic.json'
+CHAIN_FILE = 'r06_chain_latency.json'
 SEQ_K, SEQ_K_ALL = 32, 8        # control steps per launch of the two scg_step_sequence workloads (sequence_leg, tools/seq_profile.py)
 SHADER_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md
 # scg_kernels.hip defaults (scg_set_step_launch): which launch geometry of the step kernel a shard of N envs takes
@@ -160,7 +161,7 @@ _PMC_CACHE = {}
 
 
 def pmc_entry(key):
-    """Entry `key` of profiles/r05_hbm_traffic.json if that file was measured on THESE kernel sources, else (None, why)."""
+    """Entry `key` of profiles/r06_hbm_traffic.json if that file was measured on THESE kernel sources, else (None, why)."""
     if 'file' not in _PMC_CACHE:
         try:
             with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
@@ -213,13 +214,13 @@ def chain_latency_of(task, period_us):
     in-order model of tools/isa_sim.py with the measured issue / dependent-issue intervals): the bound of kernels whose control step is
     tens of substeps of a dependent chain, where neither the HBM roofline nor the issue rate explains the launch."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r05_chain_latency.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', CHAIN_FILE)) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None
     from safe_control_gym_amd import _lib
     if d.get('_meta', {}).get('source_hash') != f'0x{_lib.source_hash():016x}':
-        return {'dropped': 'profiles/r05_chain_latency.json was computed from other kernel sources'}
+        return {'dropped': f'profiles/{CHAIN_FILE} was computed from other kernel sources'}
     e = d.get(task)
     if not e or 'chain_us_per_control_step' not in e:
         return e

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const ReduceArgs R) {
     const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
     float s = 0.0f;
     if (k < words) {
-#pragma unroll 16
+#pragma unroll 8
         for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
     }
     part[grp][kl] = s;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const StepArgs S) 
     }
     float s = 0.0f;
     if (k < words) {
-#pragma unroll 16
+#pragma unroll 8
         for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
     }
     part[grp][kl_] = s;
@@ -789,7 +789,17 @@ extern "C" int scg_random_permutation_keyed(int32_t* d_out, int n, int count, co
 extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m,
                                float* d_out, const uint8_t* d_row_mask, void* stream) {
     if (!d_params || !layout || !d_x || !d_out || m <= 0) return fail(-1, "scg_mlp_forward: bad argument");
-    const int grid = std::min(256, (m + 127) / 128);
+    // Two CUs are left free (the tiles are walked with a grid stride, any width is correct): a workgroup holds most of a CU's LDS, and the
+    // asynchronous evaluation (ppo.AsyncEvaluator: two long-running workgroups on a side stream) would otherwise make the last two
+    // workgroups of a chip-wide launch queue behind it — the whole pass then takes up to twice as long (ppo_grad_kernel's 127 + 127
+    // workgroups leave the same two CUs).
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 2) n_cu = v;
+        else n_cu = 256;
+    }
+    const int grid = std::min(std::max(n_cu - 2, 1), (m + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
     if (nout == NU) {
         const size_t bytes = MlpLds<NIN, HID, NU>::END * sizeof(float);

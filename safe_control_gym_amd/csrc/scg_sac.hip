@@ -80,7 +80,12 @@ struct Part {
 };
 constexpr int PSTRIDE = (Part<NOBS, NA>::END > Part<NQ, 1>::END ? Part<NOBS, NA>::END : Part<NQ, 1>::END);
 
-__device__ __forceinline__ void padd(float* p, float v, bool first) { *p = first ? v : *p + v; }
+// (a branch on the wave-uniform `first`, not a select: the select form LOADS the partial word on every call — a global round trip per
+//  output row in the dW3 phase of a workgroup's only tile, tools/sac_timeline.py)
+__device__ __forceinline__ void padd(float* p, float v, bool first) {
+    if (first) *p = v;
+    else *p += v;
+}
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -172,6 +177,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void actor_act_kernel(const float* _
         }
     }
 }
+
+// -DSCG_S_TIMING (tools/sac_timeline.py; development builds only): wave 0 of workgroup (0, 0) of actor_grad_kernel and q_kernel<2> stamps the
+// shader clock at its phase boundaries into a device array the host reads back with scg_sac_timeline().
+#ifdef SCG_S_TIMING
+__device__ unsigned long long g_sac_tl[2][16];
+#define SCG_S_STAMP(which, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_sac_tl[which][k] = __builtin_readcyclecounter(); } while (0)
+extern "C" int scg_sac_timeline(unsigned long long* h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sac_tl), sizeof(g_sac_tl)) == hipSuccess ? 0 : -2;
+}
+#else
+#define SCG_S_STAMP(which, k) do {} while (0)
+#endif
 
 // ================================================================== collector (SAC.train_step's env-facing half, sac.py:273-311)
 // A SAMPLED action of the policy for a batch of observations (MLPActorCritic.act(obs), sac_utils.py:258-262, deterministic = False):
@@ -294,13 +311,30 @@ struct Xch {
     static constexpr int END = WAVE + NT * WAVE_WORDS;
 };
 
-// W3 and the biases of one network -> LDS (all threads; caller barriers)
+// W3 and the biases of one network -> LDS (all threads; caller barriers), in two halves: the REQUESTS (small_load) go out first in a
+// kernel, the LDS writes (small_store) after the other requests of the prologue have been issued — the memory counter retires in
+// order, so the barrier behind the stores then waits for this handful of loads only, not for the ~150 operand loads behind them
+// (tools/sac_timeline.py: 3.6 us from kernel entry to the first barrier when the small block was requested last).
 template <int NOUT>
-__device__ __forceinline__ void fill_small(float* lds, const MlpWeights& w, int tid) {           // lds = the network's Small<NOUT> block
+struct SmallRegs { float w3[(NOUT * HID + 64 * NT - 1) / (64 * NT)]; float b1, b2, b3; };
+template <int NOUT>
+__device__ __forceinline__ void small_load(SmallRegs<NOUT>& R, const MlpWeights& w, int tid) {
+    constexpr int IT = (NOUT * HID + 64 * NT - 1) / (64 * NT);
+#pragma unroll
+    for (int j = 0; j < IT; ++j) { const int k = tid + j * 64 * NT; R.w3[j] = k < NOUT * HID ? w.W3[k] : 0.0f; }
+    static_assert(HID <= 64 * NT * 2, "one bias word per thread and layer");
+    R.b1 = tid < HID ? w.b1[tid] : 0.0f;
+    R.b2 = tid < HID ? w.b2[tid] : 0.0f;
+    R.b3 = tid < NOUT ? w.b3[tid] : 0.0f;
+}
+template <int NOUT>
+__device__ __forceinline__ void small_store(float* lds, const SmallRegs<NOUT>& R, int tid) {     // lds = the network's Small<NOUT> block
     using S = Small<NOUT>;
-    for (int k = tid; k < NOUT * HID; k += 64 * NT) lds[S::W3 + k] = w.W3[k];
-    for (int k = tid; k < HID; k += 64 * NT) { lds[S::B1 + k] = w.b1[k]; lds[S::B2 + k] = w.b2[k]; }
-    if (tid < 8) lds[S::B3 + tid] = tid < NOUT ? w.b3[tid] : 0.0f;
+    constexpr int IT = (NOUT * HID + 64 * NT - 1) / (64 * NT);
+#pragma unroll
+    for (int j = 0; j < IT; ++j) { const int k = tid + j * 64 * NT; if (k < NOUT * HID) lds[S::W3 + k] = R.w3[j]; }
+    if (tid < HID) { lds[S::B1 + tid] = R.b1; lds[S::B2 + tid] = R.b2; }
+    if (tid < 8) lds[S::B3 + tid] = R.b3;
 }
 
 // MFMA operands of wave `wave` from the torch-layout parameters:
@@ -417,7 +451,7 @@ __device__ __forceinline__ void forward(const float* sm, float* xch, const float
 // this lane's sample (identical in every wave).  WGRAD: this wave's slices of the weight / bias gradients into the workgroup's
 // partial vector P;  DIN: din[j] = d loss / d input[NIN - NU + j] of this lane's sample (every wave).  One workgroup barrier
 // (two with DIN); the caller barriers before the next tile's forward().
-template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN>
+template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN, int TL = -1>
 __device__ __forceinline__ void backward(const float* sm, float* xch, const float (&bt)[NT][16], f32x16& h1, f32x16& h2,
                                          const float* dout, int wave, int lane, float* P, bool first, float* din) {
     using S = Small<NOUT>;
@@ -457,6 +491,7 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
             if (h == 0) padd(P + G::DW3 + o * HID + 32 * wave + c, acc, first);
         }
     }
+    if constexpr (TL >= 0) SCG_S_STAMP(TL, 4);
     // dz2 = (W3^T dout) * act2'(h2), in place
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -481,7 +516,9 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
         tile_transpose_inplace(scr, h1, lane);                          // h1[in 32 wave + c][sample row(q, h)]
         put_tile(xch + X::H1T + wave * XT + lane * XW, h1);
     }
+    if constexpr (TL >= 0) SCG_S_STAMP(TL, 5);
     __syncthreads();
+    if constexpr (TL >= 0) SCG_S_STAMP(TL, 6);
     // data gradient of the own input tile: dh1[32 wave + .] = sum over rho of W2[32 rho + ., 32 wave + .]^T dz2[rho]
     f32x16 acc;
 #pragma unroll
@@ -498,6 +535,7 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] *= mlp_dact<ACT>(h1[q]);       // h1 is transposed exactly when acc is
+    if constexpr (TL >= 0) SCG_S_STAMP(TL, 7);
     if constexpr (DIN) {
         // d loss / d (action inputs): this wave's 32 features, then the waves' partials through the LDS
         static_assert(!WGRAD, "the input gradient is taken from the plain data gradient");
@@ -547,6 +585,7 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
                 }
             }
         }
+        if constexpr (TL >= 0) SCG_S_STAMP(TL, 8);
         // dW2 tiles (in 32 tau.., out 32 wave..) = h1^T[tau] x dz2^T[own] over this tile's samples
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
@@ -594,37 +633,47 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_fwd_kernel(const float* __re
     extern __shared__ __align__(16) float lds[];
     const MlpWeights w = weights_of(params, lay);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    float a1[L1Q], a2[NT][16];
-    load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
-    load_a2(w.W2, wave, lane, a2);
-    fill_small<NA>(lds, w, threadIdx.x);
-    float* const xch = lds + Small<NA>::END;
-    if (la_out && blockIdx.x == 0 && threadIdx.x == 0) *la_out = *Cm.log_alpha;
-    __syncthreads();
     const int n_tiles = Cm.batch / 32;
     const float* src = use_next ? Cm.next_obs : Cm.obs;
     const uint32_t cnt = *Cm.counter;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r = tile * 32 + c;
-        int s;
-        if (idx_out) {
-            s = sample_row(r, ring_size, idx_in, cnt, Cm.k0, Cm.k1);
-            if (wave == 0 && h == 0) idx_out[r] = s;
-        } else {
-            s = Cm.idx[r];
+    // request order (see small_load): the first tile's row index, the small block, the layer operands, the row itself
+    const int tile0 = blockIdx.x, r0 = tile0 * 32 + c;
+    int s0 = 0;
+    if (tile0 < n_tiles) s0 = idx_out ? sample_row(r0, ring_size, idx_in, cnt, Cm.k0, Cm.k1) : Cm.idx[r0];
+    SmallRegs<NA> sr;
+    small_load<NA>(sr, w, threadIdx.x);
+    float a1[L1Q], a2[NT][16];
+    load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
+    load_a2(w.W2, wave, lane, a2);
+    float x[L1Q], eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (tile0 < n_tiles) {
+        load_x2<L1Q, NOBS, 0>(src + (size_t)s0 * NOBS, nullptr, h, x);
+        if (eps_in) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r0 * NU + j];
         }
-        float x[L1Q];
-        load_x2<L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
-        f32x16 h1, h2;
-        float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp;
-        forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
-        if (wave == 0) {
+    }
+    small_store<NA>(lds, sr, threadIdx.x);
+    float* const xch = lds + Small<NA>::END;
+    if (la_out && blockIdx.x == 0 && threadIdx.x == 0) *la_out = *Cm.log_alpha;
+    __syncthreads();
+    for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
+        const int r = tile * 32 + c;
+        int s = s0;
+        if (tile != tile0) {
+            s = idx_out ? sample_row(r, ring_size, idx_in, cnt, Cm.k0, Cm.k1) : Cm.idx[r];
+            load_x2<L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
             if (eps_in) {
 #pragma unroll
                 for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r * NU + j];
-            } else {
-                normal4(cnt, (uint32_t)r, stream, Cm.k0, Cm.k1, eps);
             }
+        }
+        if (idx_out && wave == 0 && h == 0) idx_out[r] = s;
+        f32x16 h1, h2;
+        float out[NA], u[NU], th[NU], sig[NU], a[NU], logp;
+        forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
+        if (wave == 0) {
+            if (!eps_in) normal4(cnt, (uint32_t)r, stream, Cm.k0, Cm.k1, eps);
             squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
             if (h == 0) {
 #pragma unroll
@@ -652,16 +701,44 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
     const int y = blockIdx.y;
     const MlpWeights w = weights_of(params, y ? lay2 : lay1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    // request order (see small_load): the first tile's row index, the small block, the forward operands, the row's values;
+    // the backward operand (bt) is requested behind the barrier and arrives under the forward pass
+    const int tile0 = blockIdx.x, r0 = tile0 * 32 + c;
+    const int s0 = tile0 < n_tiles ? Cm.idx[r0] : 0;
+    SmallRegs<1> sr;
+    small_load<1>(sr, w, threadIdx.x);
+    float w1a[(NU * HID + 64 * NT - 1) / (64 * NT)];
+    if constexpr (MODE == 1) {                                          // W1A[j][f] = W1[f][NOBS + j]
+#pragma unroll
+        for (int j = 0; j < (NU * HID + 64 * NT - 1) / (64 * NT); ++j) {
+            const int k = threadIdx.x + j * 64 * NT;
+            w1a[j] = k < NU * HID ? w.W1[(size_t)(k % HID) * NQ + NOBS + k / HID] : 0.0f;
+        }
+    }
     float a1[L1Q], a2[NT][16], bt[NT][16];
     load_a1<NQ, L1Q>(w.W1, wave, lane, a1);
     load_a2(w.W2, wave, lane, a2);
-    if constexpr (MODE != 0) load_bt(w.W2, wave, lane, bt);
-    fill_small<1>(lds, w, threadIdx.x);
-    if constexpr (MODE == 1) {                                          // W1A[j][f] = W1[f][NOBS + j]
-        for (int k = threadIdx.x; k < NU * HID; k += 64 * NT) lds[S::W1A + k] = w.W1[(size_t)(k % HID) * NQ + NOBS + k / HID];
+    float x[L1Q], v_rew = 0.0f, v_mask = 0.0f, v_qt1 = 0.0f, v_qt2 = 0.0f, v_lpn = 0.0f;
+    auto load_row = [&](int r, int s) {
+        if constexpr (MODE == 0) load_x2<L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+        else if constexpr (MODE == 1) load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+        else {
+            load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
+            v_rew = Cm.rew[s]; v_mask = Cm.mask[s]; v_qt1 = qt[r]; v_qt2 = qt[B + r]; v_lpn = logp_next[r];
+        }
+    };
+    if (tile0 < n_tiles) load_row(r0, s0);
+    small_store<1>(lds, sr, threadIdx.x);
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < (NU * HID + 64 * NT - 1) / (64 * NT); ++j) {
+            const int k = threadIdx.x + j * 64 * NT;
+            if (k < NU * HID) lds[S::W1A + k] = w1a[j];
+        }
     }
     __syncthreads();
-    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    if constexpr (MODE != 0) load_bt(w.W2, wave, lane, bt);
     float* const xch = lds + S::END;
     float* const xs = xch + Xch::WAVE + wave * Xch::WAVE_WORDS + TR_WORDS;
     float* const P = partials ? partials + ((size_t)y * Cm.n_part + blockIdx.x) * PSTRIDE : nullptr;
@@ -669,12 +746,9 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
     const float inv_b = 1.0f / (float)B;
     float st = 0.0f;
     bool first = true;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r = tile * 32 + c, s = Cm.idx[r];
-        float x[L1Q];
-        if constexpr (MODE == 0) load_x2<L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
-        else if constexpr (MODE == 1) load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
-        else load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
+    for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
+        const int r = tile * 32 + c;
+        if (tile != tile0) load_row(r, Cm.idx[r]);
         f32x16 h1, h2;
         float out[1];
         forward<NQ, 1, ACT>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
@@ -691,7 +765,7 @@ __global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__
             }
         } else {
             cache_x<NQ, L1Q>(xs, x, c, h);
-            const float target = Cm.rew[s] + Cm.gamma * Cm.mask[s] * (fminf(qt[r], qt[B + r]) - alpha * logp_next[r]);
+            const float target = v_rew + Cm.gamma * v_mask * (fminf(v_qt1, v_qt2) - alpha * v_lpn);
             const float e = out[0] - target;
             const float dout[1] = {2.0f * e * inv_b};
             if (wave == 0 && h == 0) st += e * e * inv_b;
@@ -719,51 +793,73 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __r
     extern __shared__ __align__(16) float lds[];
     const MlpWeights w = weights_of(params, lay);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    SCG_S_STAMP(0, 0);
+    // request order (see small_load): the first tile's row index, the small block, the forward operands, the row's values (observation,
+    // stored noise, q1 / q2 and both dq/da candidates — two dependent round trips that used to start behind the first barrier and in
+    // the middle of the tile); the backward operand (bt) behind the barrier, under the forward pass
+    const int tile0 = blockIdx.x, r0 = tile0 * 32 + c;
+    const int s0 = tile0 < n_tiles ? Cm.idx[r0] : 0;
+    SmallRegs<NA> sr;
+    small_load<NA>(sr, w, threadIdx.x);
     float a1[L1Q], a2[NT][16], bt[NT][16];
     load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
     load_a2(w.W2, wave, lane, a2);
-    load_bt(w.W2, wave, lane, bt);
-    fill_small<NA>(lds, w, threadIdx.x);
+    float x[L1Q], eps[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = 0.0f, q2 = 0.0f, dq[2][NU];
+    auto load_row = [&](int r, int s) {
+        load_x2<L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            eps[j] = eps_all[(size_t)r * NU + j];
+            dq[0][j] = dqda[(size_t)r * NU + j];
+            dq[1][j] = dqda[((size_t)B + r) * NU + j];
+        }
+        q1 = qpi[r]; q2 = qpi[B + r];
+    };
+    if (tile0 < n_tiles) load_row(r0, s0);
+    small_store<NA>(lds, sr, threadIdx.x);
     __syncthreads();
-    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    SCG_S_STAMP(0, 1);
+    load_bt(w.W2, wave, lane, bt);
     float* const xch = lds + S::END;
     float* const xs = xch + Xch::WAVE + wave * Xch::WAVE_WORDS + TR_WORDS;
     float* const P = partials + (size_t)blockIdx.x * PSTRIDE;
     const float alpha = expf(*Cm.log_alpha), inv_b = 1.0f / (float)B;
     float st_loss = 0.0f, st_logp = 0.0f;
     bool first = true;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r = tile * 32 + c, s = Cm.idx[r];
-        float x[L1Q];
-        load_x2<L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x);
+    for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
+        const int r = tile * 32 + c;
+        if (tile != tile0) load_row(r, Cm.idx[r]);
         cache_x<NOBS, L1Q>(xs, x, c, h);
         f32x16 h1, h2;
-        float out[NA], eps[4], u[NU], th[NU], sig[NU], a[NU], logp, dout[NA];
+        float out[NA], u[NU], th[NU], sig[NU], a[NU], logp, dout[NA];
         forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
-#pragma unroll
-        for (int j = 0; j < NU; ++j) eps[j] = eps_all[(size_t)r * NU + j];
+        SCG_S_STAMP(0, 2);
         squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
-        const float q1 = qpi[r], q2 = qpi[B + r];
         const int ysel = q2 < q1 ? 1 : 0;                                          // torch.min: gradient to the smaller (q1 on a tie)
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
-            const float dq = dqda[((size_t)ysel * B + r) * NU + j];
-            const float du = inv_b * (alpha * 2.0f * th[j] - dq * 0.5f * (Cm.high[j] - Cm.low[j]) * (1.0f - th[j] * th[j]));
+            const float dqj = ysel ? dq[1][j] : dq[0][j];
+            const float du = inv_b * (alpha * 2.0f * th[j] - dqj * 0.5f * (Cm.high[j] - Cm.low[j]) * (1.0f - th[j] * th[j]));
             const float raw = out[NU + j];
             const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;      // torch.clamp's gradient
             dout[j] = du;
             dout[NU + j] = pass * (du * sig[j] * eps[j] - inv_b * alpha);
         }
         if (wave == 0 && h == 0) { st_loss += (alpha * logp - fminf(q1, q2)) * inv_b; st_logp += logp * inv_b; }
-        backward<NOBS, NA, MLP_ACT_NONE, true, false>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr);
+        SCG_S_STAMP(0, 3);
+        backward<NOBS, NA, MLP_ACT_NONE, true, false, 0>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr);
+        SCG_S_STAMP(0, 9);
         first = false;
         __syncthreads();
+        SCG_S_STAMP(0, 10);
     }
     if (wave == 0) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { st_loss += __shfl_xor(st_loss, m, 64); st_logp += __shfl_xor(st_logp, m, 64); }
         if (lane == 0) { P[G::STAT] = st_loss; P[G::STAT + 1] = st_logp; }
     }
+    SCG_S_STAMP(0, 11);
 }
 
 }  // namespace wide
@@ -821,8 +917,18 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     __shared__ float other[512];                            // (n_part <= 512, n_part_of)
     constexpr int KS = Part<NIN, NOUT>::STAT;
     const bool fin_block = R.fin.steps && net == 0 && blockIdx.x == KS / 64;
+    // the bookkeeping thread's inputs, requested up here: behind its sum they would be three dependent memory round trips at the end of
+    // the launch's longest-running thread
+    float f_steps0 = 0.0f, f_steps2 = 0.0f, f_pl = 0.0f, f_ml = 0.0f, f_la = 0.0f, f_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t f_cnt = 0u;
     if (fin_block) {                                        // network 1's statistics word of every partial: one load per thread
         for (int g = threadIdx.x; g < R.n_part; g += 256) other[g] = R.partials[((size_t)R.n_part + g) * PSTRIDE + KS];
+        if (grp == 0 && k == KS) {
+            const ReduceArgs::Fin& F = R.fin;
+            f_steps0 = F.steps[0]; f_steps2 = F.steps[2]; f_cnt = *F.counter; f_pl = F.actor_stat[0]; f_ml = F.actor_stat[1];
+            f_la = *F.log_alpha_before;
+            if (F.stats_acc) { f_acc[0] = F.stats_acc[0]; f_acc[1] = F.stats_acc[1]; f_acc[2] = F.stats_acc[2]; f_acc[3] = F.stats_acc[3]; }
+        }
     }
     __syncthreads();
     if (grp != 0 || k >= words) return;
@@ -839,10 +945,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
         if (R.bump_critic) R.steps_rw[1] += 1.0f;
         if (fin_block) {                                    // what finish_kernel does on the data-parallel path
             const ReduceArgs::Fin& F = R.fin;
-            F.steps[0] += 1.0f;
-            if (F.alpha_on) F.steps[2] += 1.0f;
-            *F.counter += 1u;
-            const float pl = F.actor_stat[0], ml = F.actor_stat[1];
+            F.steps[0] = f_steps0 + 1.0f;
+            if (F.alpha_on) F.steps[2] = f_steps2 + 1.0f;
+            *F.counter = f_cnt + 1u;
+            const float pl = f_pl, ml = f_ml;
             float o4[4];                                    // summed exactly as network 1's own block sums its word
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -851,9 +957,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
                 o4[q] = o;
             }
             const float cl = s + ((o4[0] + o4[1]) + (o4[2] + o4[3]));
-            const float el = F.alpha_on ? -(*F.log_alpha_before) * (ml + F.target_entropy) : 0.0f;
+            const float el = F.alpha_on ? -f_la * (ml + F.target_entropy) : 0.0f;
             F.stats[0] = pl; F.stats[1] = cl; F.stats[2] = el; F.stats[3] = ml;
-            if (F.stats_acc) { F.stats_acc[0] += pl; F.stats_acc[1] += cl; F.stats_acc[2] += el; F.stats_acc[3] += ml; }
+            if (F.stats_acc) { F.stats_acc[0] = f_acc[0] + pl; F.stats_acc[1] = f_acc[1] + cl; F.stats_acc[2] = f_acc[2] + el; F.stats_acc[3] = f_acc[3] + ml; }
         }
     } else if (d == -3) {
         R.stat_out[2 * net + 1] = s;

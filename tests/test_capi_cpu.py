@@ -244,9 +244,32 @@ def test_bench_names_the_launch_geometry_and_gates_the_chain_model_on_the_source
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
     model = {'_meta': {'source_hash': f'0x{_lib.source_hash():016x}'},
              'cartpole_stab': {'chain_us_per_control_step': 3.7, 'issue_limit_us_per_control_step': 2.7, 'dependent_instructions_per_substep': 21.0}}
-    (tmp_path / 'profiles' / 'r05_chain_latency.json').write_text(json.dumps(model))
+    (tmp_path / 'profiles' / bench.CHAIN_FILE).write_text(json.dumps(model))
     got = bench.chain_latency_of('cartpole_stab', 5.5)
     assert got['frac_of_launch'] == pytest.approx(3.7 / 5.5) and got['issue_limit_us'] == 2.7
     model['_meta']['source_hash'] = '0x0123456789abcdef'
-    (tmp_path / 'profiles' / 'r05_chain_latency.json').write_text(json.dumps(model))
+    (tmp_path / 'profiles' / bench.CHAIN_FILE).write_text(json.dumps(model))
     assert 'dropped' in bench.chain_latency_of('cartpole_stab', 5.5)
+
+
+def test_bench_learner_kernel_sums_are_gated_on_the_source_hashes(tmp_path, monkeypatch):
+    """bench.py quotes a learner iteration's rocprofv3 kernel sum (ppo.iteration_ms.kernel_sum, sac.roofline.gradient_step_us_rocprof)
+    only from a profiles/r06_learner_kernel_sums.json measured on THESE kernel sources; the flop counts are the documented formulas."""
+    import json
+    import bench
+    from safe_control_gym_amd import _learn, _lib, _sac
+    assert bench.mlp_flops(12, 128, 2) == 2 * (12 * 128 + 128 * 128 + 128 * 2) and bench.mlp_flops(12, 128, 1, True) == 3 * bench.mlp_flops(12, 128, 1)
+    os.makedirs(tmp_path / 'profiles')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    hashes = {'env': f'0x{_lib.source_hash():016x}', 'learn': f'0x{_learn.source_hash():016x}', 'sac': f'0x{_sac.source_hash():016x}'}
+    d = {'_meta': {'source_hashes': hashes}, 'ppo/65536/48x16256': {'kernel_sum_ms_per_iteration': 4.9}, 'sac/4096/16': {'gradient_step_us': 109.0}}
+    (tmp_path / 'profiles' / bench.LEARNER_SUMS_FILE).write_text(json.dumps(d))
+    e, src = bench.learner_kernel_sum('ppo/65536/48x16256')
+    assert e['kernel_sum_ms_per_iteration'] == 4.9 and 'rocprofv3' in src
+    assert bench.learner_kernel_sum('ppo/16384/64x16256')[0] is None
+    d['_meta']['source_hashes'] = dict(hashes, sac='0x0')               # another SAC library: the PPO entry stays, the SAC entry goes
+    (tmp_path / 'profiles' / bench.LEARNER_SUMS_FILE).write_text(json.dumps(d))
+    assert bench.learner_kernel_sum('ppo/65536/48x16256')[0] is not None and bench.learner_kernel_sum('sac/4096/16')[0] is None
+    d['_meta']['source_hashes'] = dict(hashes, learn='0x0')
+    (tmp_path / 'profiles' / bench.LEARNER_SUMS_FILE).write_text(json.dumps(d))
+    assert bench.learner_kernel_sum('ppo/65536/48x16256')[0] is None and 'dropped' in bench.learner_kernel_sum('ppo/65536/48x16256')[1]

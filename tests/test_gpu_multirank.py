@@ -84,6 +84,10 @@ def test_bench_ppo_leg_two_ranks_on_one_gpu():
     assert p['n_gpus'] == 2 and p['seeds'] == [1] and p['iterations'][0] >= 3 and p['envs_per_gpu'] == 16384
     assert 200.0 < p['target_return'] < 250.0 and p['shipped_model_eval']['episodes'] == 1024    # the shipped model, randomised-init protocol
     assert p['best_eval_return'][0] > 0          # evaluations came back (the policy is far from trained in 3 s on a shared GPU)
+    # one diagnostic row per rank: how its data-parallel epoch ran, its iteration time, the spread (what a driver's --gpus N line is read by)
+    assert [q['rank'] for q in p['ranks']] == [0, 1] and all(q['dp_path'].startswith('eager') and q['iteration_ms'] > 0 for q in p['ranks'])
+    assert p['iteration_ms_max_over_ranks'] >= p['ranks'][0]['iteration_ms'] and p['iteration_ms_skew_max_minus_min'] >= 0
+    assert p['roofline']['flops_per_iteration'] > 1e10 and p['roofline']['frac_of_f32_mfma_peak'] > 0
 
 
 def test_train_ppo_two_ranks_stay_in_lock_step(tmp_path):
@@ -115,6 +119,8 @@ def test_bench_sac_leg_two_ranks_on_one_gpu():
     assert 'error' not in s, s
     assert s['n_gpus'] == 2 and s['fused_update'] is True and s['env_steps'][0] > 0 and s['gradient_steps'][0] > 0
     assert 150.0 < s['target_return'] < 250.0
+    assert [q['rank'] for q in s['ranks']] == [0, 1] and all(q['dp_path'] == 'eager' for q in s['ranks'])       # (gloo: no captured collectives)
+    assert s['roofline']['flops_per_gradient_step'] > 1e9
 
 
 def test_train_sac_two_ranks_stay_in_lock_step(tmp_path):

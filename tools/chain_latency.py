@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Serial-chain estimate of the engine-substep loop of a shipped task's specialised step kernel (one wave per SIMD regime).
 
-    python tools/chain_latency.py [task ...]        -> profiles/r05_chain_latency.json
+    python tools/chain_latency.py [task ...]        -> profiles/r06_chain_latency.json
 
 Compiles the float32 specialised build to assembly, takes the step kernel's longest backward-branch loop (the unrolled substep
 loop; kernels whose loop is fully unrolled — Quadrotor2D — have none and are reported from the whole integrator block between the
@@ -81,7 +81,7 @@ def main():
         print(task, json.dumps(e))
     res['_meta'] = {'source_hash': f'0x{_lib.source_hash():016x}', 'model': 'tools/isa_sim.py with profiles/r05_issue_rate.txt: one wave issues a VALU '
                     'instruction per 4.8 clocks, a dependent one per 8.4 (v_rcp 12.3, v_mad_u64_u32 8.8)', 'clock_GHz': CLOCK_GHZ}
-    json.dump(res, open(os.path.join(ROOT, 'profiles', 'r05_chain_latency.json'), 'w'), indent=1)
+    json.dump(res, open(os.path.join(ROOT, 'profiles', 'r06_chain_latency.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
