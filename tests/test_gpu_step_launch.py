@@ -71,3 +71,24 @@ def test_launch_thresholds_are_a_per_handle_setting():
     out = env.step_tensors(torch.zeros(128, 2, device=env.device))
     assert bool(torch.isfinite(out.obs).all())
     env.close()
+
+
+def test_env_random_state_carries_the_rng_layout_version():
+    """include/scg_hip.h: SCG_RNG_LAYOUT_VERSION — which bits of which Philox block feed which reset draw.  Checkpoints carry it; a state
+    saved under another layout (or before the field existed: rounds 1-4, layout 1) loads with a warning, not silently."""
+    import warnings
+    from safe_control_gym_amd.registration import load_task
+    from safe_control_gym_amd.vec_env import HipVecEnv
+    env_id, cfg = load_task('quadrotor_2D_track')
+    env = HipVecEnv(env_id, 128, seed=3, return_numpy=False, **cfg)
+    env.reset_tensors()
+    st = env.get_env_random_state()
+    assert st[0]['rng_layout_version'] == 2 == int(env._lib.scg_rng_layout_version())
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        env.set_env_random_state(st)                        # same layout: silent
+    old = [dict(st[0])]
+    old[0].pop('rng_layout_version')
+    with pytest.warns(UserWarning, match='Philox word layout 1'):
+        env.set_env_random_state(old)
+    env.close()

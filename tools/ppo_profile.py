@@ -28,7 +28,7 @@ def main():
     eval_env = HipVecEnv(env_id, 256, seed=222, return_numpy=False, policy=pol, **dict(cfg, randomized_init=False))
     pcfg = PPOConfig(hidden_dim=128, activation='tanh', use_gae=True, target_kl=0.03, opt_epochs=args.epochs,
                      mini_batch_size=args.minibatch, actor_lr=2e-3, critic_lr=2e-3, rollout_batch_size=args.envs,
-                     rollout_steps=args.rollout_steps, extra={'fused_update': not args.no_fused, 'fused_rollout': args.fused_rollout,
+                     rollout_steps=args.rollout_steps, extra={'fused_update': not args.no_fused, 'fused_rollout': args.fused_rollout, 'iteration_graph': False,   # (per-phase clocks need the phases as separate enqueues)
                             **({'minibatches_per_epoch': args.mb_per_epoch} if args.mb_per_epoch else {})})
     ppo = PPO(env, pcfg, seed=2)
     tot = {'collect': 0.0, 'update': 0.0, 'eval': 0.0}
