@@ -2,7 +2,9 @@
  * SACAgent.update (/root/reference/safe_control_gym/controllers/sac/sac_utils.py:110-170) on MI355X, fused.
  *
  * What one scg_sac_update call enqueues (8 kernels; no host synchronisation, exact float32, matrix products on
- * v_mfma_f32_32x32x2_f32, every reduction in a fixed order: the step is bitwise reproducible):
+ * v_mfma_f32_32x32x2_f32, every reduction in a fixed order: the step is bitwise reproducible).  A forward pass that feeds a
+ * gradient kernel leaves its activation tiles in the workspace (the actor's at obs; the critics' at (obs, act), evaluated next
+ * to the target networks), so the gradient kernels start at the loss derivatives:
  *   sample     batch rows ~ U[0, *d_ring_size) of the device replay ring (SACBuffer.sample, sac_utils.py:399-413)
  *   actor fwd  a, log pi = actor(obs) with the reparameterised tanh-Gaussian (sac_utils.py:185-222; log-prob correction
  *              2 (log 2 - u - softplus(-2u)))
@@ -83,6 +85,11 @@ size_t scg_sac_workspace_bytes(int batch);
  * operation).  scg_sac_update / scg_sac_act call it themselves otherwise. */
 int scg_sac_prepare(void);
 int scg_sac_update(const scg_sac_args* args, void* stream);
+/* n_steps whole gradient steps (args->phases must be 0), bit-identical to n_steps scg_sac_update calls, in 7 n_steps + 1 launches: step
+ * k's target-action launch (actor at next_obs) also draws step k + 1's minibatch rows and evaluates the actor at its obs rows — the
+ * critics' step between the two touches neither the actor nor the replay ring, and the two 128-workgroup jobs fill the chip together.
+ * What SACAgent.update's loop over `n_updates` gradient steps (sac.py:307-311 -> sac_utils.py:143-170) enqueues on one GPU. */
+int scg_sac_update_n(const scg_sac_args* args, int n_steps, void* stream);
 
 /* The deterministic actor on a batch (MLPActorCritic.act(obs, deterministic=True), sac_utils.py:258-262):
  * d_act_out[m][act_dim] = low + 0.5 (tanh(mu(obs)) + 1)(high - low).  Evaluation / acting without PyTorch kernels. */

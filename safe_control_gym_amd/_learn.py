@@ -11,7 +11,7 @@ from safe_control_gym_amd import _lib as L
 
 ACTS = {'tanh': 0, 'relu': 1, 'leaky_relu': 2}
 SRC = os.path.join(L.CSRC_DIR, 'scg_learn.hip')
-DEPS = [SRC, os.path.join(L.CSRC_DIR, 'scg_mlp.h'), os.path.join(L.CSRC_DIR, 'scg_once.h'), os.path.normpath(os.path.join(L.CSRC_DIR, '..', '..', 'include', 'scg_learn.h'))]
+DEPS = [SRC, os.path.join(L.CSRC_DIR, 'scg_adam.h'), os.path.join(L.CSRC_DIR, 'scg_mlp.h'), os.path.join(L.CSRC_DIR, 'scg_once.h'), os.path.normpath(os.path.join(L.CSRC_DIR, '..', '..', 'include', 'scg_learn.h'))]
 
 
 class MlpLayout(C.Structure):

@@ -9,7 +9,7 @@ from safe_control_gym_amd import _lib as L
 from safe_control_gym_amd._learn import ACTS, MlpLayout
 
 SRC = os.path.join(L.CSRC_DIR, 'scg_sac.hip')
-DEPS = [SRC, os.path.join(L.CSRC_DIR, 'scg_mlp.h'), os.path.join(L.CSRC_DIR, 'scg_once.h'), os.path.join(L.CSRC_DIR, 'scg_rng.h'),
+DEPS = [SRC, os.path.join(L.CSRC_DIR, 'scg_adam.h'), os.path.join(L.CSRC_DIR, 'scg_mlp.h'), os.path.join(L.CSRC_DIR, 'scg_once.h'), os.path.join(L.CSRC_DIR, 'scg_rng.h'),
         os.path.normpath(os.path.join(L.CSRC_DIR, '..', '..', 'include', 'scg_sac.h')),
         os.path.normpath(os.path.join(L.CSRC_DIR, '..', '..', 'include', 'scg_learn.h'))]
 
@@ -84,6 +84,7 @@ def lib(obs_dim, hidden, act_dim, activation):
     D.scg_sac_workspace_bytes.restype = C.c_size_t
     D.scg_sac_workspace_bytes.argtypes = [C.c_int]
     D.scg_sac_update.argtypes = [C.POINTER(SacArgs), C.c_void_p]
+    D.scg_sac_update_n.argtypes = [C.POINTER(SacArgs), C.c_int, C.c_void_p]
     D.scg_sac_act.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_void_p,
                               C.c_void_p]
     D.scg_sac_sample.argtypes = [C.c_void_p, C.POINTER(MlpLayout), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_uint64,

@@ -692,8 +692,12 @@ constexpr uint32_t RNG_CH_POLICY = 5;
 // lane (c, h) of both halves carries env c — the two halves simulate the same env redundantly (those lanes would idle
 // otherwise) and between them hold the two k-rows of the MFMA's B operand, so the actor is ONE tile per step with no lane
 // exchange; half 0 stores.  Twice the waves, each with half the matrix work per control step.
-template <int SYS, bool DIST, int EPW>
-__global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<float> I, const PolicyArgs A) {
+// WPW = waves per workgroup behind ONE weight image.  8 = two waves per SIMD (the kernel needs < 256 registers: h1 / h2 do not live
+// across the env step): a control step is ~290 dependent MFMAs per column tile followed layer by layer by the activations of 16 NT
+// values per lane on the vector unit (tanh: v_exp + v_rcp at quarter rate) and then the in-register simulation — with one wave per
+// SIMD the matrix pipe idles through both; a second wave's products run under them (round 6: 65 536 envs = 2048 waves of 32 envs).
+template <int SYS, bool DIST, int EPW, int WPW>
+__global__ __launch_bounds__(64 * WPW) void rollout_policy_kernel(const InstParams<float> I, const PolicyArgs A) {
     using T = float;
     using Ops = EnvOps<SYS, T, DIST, SCG_SEQ_ST_AUX>;
     using D = Dims<SYS>;
@@ -703,21 +707,21 @@ __global__ __launch_bounds__(256) void rollout_policy_kernel(const InstParams<fl
     using L = MlpLds<NIN, HID, NU, 16>;
     constexpr int L1Q = L::L1Q;
     extern __shared__ __align__(16) float lds[];
-    unsigned char* const s_obs = reinterpret_cast<unsigned char*>(lds + L::END);       // [4 waves][64 rows][NIN] transpose scratch
+    unsigned char* const s_obs = reinterpret_cast<unsigned char*>(lds + L::END);       // [WPW waves][64 rows][NIN] transpose scratch
     const PV<T> P{kcfg, I};
     const GoalTab<T> goal{nullptr, I.x_goal, false};
     {
         const MlpWeights w{A.params + A.W1, A.params + A.b1, A.params + A.W2, A.params + A.b2, A.params + A.W3, A.params + A.b3};
-        mlp_fill_lds<NIN, HID, NU, 16>(lds, w, threadIdx.x);
+        mlp_fill_lds<NIN, HID, NU, 16, 64 * WPW>(lds, w, threadIdx.x);
     }
     __syncthreads();
     const int N = I.num_envs;
     static_assert(EPW == 64 || EPW == 32, "envs per wave");
     const int lane = threadIdx.x & 63, h = lane >> 5;
-    const int i0 = EPW == 64 ? blockIdx.x * 256 + threadIdx.x : (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (lane & 31);
+    const int i0 = EPW == 64 ? blockIdx.x * (64 * WPW) + threadIdx.x : (blockIdx.x * WPW + (threadIdx.x >> 6)) * 32 + (lane & 31);
     const bool live = i0 < N && (EPW == 64 || h == 0);
     const int i = i0 < N ? i0 : N - 1;                // surplus lanes shadow the last env (they take part in the MFMAs, never store)
-    const bool full_wave = EPW == 64 && (blockIdx.x * 256 + (threadIdx.x & ~63) + 64) <= N;
+    const bool full_wave = EPW == 64 && (blockIdx.x * (64 * WPW) + (threadIdx.x & ~63) + 64) <= N;
     unsigned char* const s_wave = s_obs + (threadIdx.x >> 6) * (64 * NIN * (int)sizeof(T));
     typename Ops::E e;
     Ops::load_state(P, i, e);

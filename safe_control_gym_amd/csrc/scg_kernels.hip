@@ -818,23 +818,32 @@ extern "C" int scg_rollout_policy(scg_env* env, const scg_policy* pol, int k_ste
     A.ep_stats = (float*)out->d_ep_stats; A.episode_acc = (float*)out->d_episode_acc; A.max_episodes = out->max_episodes;
     const InstParams<float> I = inst_of<float>(env);
     constexpr int nobs = scg_make_spec_cfg<float>().nobs;
-    const size_t bytes = MlpLds<nobs, SCG_POLICY_H, Dims<S>::NU, 16>::END * sizeof(float) + 4 * 64 * nobs * sizeof(float);
-    // envs per wave: 32 while that still fits one wave per SIMD (4 x 256 CUs), else 64 (scg_env_kernels.h).  SCG_ROLLOUT_EPW = 32 | 64
-    // overrides (tests run both geometries on small batches; results do not depend on it: Philox streams are per env).
-    int epw = env->cfg.num_envs <= 32768 ? 32 : 64;
+    // Launch geometry (scg_env_kernels.h): envs per wave 32 while that gives at most two waves per SIMD (2 x 4 x 256 CUs), else 64; waves
+    // per workgroup 4 up to one wave per SIMD, 8 above (two waves per SIMD behind one weight image).  SCG_ROLLOUT_EPW = 32 | 64 and
+    // SCG_ROLLOUT_WPW = 4 | 8 override (tests run the geometries on small batches; results do not depend on them: Philox streams
+    // are per env, the MFMA sequence per env is the same).
+    int epw = env->cfg.num_envs <= 65536 ? 32 : 64;
+    int wpw = env->cfg.num_envs <= 32768 ? 4 : 8;
     if (const char* o = getenv("SCG_ROLLOUT_EPW")) { if (atoi(o) == 32 || atoi(o) == 64) epw = atoi(o); }
+    if (const char* o = getenv("SCG_ROLLOUT_WPW")) { if (atoi(o) == 4 || atoi(o) == 8) wpw = atoi(o); }
+    const size_t bytes = MlpLds<nobs, SCG_POLICY_H, Dims<S>::NU, 16>::END * sizeof(float) + (size_t)wpw * 64 * nobs * sizeof(float);
+    const size_t bytes8 = MlpLds<nobs, SCG_POLICY_H, Dims<S>::NU, 16>::END * sizeof(float) + (size_t)8 * 64 * nobs * sizeof(float);
     static scg::PerDeviceOnce attr;         // (per device, scg_once.h: the caller has made the handle's device current)
     int attr_dev;
     if (attr.pending(&attr_dev)) {
-        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes8));
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes8));
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes8));
+        HIP_TRY(hipFuncSetAttribute((const void*)rollout_policy_kernel<S, DD, 32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes8));
         attr.commit(attr_dev);
     }
-    if (epw == 64) {
-        rollout_policy_kernel<S, DD, 64><<<dim3((env->cfg.num_envs + 255) / 256), dim3(256), bytes, (hipStream_t)stream>>>(I, A);
-    } else {
-        rollout_policy_kernel<S, DD, 32><<<dim3((env->cfg.num_envs + 127) / 128), dim3(256), bytes, (hipStream_t)stream>>>(I, A);
-    }
+    const int per_wg = epw * wpw;
+    const dim3 grid((env->cfg.num_envs + per_wg - 1) / per_wg), block(64 * wpw);
+    hipStream_t st = (hipStream_t)stream;
+    if (epw == 64 && wpw == 4) rollout_policy_kernel<S, DD, 64, 4><<<grid, block, bytes, st>>>(I, A);
+    else if (epw == 64) rollout_policy_kernel<S, DD, 64, 8><<<grid, block, bytes, st>>>(I, A);
+    else if (wpw == 4) rollout_policy_kernel<S, DD, 32, 4><<<grid, block, bytes, st>>>(I, A);
+    else rollout_policy_kernel<S, DD, 32, 8><<<grid, block, bytes, st>>>(I, A);
     HIP_TRY(hipGetLastError());
     return SCG_OK;
 #else

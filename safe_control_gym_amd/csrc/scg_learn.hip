@@ -26,6 +26,7 @@
 #include <string>
 
 #include "../../include/scg_learn.h"
+#include "scg_adam.h"
 #include "scg_mlp.h"
 #include "scg_once.h"
 
@@ -81,14 +82,19 @@ __device__ __forceinline__ void load_x(const float* __restrict__ obs, int sample
 }
 
 // ------------------------------------------------------------------ batched forward (inference / tests)
+// FWD_WAVES = 8: TWO waves per SIMD behind one weight image (the kernel keeps h1 / h2 = 2 NT accumulator tiles per wave: <= 256 registers).
+// A tile is 32 NT (NT + L1Q / 16) dependent MFMAs followed, layer by layer, by the activation of 16 NT values per lane on the vector
+// unit (tanh = v_exp + v_rcp at quarter rate: ~40 % of the tile's time with one wave per SIMD, during which the matrix pipe idles);
+// a second wave's products run under it.
+constexpr int FWD_WAVES = 8;
 template <int NOUT>
-__global__ __launch_bounds__(256) void mlp_forward_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
+__global__ __launch_bounds__(64 * FWD_WAVES) void mlp_forward_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
                                                           const float* __restrict__ xin, int M, float* __restrict__ out,
                                                           const uint8_t* __restrict__ row_mask) {
     using L = MlpLds<NIN, HID, NOUT>;
     extern __shared__ __align__(16) float lds[];
     const MlpWeights w = weights_of(params, lay);
-    mlp_fill_lds<NIN, HID, NOUT>(lds, w, threadIdx.x);
+    mlp_fill_lds<NIN, HID, NOUT, 20, 64 * FWD_WAVES>(lds, w, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -629,39 +635,51 @@ __global__ __launch_bounds__(256) void ppo_reduce_adam_kernel(const StepArgs S) 
     const int kl_ = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kl_;
     const int words = net == 0 ? partial_words<NU>() : partial_words<1>();
+    // Request order (round 6): the approx-KL word of this thread's workgroup, what the word's OWNER needs for its Adam step (moments,
+    // parameter, step count — asked for behind the sum they were one more memory round trip at the end of every block), then ALL of
+    // this thread's partial words at once (32 at 127 workgroups; `unroll 8` made that four rounds of eight).  Every sum keeps its order.
+    constexpr int KW = GradLds<NU>::STAT + 1;               // the actor's approx-KL word
+    float klv = 0.0f;
+    if ((int)threadIdx.x < R.n_wg) klv = 0.0f + R.partials[((size_t)threadIdx.x * 2 + 0) * PARTIAL_STRIDE + KW];
+    const bool owner = grp == 0 && k < words;
+    const bool critic = net == 1;
+    int d = -1;
+    float o_p = 0.0f, o_m = 0.0f, o_v = 0.0f, o_t = 0.0f;
+    if (owner) {
+        d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
+        if (d >= 0) { o_p = S.p[d]; o_m = S.m[d]; o_v = S.v[d]; o_t = S.steps_in[critic ? 1 : 0]; }
+    }
+    float s = 0.0f;
+    if (k < words) {
+        const float* const src = R.partials + ((size_t)grp * 2 + net) * PARTIAL_STRIDE + k;       // workgroups grp, grp + 4, ...
+        const int mine = (R.n_wg - grp + 3) / 4;
+        for (int g0 = 0; g0 < mine; g0 += 32) {
+            float v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = g0 + j < mine ? src[(size_t)(g0 + j) * 8 * PARTIAL_STRIDE] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { if (g0 + j < mine) s += v[j]; }
+        }
+    }
     {
-        constexpr int KW = GradLds<NU>::STAT + 1;           // the actor's approx-KL word
-        float v = 0.0f;
-        for (int g = threadIdx.x; g < R.n_wg; g += 256) v += R.partials[((size_t)g * 2 + 0) * PARTIAL_STRIDE + KW];
+        float v = klv;
+        for (int g = threadIdx.x + 256; g < R.n_wg; g += 256) v += R.partials[((size_t)g * 2 + 0) * PARTIAL_STRIDE + KW];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         if (kl_ == 0) klw[grp] = v;
     }
-    float s = 0.0f;
-    if (k < words) {
-#pragma unroll 8
-        for (int g = grp; g < R.n_wg; g += 4) s += R.partials[((size_t)g * 2 + net) * PARTIAL_STRIDE + k];
-    }
     part[grp][kl_] = s;
     __syncthreads();
-    if (grp != 0 || k >= words) return;
+    if (!owner) return;
     s = (part[0][kl_] + part[1][kl_]) + (part[2][kl_] + part[3][kl_]);
     const float kl = (klw[0] + klw[1]) + (klw[2] + klw[3]);
     const bool gate = S.target_kl <= 0.0f || kl <= 1.5f * S.target_kl;
-    const int d = net == 0 ? dest_of<NU>(k, R.actor, R.logstd_off, true) : dest_of<1>(k, R.critic, 0, false);
     if (d >= 0) {
         if (net == 0 && d >= R.logstd_off && d < R.logstd_off + NU) s -= R.entropy_coef;   // d (c_ent * entropy_loss) / d logstd
         R.grad[d] = s;
-        const bool critic = net == 1;
         if (critic || gate) {
-            const float t = S.steps_in[critic ? 1 : 0] + 1.0f;
-            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-            const float m = b1 * S.m[d] + (1.0f - b1) * s;
-            const float v = b2 * S.v[d] + (1.0f - b2) * s * s;
-            S.m[d] = m; S.v[d] = v;
-            const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-            const float lr = critic ? S.lr_critic : S.lr_actor;
-            S.p[d] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
+            adam_element(o_p, s, o_m, o_v, critic ? S.lr_critic : S.lr_actor, o_t + 1.0f);
+            S.m[d] = o_m; S.v[d] = o_v; S.p[d] = o_p;
         }
     } else if (d == -2) {                                   // loss sum
         R.stats[net == 0 ? 0 : 1] = s;
@@ -699,15 +717,10 @@ __global__ __launch_bounds__(256) void adam_gated_kernel(const AdamArgs A) {
     if (e < A.n) {
         const bool critic = e >= A.n_actor;
         if (critic || gate) {
-            const float t = critic ? t_critic : t_actor;
-            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-            const float g = A.g[e] * A.gscale;
-            const float m = b1 * A.m[e] + (1.0f - b1) * g;
-            const float v = b2 * A.v[e] + (1.0f - b2) * g * g;
-            A.m[e] = m; A.v[e] = v;
-            const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-            const float lr = critic ? A.lr_critic : A.lr_actor;
-            A.p[e] -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
+            const float g = __fmul_rn(A.g[e], A.gscale);
+            float p = A.p[e], m = A.m[e], v = A.v[e];
+            adam_element(p, g, m, v, critic ? A.lr_critic : A.lr_actor, critic ? t_critic : t_actor);
+            A.m[e] = m; A.v[e] = v; A.p[e] = p;
         }
     }
     __syncthreads();
@@ -799,20 +812,20 @@ extern "C" int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layo
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 2) n_cu = v;
         else n_cu = 256;
     }
-    const int grid = std::min(std::max(n_cu - 2, 1), (m + 127) / 128);
+    const int grid = std::min(std::max(n_cu - 2, 1), (m + 32 * FWD_WAVES - 1) / (32 * FWD_WAVES));
     hipStream_t st = (hipStream_t)stream;
     if (nout == NU) {
         const size_t bytes = MlpLds<NIN, HID, NU>::END * sizeof(float);
         static scg::PerDeviceOnce set_a;    // (once per device: the attribute call costs more host time than the launch)
         int dev;
         if (set_a.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_a.commit(dev); }
-        mlp_forward_kernel<NU><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
+        mlp_forward_kernel<NU><<<dim3(grid), dim3(64 * FWD_WAVES), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else if (nout == 1) {
         const size_t bytes = MlpLds<NIN, HID, 1>::END * sizeof(float);
         static scg::PerDeviceOnce set_c;
         int dev;
         if (set_c.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_c.commit(dev); }
-        mlp_forward_kernel<1><<<dim3(grid), dim3(256), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
+        mlp_forward_kernel<1><<<dim3(grid), dim3(64 * FWD_WAVES), bytes, st>>>(d_params, *layout, d_x, m, d_out, d_row_mask);
     } else {
         return fail(-1, "scg_mlp_forward: this library serves nout = act_dim or 1");
     }

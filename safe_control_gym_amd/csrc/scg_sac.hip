@@ -32,6 +32,7 @@
 #include <string>
 
 #include "../../include/scg_sac.h"
+#include "scg_adam.h"
 #include "scg_mlp.h"
 #include "scg_once.h"
 #include "scg_rng.h"
@@ -91,6 +92,22 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sum over lanes 0..31 of v, valid in lane 0: through 32 words of the wave's LDS (one 4-byte write per lane, eight 16-byte reads in lane 0,
+// a fixed order) — a butterfly over the lanes is 5-6 dependent ds_bpermute round trips.
+__device__ __forceinline__ float row_sum32(float* row, float v, int lane) {
+    if (lane < 32) row[lane] = v;
+    wave_sync();
+    float s = 0.0f;
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(row + 4 * g);
+            s += d4.x; s += d4.y; s += d4.z; s += d4.w;
+        }
+    }
+    return s;
 }
 
 // x[q] = input feature row(q, h) of one sample, the input being [a [NA_] | b [NB_]] (rows >= NA_ + NB_ are zero)
@@ -425,6 +442,9 @@ __device__ __forceinline__ void forward(const float* sm, float* xch, const float
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = mlp_act<ACT2>(acc[q]);
     h2 = acc;
+    // (all outputs' partial sums first, then the NOUT lane-half exchanges back to back: written per output — sum, exchange, store — the
+    //  exchanges were NOUT dependent LDS round trips in a row, 8 for the actor's head)
+    float so[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
         float s = 0.0f;
@@ -434,8 +454,14 @@ __device__ __forceinline__ void forward(const float* sm, float* xch, const float
             s = __builtin_fmaf(w.x, h2[4 * g], s); s = __builtin_fmaf(w.y, h2[4 * g + 1], s);
             s = __builtin_fmaf(w.z, h2[4 * g + 2], s); s = __builtin_fmaf(w.w, h2[4 * g + 3], s);
         }
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) xch[X::RED + (wave * 8 + o) * 32 + c] = s;
+        so[o] = s;
+    }
+    float sx[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) sx[o] = __shfl_xor(so[o], 32, 64);
+    if (h == 0) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) xch[X::RED + (wave * 8 + o) * 32 + c] = so[o] + sx[o];
     }
     __syncthreads();
 #pragma unroll
@@ -447,13 +473,25 @@ __device__ __forceinline__ void forward(const float* sm, float* xch, const float
     }
 }
 
+// the wave's own sample cache for the dW1 product: xs[column][sample], a ones row and a zeros row behind the inputs
+template <int NIN, int L1Q>
+__device__ __forceinline__ void cache_x(float* xs, const float* x, int c, int h) {
+#pragma unroll
+    for (int q = 0; q < L1Q; ++q) {
+        const int f = d_row(q, 0);
+        if (f + 4 < NIN) xs[(f + 4 * h) * 32 + c] = x[q];
+        else if (f < NIN) { if (h == 0) xs[f * 32 + c] = x[q]; }
+    }
+    if (h == 0) { xs[NIN * 32 + c] = 1.0f; xs[(NIN + 1) * 32 + c] = 0.0f; }
+}
+
 // Backward pass of the workgroup's tile (see the scheme above).  h1, h2: this wave's tiles from forward(); dout: d loss / d out of
 // this lane's sample (identical in every wave).  WGRAD: this wave's slices of the weight / bias gradients into the workgroup's
 // partial vector P;  DIN: din[j] = d loss / d input[NIN - NU + j] of this lane's sample (every wave).  One workgroup barrier
 // (two with DIN); the caller barriers before the next tile's forward().
 template <int NIN, int NOUT, int ACT2, bool WGRAD, bool DIN, int TL = -1>
 __device__ __forceinline__ void backward(const float* sm, float* xch, const float (&bt)[NT][16], f32x16& h1, f32x16& h2,
-                                         const float* dout, int wave, int lane, float* P, bool first, float* din) {
+                                         const float* dout, int wave, int lane, float* P, bool first, float* din, const float* xin = nullptr) {
     using S = Small<NOUT>;
     using X = Xch;
     using G = Part<NIN, NOUT>;
@@ -466,20 +504,24 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) dout_l[o * 32 + c] = dout[o];
         }
-        if (wave == 0) {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {                            // db3: sum over the tile's 32 samples
-                float v = dout[o];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-                if (lane == 0) padd(P + G::DB3 + o, v, first);
-            }
-        }
         wave_sync();
+        // db3: lane o of the LAST wave sums row o of the LDS copy (8 x 16-byte reads, a fixed order).  (As a butterfly over the lanes it was
+        // 5 dependent ds_bpermute round trips per output, and the branches of the stores in between kept the compiler from overlapping the
+        // outputs' chains: 40 in a row for the actor's head — ~2 us in front of the workgroup barrier, tools/sac_timeline.py.)
+        if (wave == NT - 1 && lane < NOUT) {
+            float v = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dout_l + lane * 32 + 4 * g);
+                v += d4.x; v += d4.y; v += d4.z; v += d4.w;
+            }
+            padd(P + G::DB3 + lane, v, first);
+        }
         float t[16];
         tile_transpose(scr, h2, t, lane);                               // t[q] = h2[feature 32 wave + c][sample row(q, h)]
+        float a3[NOUT];                                                 // dW3[o][f] = sum_s h2[f][s] dout[o][s]: all outputs, then the exchanges
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {                                // dW3[o][f] = sum_s h2[f][s] dout[o][s]
+        for (int o = 0; o < NOUT; ++o) {
             float acc = 0.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -487,8 +529,20 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
                 acc = __builtin_fmaf(t[4 * g], dv.x, acc); acc = __builtin_fmaf(t[4 * g + 1], dv.y, acc);
                 acc = __builtin_fmaf(t[4 * g + 2], dv.z, acc); acc = __builtin_fmaf(t[4 * g + 3], dv.w, acc);
             }
-            acc += __shfl_xor(acc, 32, 64);
-            if (h == 0) padd(P + G::DW3 + o * HID + 32 * wave + c, acc, first);
+            a3[o] = acc;
+        }
+        float x3[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) x3[o] = __shfl_xor(a3[o], 32, 64);
+        if (h == 0) {
+            float* const p3 = P + G::DW3 + 32 * wave + c;
+            if (first) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) p3[o * HID] = a3[o] + x3[o];
+            } else {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) p3[o * HID] += a3[o] + x3[o];
+            }
         }
     }
     if constexpr (TL >= 0) SCG_S_STAMP(TL, 4);
@@ -516,6 +570,12 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
         tile_transpose_inplace(scr, h1, lane);                          // h1[in 32 wave + c][sample row(q, h)]
         put_tile(xch + X::H1T + wave * XT + lane * XW, h1);
     }
+    if constexpr (WGRAD) {
+        // the tile's input rows -> the wave's sample cache (dW1's operand).  Here, not at the top of the tile: the rows are an index -> row
+        // gather, two dependent memory round trips that nothing in front of this point has to wait for
+        constexpr int L1Q = 4 * ((NIN + 7) / 8);
+        cache_x<NIN, L1Q>(xs, xin, c, h);
+    }
     if constexpr (TL >= 0) SCG_S_STAMP(TL, 5);
     __syncthreads();
     if constexpr (TL >= 0) SCG_S_STAMP(TL, 6);
@@ -539,6 +599,7 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
     if constexpr (DIN) {
         // d loss / d (action inputs): this wave's 32 features, then the waves' partials through the LDS
         static_assert(!WGRAD, "the input gradient is taken from the plain data gradient");
+        float sj[NU], xj[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             float s = 0.0f;
@@ -548,8 +609,13 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
                 s = __builtin_fmaf(wv.x, acc[4 * g], s); s = __builtin_fmaf(wv.y, acc[4 * g + 1], s);
                 s = __builtin_fmaf(wv.z, acc[4 * g + 2], s); s = __builtin_fmaf(wv.w, acc[4 * g + 3], s);
             }
-            s += __shfl_xor(s, 32, 64);
-            if (h == 0) xch[X::DIN + (wave * 4 + j) * 32 + c] = s;
+            sj[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) xj[j] = __shfl_xor(sj[j], 32, 64);
+        if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) xch[X::DIN + (wave * 4 + j) * 32 + c] = sj[j] + xj[j];
         }
         __syncthreads();
 #pragma unroll
@@ -607,61 +673,79 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
     }
 }
 
-// the wave's own sample cache for the dW1 product: xs[column][sample], a ones row and a zeros row behind the inputs
-template <int NIN, int L1Q>
-__device__ __forceinline__ void cache_x(float* xs, const float* x, int c, int h) {
+// ---- a wave's activation tiles across launches.  The forward pass that FEEDS a gradient kernel runs in the launch before it (the actor
+// at obs: actor_fwd_kernel; the critics at (obs, act): q_kernel<0>'s online blocks), which leaves every wave's h1 / h2 tile — accumulator
+// layout, read back by the same (tile, wave, lane) — in the workspace: [tile][wave][g][lane][4], 16-byte accesses, 1 KB per instruction.
+// The gradient kernels then START at the loss derivatives: no operand loads for the forward products, no forward pass, no tanh-Gaussian
+// algebra on their critical path (round 6's timeline of actor_grad_kernel: 4.8 + 1.5 of the 18.9 us a wave lived).
+__device__ __forceinline__ void act_store(float* __restrict__ base, int tile, int wave, int lane, const f32x16& t) {
+    float* const p = base + (((size_t)tile * NT + wave) * 4 * 64 + lane) * 4;
 #pragma unroll
-    for (int q = 0; q < L1Q; ++q) {
-        const int f = d_row(q, 0);
-        if (f + 4 < NIN) xs[(f + 4 * h) * 32 + c] = x[q];
-        else if (f < NIN) { if (h == 0) xs[f * 32 + c] = x[q]; }
-    }
-    if (h == 0) { xs[NIN * 32 + c] = 1.0f; xs[(NIN + 1) * 32 + c] = 0.0f; }
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(p + g * 256) = (f32x4){t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
 }
+__device__ __forceinline__ void act_load(const float* __restrict__ base, int tile, int wave, int lane, f32x16& t) {
+    const float* const p = base + (((size_t)tile * NT + wave) * 4 * 64 + lane) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + g * 256);
+        t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+    }
+}
+constexpr int HEADW = 3 * NU;                   // per batch row, [j][B]: tanh u | sigma | clamp pass (what the policy gradient needs of the head)
 
 // ---- kernels: gridDim.x workgroups of NT waves walk the 32-row tiles
-// actor forward on obs rows idx (use_next = 0) or next_obs rows (1): eps, action, log pi per batch row.
-// idx_out != nullptr (first launch of an update): the launch also DRAWS the minibatch rows and leaves them in idx_out for the later
-// launches, and snapshots log_alpha (la_out) as the policy loss sees it — a sampling launch and a 4-byte copy less
-__global__ __launch_bounds__(64 * NT, 1) void actor_fwd_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
-                                                                int use_next, const float* __restrict__ eps_in, uint32_t stream,
-                                                                float* __restrict__ eps_out, float* __restrict__ a_out,
-                                                                float* __restrict__ logp_out, int32_t* __restrict__ idx_out,
-                                                                const int32_t* __restrict__ ring_size, const int32_t* __restrict__ idx_in,
-                                                                float* __restrict__ la_out) {
+// One actor forward job: rows `idx` (or, with idx_out, DRAWN here ~ U[0, ring size) and kept for the later launches) of `src`; noise,
+// action, log pi per batch row; optionally (head / h1s / h2s) what actor_grad_kernel needs of this pass.
+struct AfJob {
+    const float* src;                           // obs (policy loss) or next_obs (target action)
+    const int32_t* idx; int32_t* idx_out; const int32_t* ring_size; const int32_t* idx_in;
+    const float* eps_in; uint32_t stream; uint32_t cnt_add;
+    float* eps_out; float* a_out; float* logp_out;
+    float* la_out;                              // nullable: snapshot of log_alpha as the policy loss sees it
+    float* head; float* h1s; float* h2s;        // nullable
+};
+// blockIdx.y selects the job.  Two jobs in one launch (scg_sac_update_n): the target action of step k (next_obs, the actor step k just
+// updated) and the policy-loss action of step k + 1 (obs, the same actor — the critics' step in between does not touch it): 2 x 128
+// workgroups fill the chip where each launch alone left half of it idle, and step k + 1 starts at q_kernel<1>.
+__global__ __launch_bounds__(64 * NT, 2) void actor_fwd_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
+                                                                const AfJob J0, const AfJob J1) {
     constexpr int L1Q = 4 * ((NOBS + 7) / 8);
     extern __shared__ __align__(16) float lds[];
+    const AfJob& J = blockIdx.y ? J1 : J0;
     const MlpWeights w = weights_of(params, lay);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    const int n_tiles = Cm.batch / 32;
-    const float* src = use_next ? Cm.next_obs : Cm.obs;
-    const uint32_t cnt = *Cm.counter;
-    // request order (see small_load): the first tile's row index, the small block, the layer operands, the row itself
+    const int n_tiles = Cm.batch / 32, B = Cm.batch;
+    const float* const src = J.src;
+    const float* const eps_in = J.eps_in;
+    int32_t* const idx_out = J.idx_out;
+    const uint32_t cnt = *Cm.counter + J.cnt_add;
+    // request order (see small_load): the first tile's row index (gridDim.x <= n_tiles: unconditional), the small block, the layer
+    // operands, the row itself.  A job that DRAWS its rows computes the index behind the operand requests: the Philox block waits for the
+    // counter word, and in front of them that wait was a whole memory round trip with nothing else in flight.
     const int tile0 = blockIdx.x, r0 = tile0 * 32 + c;
     int s0 = 0;
-    if (tile0 < n_tiles) s0 = idx_out ? sample_row(r0, ring_size, idx_in, cnt, Cm.k0, Cm.k1) : Cm.idx[r0];
+    if (!idx_out) s0 = J.idx[r0];
     SmallRegs<NA> sr;
     small_load<NA>(sr, w, threadIdx.x);
     float a1[L1Q], a2[NT][16];
     load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
     load_a2(w.W2, wave, lane, a2);
+    if (idx_out) s0 = sample_row(r0, J.ring_size, J.idx_in, cnt, Cm.k0, Cm.k1);
     float x[L1Q], eps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (tile0 < n_tiles) {
-        load_x2<L1Q, NOBS, 0>(src + (size_t)s0 * NOBS, nullptr, h, x);
-        if (eps_in) {
+    load_x2<L1Q, NOBS, 0>(src + (size_t)s0 * NOBS, nullptr, h, x);
+    if (eps_in) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r0 * NU + j];
-        }
+        for (int j = 0; j < NU; ++j) eps[j] = eps_in[(size_t)r0 * NU + j];
     }
     small_store<NA>(lds, sr, threadIdx.x);
     float* const xch = lds + Small<NA>::END;
-    if (la_out && blockIdx.x == 0 && threadIdx.x == 0) *la_out = *Cm.log_alpha;
+    if (J.la_out && blockIdx.x == 0 && threadIdx.x == 0) *J.la_out = *Cm.log_alpha;
     __syncthreads();
     for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
         const int r = tile * 32 + c;
         int s = s0;
         if (tile != tile0) {
-            s = idx_out ? sample_row(r, ring_size, idx_in, cnt, Cm.k0, Cm.k1) : Cm.idx[r];
+            s = idx_out ? sample_row(r, J.ring_size, J.idx_in, cnt, Cm.k0, Cm.k1) : J.idx[r];
             load_x2<L1Q, NOBS, 0>(src + (size_t)s * NOBS, nullptr, h, x);
             if (eps_in) {
 #pragma unroll
@@ -672,121 +756,172 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_fwd_kernel(const float* __re
         f32x16 h1, h2;
         float out[NA], u[NU], th[NU], sig[NU], a[NU], logp;
         forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
+        if (J.h1s) { act_store(J.h1s, tile, wave, lane, h1); act_store(J.h2s, tile, wave, lane, h2); }
         if (wave == 0) {
-            if (!eps_in) normal4(cnt, (uint32_t)r, stream, Cm.k0, Cm.k1, eps);
+            if (!eps_in) normal4(cnt, (uint32_t)r, J.stream, Cm.k0, Cm.k1, eps);
             squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
             if (h == 0) {
 #pragma unroll
-                for (int j = 0; j < NU; ++j) { eps_out[(size_t)r * NU + j] = eps[j]; a_out[(size_t)r * NU + j] = a[j]; }
-                logp_out[r] = logp;
+                for (int j = 0; j < NU; ++j) { J.eps_out[(size_t)r * NU + j] = eps[j]; J.a_out[(size_t)r * NU + j] = a[j]; }
+                J.logp_out[r] = logp;
+                if (J.head) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) {
+                        const float raw = out[NU + j];
+                        J.head[(size_t)j * B + r] = th[j];
+                        J.head[(size_t)(NU + j) * B + r] = sig[j];
+                        J.head[(size_t)(2 * NU + j) * B + r] = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;      // torch.clamp's gradient
+                    }
+                }
             }
         }
     }
 }
 
-// Q networks, blockIdx.y = which (q1 / q2).
-//   MODE 0: target networks at (next_obs[idx], a_in[row])                 -> q_out[y][row]
-//   MODE 1: online networks at (obs[idx], a_in[row]), data gradient       -> q_out[y][row], dqda[y][row][NU]
-//   MODE 2: online networks at (obs[idx], act[idx]): d mean (q - y)^2 / d(theta_y) into the workgroups' partials,
-//           y = rew + gamma mask (min(qt1, qt2) - alpha logp_next)
+// Q networks.
+//   MODE 0: forward only, blockIdx.y = y + 2 * online:
+//             online = 0: TARGET network y at (next_obs[idx], a_in[row])          -> q_out[y][row]
+//             online = 1: ONLINE network y at (obs[idx], act[idx])                -> qo[y][row] and the waves' h1 / h2 tiles, for MODE 2
+//           (the second kind does not depend on the first: it is the forward half of the critic loss, run here next to the targets
+//            instead of behind them)
+//   MODE 1: online networks at (obs[idx], a_in[row]), data gradient       -> q_out[y][row], dqda[y][row][NU]; blockIdx.y = y
+//   MODE 2: backward only, blockIdx.y = y: d mean (q - y)^2 / d(theta_y) into the workgroups' partials, q = qo[y][row] and the stored
+//           tiles, y = rew + gamma mask (min(qt1, qt2) - alpha logp_next)
+struct QAct { float* qo; float* h1s; float* h2s; float* rew; float* mask; };     // [2][B], [2][B / 32 tiles][NT][1024] each, [B], [B]
 template <int MODE>
-__global__ __launch_bounds__(64 * NT, 1) void q_kernel(const float* __restrict__ params, const scg_mlp_layout lay1, const scg_mlp_layout lay2,
+__global__ __launch_bounds__(64 * NT, MODE == 0 ? 2 : 1) void q_kernel(const float* __restrict__ params, const float* __restrict__ params_online,
+                                                        const scg_mlp_layout lay1, const scg_mlp_layout lay2,
                                                         const Common Cm, const float* __restrict__ a_in, const float* __restrict__ qt,
                                                         const float* __restrict__ logp_next, float* __restrict__ q_out,
-                                                        float* __restrict__ dqda, float* __restrict__ partials) {
+                                                        float* __restrict__ dqda, const QAct QA, float* __restrict__ partials) {
     using S = Small<1>;
     using G = Part<NQ, 1>;
     constexpr int L1Q = 4 * ((NQ + 7) / 8);
     extern __shared__ __align__(16) float lds[];
-    const int y = blockIdx.y;
-    const MlpWeights w = weights_of(params, y ? lay2 : lay1);
+    const int y = blockIdx.y & 1;
+    const bool online = MODE == 0 && (blockIdx.y >> 1);
+    const MlpWeights w = weights_of(online ? params_online : params, y ? lay2 : lay1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const int n_tiles = Cm.batch / 32, B = Cm.batch;
-    // request order (see small_load): the first tile's row index, the small block, the forward operands, the row's values;
-    // the backward operand (bt) is requested behind the barrier and arrives under the forward pass
     const int tile0 = blockIdx.x, r0 = tile0 * 32 + c;
-    const int s0 = tile0 < n_tiles ? Cm.idx[r0] : 0;
+    const int s0 = Cm.idx[r0];                                          // (gridDim.x <= n_tiles; unconditional: see actor_grad_kernel)
     SmallRegs<1> sr;
     small_load<1>(sr, w, threadIdx.x);
-    float w1a[(NU * HID + 64 * NT - 1) / (64 * NT)];
-    if constexpr (MODE == 1) {                                          // W1A[j][f] = W1[f][NOBS + j]
-#pragma unroll
-        for (int j = 0; j < (NU * HID + 64 * NT - 1) / (64 * NT); ++j) {
-            const int k = threadIdx.x + j * 64 * NT;
-            w1a[j] = k < NU * HID ? w.W1[(size_t)(k % HID) * NQ + NOBS + k / HID] : 0.0f;
-        }
-    }
-    float a1[L1Q], a2[NT][16], bt[NT][16];
-    load_a1<NQ, L1Q>(w.W1, wave, lane, a1);
-    load_a2(w.W2, wave, lane, a2);
-    float x[L1Q], v_rew = 0.0f, v_mask = 0.0f, v_qt1 = 0.0f, v_qt2 = 0.0f, v_lpn = 0.0f;
-    auto load_row = [&](int r, int s) {
-        if constexpr (MODE == 0) load_x2<L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
-        else if constexpr (MODE == 1) load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
-        else {
-            load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
-            v_rew = Cm.rew[s]; v_mask = Cm.mask[s]; v_qt1 = qt[r]; v_qt2 = qt[B + r]; v_lpn = logp_next[r];
-        }
-    };
-    if (tile0 < n_tiles) load_row(r0, s0);
-    small_store<1>(lds, sr, threadIdx.x);
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int j = 0; j < (NU * HID + 64 * NT - 1) / (64 * NT); ++j) {
-            const int k = threadIdx.x + j * 64 * NT;
-            if (k < NU * HID) lds[S::W1A + k] = w1a[j];
-        }
-    }
-    __syncthreads();
-    if constexpr (MODE != 0) load_bt(w.W2, wave, lane, bt);
     float* const xch = lds + S::END;
-    float* const xs = xch + Xch::WAVE + wave * Xch::WAVE_WORDS + TR_WORDS;
-    float* const P = partials ? partials + ((size_t)y * Cm.n_part + blockIdx.x) * PSTRIDE : nullptr;
-    const float alpha = MODE == 2 ? expf(*Cm.log_alpha) : 0.0f;
-    const float inv_b = 1.0f / (float)B;
-    float st = 0.0f;
-    bool first = true;
-    for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
-        const int r = tile * 32 + c;
-        if (tile != tile0) load_row(r, Cm.idx[r]);
+    if constexpr (MODE == 2) {
+        // ---- backward only.  Request order: row index, small block, the tiles and the row's values, the data-gradient operand
+        float bt[NT][16];
+        const float* const h1s = QA.h1s + (size_t)y * B * HID;
+        const float* const h2s = QA.h2s + (size_t)y * B * HID;
         f32x16 h1, h2;
-        float out[1];
-        forward<NQ, 1, ACT>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
-        if constexpr (MODE == 0) {
-            if (wave == 0 && h == 0) q_out[(size_t)y * B + r] = out[0];
-        } else if constexpr (MODE == 1) {
-            const float dout[1] = {1.0f};
-            float din[NU];
-            backward<NQ, 1, ACT, false, true>(lds, xch, bt, h1, h2, dout, wave, lane, nullptr, true, din);
-            if (wave == 0 && h == 0) {
-                q_out[(size_t)y * B + r] = out[0];
-#pragma unroll
-                for (int j = 0; j < NU; ++j) dqda[((size_t)y * B + r) * NU + j] = din[j];
-            }
-        } else {
-            cache_x<NQ, L1Q>(xs, x, c, h);
+        float x[L1Q], v_rew = 0.0f, v_mask = 0.0f, v_qt1 = 0.0f, v_qt2 = 0.0f, v_lpn = 0.0f, v_q = 0.0f;
+        // (reward and mask by BATCH row, left by q_kernel<0>'s online blocks: nothing the loss derivative needs waits for the row index)
+        auto load_row = [&](int tile, int r) {
+            act_load(h1s, tile, wave, lane, h1); act_load(h2s, tile, wave, lane, h2);
+            v_q = QA.qo[(size_t)y * B + r]; v_qt1 = qt[r]; v_qt2 = qt[B + r]; v_lpn = logp_next[r];
+            v_rew = QA.rew[r]; v_mask = QA.mask[r];
+        };
+        auto load_in = [&](int s) { load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x); };
+        load_row(tile0, r0);
+        load_bt(w.W2, wave, lane, bt);                                  // (see actor_grad_kernel)
+        load_in(s0);
+        small_store<1>(lds, sr, threadIdx.x);
+        __syncthreads();
+        float* const P = partials + ((size_t)y * Cm.n_part + blockIdx.x) * PSTRIDE;
+        const float alpha = expf(*Cm.log_alpha);
+        const float inv_b = 1.0f / (float)B;
+        float st = 0.0f;
+        bool first = true;
+        for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
+            const int r = tile * 32 + c;
+            if (tile != tile0) { load_row(tile, r); load_in(Cm.idx[r]); }
             const float target = v_rew + Cm.gamma * v_mask * (fminf(v_qt1, v_qt2) - alpha * v_lpn);
-            const float e = out[0] - target;
+            const float e = v_q - target;
             const float dout[1] = {2.0f * e * inv_b};
             if (wave == 0 && h == 0) st += e * e * inv_b;
-            backward<NQ, 1, ACT, true, false>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr);
+            backward<NQ, 1, ACT, true, false>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr, x);
             first = false;
+            __syncthreads();                                            // the exchange buffers are free for the next tile
         }
-        __syncthreads();                                                // the exchange buffers are free for the next tile
-    }
-    if constexpr (MODE == 2) {
-        if (wave == 0) {
+        if (wave == 0) {                                                // (st lives in the lanes of half 0)
+            const float v = row_sum32(xch + Xch::WAVE + TR_WORDS + 34 * 32, st, lane);
+            if (lane == 0) { P[G::STAT] = v; P[G::STAT + 1] = 0.0f; }
+        }
+    } else {
+        // request order (see small_load): the first tile's row index, the small block, the forward operands, the row's values;
+        // the backward operand (bt) is requested behind the barrier and arrives under the forward pass
+        float w1a[(NU * HID + 64 * NT - 1) / (64 * NT)];
+        if constexpr (MODE == 1) {                                      // W1A[j][f] = W1[f][NOBS + j]
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) st += __shfl_xor(st, m, 64);
-            if (lane == 0) { P[G::STAT] = st; P[G::STAT + 1] = 0.0f; }
+            for (int j = 0; j < (NU * HID + 64 * NT - 1) / (64 * NT); ++j) {
+                const int k = threadIdx.x + j * 64 * NT;
+                w1a[j] = k < NU * HID ? w.W1[(size_t)(k % HID) * NQ + NOBS + k / HID] : 0.0f;
+            }
+        }
+        float a1[L1Q], a2[NT][16];
+        load_a1<NQ, L1Q>(w.W1, wave, lane, a1);
+        load_a2(w.W2, wave, lane, a2);
+        float x[L1Q], v_rew = 0.0f, v_mask = 0.0f;
+        auto load_row = [&](int r, int s) {
+            if constexpr (MODE == 0) {
+                if (online) {
+                    load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, Cm.act + (size_t)s * NU, h, x);
+                    if (y == 0) { v_rew = Cm.rew[s]; v_mask = Cm.mask[s]; }
+                } else load_x2<L1Q, NOBS, NU>(Cm.next_obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+            } else {
+                load_x2<L1Q, NOBS, NU>(Cm.obs + (size_t)s * NOBS, a_in + (size_t)r * NU, h, x);
+            }
+        };
+        load_row(r0, s0);
+        small_store<1>(lds, sr, threadIdx.x);
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < (NU * HID + 64 * NT - 1) / (64 * NT); ++j) {
+                const int k = threadIdx.x + j * 64 * NT;
+                if (k < NU * HID) lds[S::W1A + k] = w1a[j];
+            }
+        }
+        __syncthreads();
+        float bt[MODE == 1 ? NT : 1][16];
+        if constexpr (MODE == 1) load_bt(w.W2, wave, lane, bt);
+        for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
+            const int r = tile * 32 + c;
+            if (tile != tile0) load_row(r, Cm.idx[r]);
+            f32x16 h1, h2;
+            float out[1];
+            forward<NQ, 1, ACT>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
+            if constexpr (MODE == 0) {
+                if (online) {
+                    act_store(QA.h1s + (size_t)y * B * HID, tile, wave, lane, h1);
+                    act_store(QA.h2s + (size_t)y * B * HID, tile, wave, lane, h2);
+                    if (wave == 0 && h == 0) QA.qo[(size_t)y * B + r] = out[0];
+                    if (wave == 1 % NT && h == 0 && y == 0) { QA.rew[r] = v_rew; QA.mask[r] = v_mask; }
+                } else if (wave == 0 && h == 0) {
+                    q_out[(size_t)y * B + r] = out[0];
+                }
+            } else {
+                const float dout[1] = {1.0f};
+                float din[NU];
+                backward<NQ, 1, ACT, false, true>(lds, xch, bt, h1, h2, dout, wave, lane, nullptr, true, din);
+                if (wave == 0 && h == 0) {
+                    q_out[(size_t)y * B + r] = out[0];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) dqda[((size_t)y * B + r) * NU + j] = din[j];
+                }
+                __syncthreads();                                        // the exchange buffers are free for the next tile
+            }
         }
     }
 }
 
-// actor gradient of policy_loss = mean(alpha log pi - min(q1, q2)(obs, a)): forward recomputed with the stored noise
+// actor gradient of policy_loss = mean(alpha log pi - min(q1, q2)(obs, a)), from the pass actor_fwd_kernel left behind: the waves' h1 / h2
+// tiles, the head's (tanh u, sigma, clamp pass), log pi and the noise.  Request order: row index, small block (W3 for dz2), the tiles,
+// the row's values, the observation (dW1's operand), the data-gradient operand.
 __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __restrict__ params, const scg_mlp_layout lay, const Common Cm,
                                                                  const float* __restrict__ eps_all, const float* __restrict__ qpi,
-                                                                 const float* __restrict__ dqda, float* __restrict__ partials) {
+                                                                 const float* __restrict__ dqda, const float* __restrict__ head,
+                                                                 const float* __restrict__ logp_all, const float* __restrict__ h1s,
+                                                                 const float* __restrict__ h2s, float* __restrict__ partials) {
     using S = Small<NA>;
     using G = Part<NOBS, NA>;
     constexpr int L1Q = 4 * ((NOBS + 7) / 8);
@@ -795,69 +930,75 @@ __global__ __launch_bounds__(64 * NT, 1) void actor_grad_kernel(const float* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const int n_tiles = Cm.batch / 32, B = Cm.batch;
     SCG_S_STAMP(0, 0);
-    // request order (see small_load): the first tile's row index, the small block, the forward operands, the row's values (observation,
-    // stored noise, q1 / q2 and both dq/da candidates — two dependent round trips that used to start behind the first barrier and in
-    // the middle of the tile); the backward operand (bt) behind the barrier, under the forward pass
     const int tile0 = blockIdx.x, r0 = tile0 * 32 + c;
-    const int s0 = tile0 < n_tiles ? Cm.idx[r0] : 0;
+    // (unconditional — gridDim.x <= n_tiles: written as `tile0 < n_tiles ? idx[r0] : 0` the row's byte offset was computed in the branch
+    //  that held the load, behind an s_waitcnt vmcnt(0): one whole memory round trip at kernel entry before anything else was requested)
+    const int s0 = Cm.idx[r0];
     SmallRegs<NA> sr;
     small_load<NA>(sr, w, threadIdx.x);
-    float a1[L1Q], a2[NT][16], bt[NT][16];
-    load_a1<NOBS, L1Q>(w.W1, wave, lane, a1);
-    load_a2(w.W2, wave, lane, a2);
-    float x[L1Q], eps[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = 0.0f, q2 = 0.0f, dq[2][NU];
-    auto load_row = [&](int r, int s) {
-        load_x2<L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x);
+    float bt[NT][16];
+    f32x16 h1, h2;
+    float x[L1Q], eps[NU], th[NU], sig[NU], pass[NU], logp = 0.0f, q1 = 0.0f, q2 = 0.0f, dq[2][NU];
+    auto load_row = [&](int tile, int r) {
+        act_load(h1s, tile, wave, lane, h1); act_load(h2s, tile, wave, lane, h2);
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             eps[j] = eps_all[(size_t)r * NU + j];
+            th[j] = head[(size_t)j * B + r]; sig[j] = head[(size_t)(NU + j) * B + r]; pass[j] = head[(size_t)(2 * NU + j) * B + r];
             dq[0][j] = dqda[(size_t)r * NU + j];
             dq[1][j] = dqda[((size_t)B + r) * NU + j];
         }
-        q1 = qpi[r]; q2 = qpi[B + r];
+        q1 = qpi[r]; q2 = qpi[B + r]; logp = logp_all[r];
     };
-    if (tile0 < n_tiles) load_row(r0, s0);
+    auto load_in = [&](int s) { load_x2<L1Q, NOBS, 0>(Cm.obs + (size_t)s * NOBS, nullptr, h, x); };
+    load_row(tile0, r0);
+    // (the data-gradient operand behind the tiles and the row values: 16 NT one-word loads per lane, needed only behind the tile's workgroup
+    //  barrier — in front of them they filled the 63-deep memory counter and what is needed first was issued a round trip late; the
+    //  observation last: it waits for the row index, and nothing needs it before the sample cache is written in backward())
+    load_bt(w.W2, wave, lane, bt);
+    load_in(s0);
     small_store<NA>(lds, sr, threadIdx.x);
     __syncthreads();
     SCG_S_STAMP(0, 1);
-    load_bt(w.W2, wave, lane, bt);
     float* const xch = lds + S::END;
-    float* const xs = xch + Xch::WAVE + wave * Xch::WAVE_WORDS + TR_WORDS;
     float* const P = partials + (size_t)blockIdx.x * PSTRIDE;
     const float alpha = expf(*Cm.log_alpha), inv_b = 1.0f / (float)B;
     float st_loss = 0.0f, st_logp = 0.0f;
     bool first = true;
     for (int tile = tile0; tile < n_tiles; tile += gridDim.x) {
         const int r = tile * 32 + c;
-        if (tile != tile0) load_row(r, Cm.idx[r]);
-        cache_x<NOBS, L1Q>(xs, x, c, h);
-        f32x16 h1, h2;
-        float out[NA], u[NU], th[NU], sig[NU], a[NU], logp, dout[NA];
-        forward<NOBS, NA, MLP_ACT_NONE>(lds, xch, a1, a2, x, wave, lane, h1, h2, out);
+        if (tile != tile0) { load_row(tile, r); load_in(Cm.idx[r]); }
         SCG_S_STAMP(0, 2);
-        squash(out, eps, Cm.low, Cm.high, u, th, sig, a, logp);
+        float dout[NA];
         const int ysel = q2 < q1 ? 1 : 0;                                          // torch.min: gradient to the smaller (q1 on a tie)
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             const float dqj = ysel ? dq[1][j] : dq[0][j];
             const float du = inv_b * (alpha * 2.0f * th[j] - dqj * 0.5f * (Cm.high[j] - Cm.low[j]) * (1.0f - th[j] * th[j]));
-            const float raw = out[NU + j];
-            const float pass = (raw >= -20.0f && raw <= 2.0f) ? 1.0f : 0.0f;      // torch.clamp's gradient
             dout[j] = du;
-            dout[NU + j] = pass * (du * sig[j] * eps[j] - inv_b * alpha);
+            dout[NU + j] = pass[j] * (du * sig[j] * eps[j] - inv_b * alpha);
         }
         if (wave == 0 && h == 0) { st_loss += (alpha * logp - fminf(q1, q2)) * inv_b; st_logp += logp * inv_b; }
         SCG_S_STAMP(0, 3);
-        backward<NOBS, NA, MLP_ACT_NONE, true, false, 0>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr);
+        backward<NOBS, NA, MLP_ACT_NONE, true, false, 0>(lds, xch, bt, h1, h2, dout, wave, lane, P, first, nullptr, x);
         SCG_S_STAMP(0, 9);
         first = false;
         __syncthreads();
         SCG_S_STAMP(0, 10);
     }
-    if (wave == 0) {
+    if (wave == 0) {                                                    // (the sums live in the lanes of half 0)
+        float* const r = xch + Xch::WAVE + TR_WORDS + 34 * 32;          // wave 0's dout_l rows: free behind the last tile's barrier
+        if (lane < 32) { r[lane] = st_loss; r[32 + lane] = st_logp; }
+        wave_sync();
+        if (lane < 2) {
+            float v = 0.0f;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { st_loss += __shfl_xor(st_loss, m, 64); st_logp += __shfl_xor(st_logp, m, 64); }
-        if (lane == 0) { P[G::STAT] = st_loss; P[G::STAT + 1] = st_logp; }
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(r + 32 * lane + 4 * g);
+                v += d4.x; v += d4.y; v += d4.z; v += d4.w;
+            }
+            P[G::STAT + lane] = v;
+        }
     }
     SCG_S_STAMP(0, 11);
 }
@@ -908,10 +1049,35 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
     const int kl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kl;
     constexpr int words = Part<NIN, NOUT>::END;
+    // Request order: what the word's OWNER needs for its optimiser step (parameter, moments, target copy, step count) goes out first and
+    // arrives under the partial loads — asked for behind the sum it was one more memory round trip at the end of every block; then ALL
+    // of this thread's partial words at once (32 at n_part = 128; `unroll 8` made that four rounds of eight).  The sum keeps its order.
+    const bool owner = grp == 0 && k < words;
+    int d = -1;
+    float o_p = 0.0f, o_m = 0.0f, o_v = 0.0f, o_t = 0.0f, o_steps = 0.0f;
+    if (owner) {
+        d = dest_of<NIN, NOUT>(k, R.lay[net]);
+        if (d >= 0 && R.p) {
+            o_p = R.p[d]; o_m = R.m[d]; o_v = R.v[d]; o_steps = R.steps[R.step_slot];
+            if (R.target) o_t = R.target[d];
+        } else if (d == -2 && R.bump_critic) {
+            o_steps = R.steps_rw[1];
+        } else if (d == -3 && R.alpha_slot >= 0 && R.p && R.alpha_on) {                 // the temperature's step
+            const int a = R.alpha_slot;
+            o_p = R.p[a]; o_m = R.m[a]; o_v = R.v[a]; o_steps = R.steps[2];
+        }
+    }
     float s = 0.0f;
     if (k < words) {
-#pragma unroll 8
-        for (int g = grp; g < R.n_part; g += 4) s += R.partials[((size_t)net * R.n_part + g) * PSTRIDE + k];
+        const float* const src = R.partials + ((size_t)net * R.n_part + grp) * PSTRIDE + k;      // partials grp, grp + 4, ...
+        const int mine = (R.n_part - grp + 3) / 4;
+        for (int g0 = 0; g0 < mine; g0 += 32) {
+            float v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = g0 + j < mine ? src[(size_t)(g0 + j) * 4 * PSTRIDE] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { if (g0 + j < mine) s += v[j]; }
+        }
     }
     part[grp][kl] = s;
     __shared__ float other[512];                            // (n_part <= 512, n_part_of)
@@ -931,18 +1097,18 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
         }
     }
     __syncthreads();
-    if (grp != 0 || k >= words) return;
+    if (!owner) return;
     s = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
-    const int d = dest_of<NIN, NOUT>(k, R.lay[net]);
     if (d >= 0) {
         R.grad[d] = s;
         if (R.p) {
-            adam_one(R.p[d], s, R.m[d], R.v[d], R.lr, R.steps[R.step_slot] + R.t_add);
-            if (R.target) R.target[d] = (1.0f - R.tau) * R.target[d] + R.tau * R.p[d];
+            adam_one(o_p, s, o_m, o_v, R.lr, o_steps + R.t_add);
+            R.p[d] = o_p; R.m[d] = o_m; R.v[d] = o_v;
+            if (R.target) R.target[d] = polyak(o_t, o_p, R.tau);
         }
     } else if (d == -2) {
         R.stat_out[2 * net] = s;
-        if (R.bump_critic) R.steps_rw[1] += 1.0f;
+        if (R.bump_critic) R.steps_rw[1] = o_steps + 1.0f;
         if (fin_block) {                                    // what finish_kernel does on the data-parallel path
             const ReduceArgs::Fin& F = R.fin;
             F.steps[0] = f_steps0 + 1.0f;
@@ -969,7 +1135,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
             const float g = -(s + R.target_entropy);
             const int a = R.alpha_slot;
             R.grad[a] = g;
-            if (R.p && R.alpha_on) adam_one(R.p[a], g, R.m[a], R.v[a], R.lr_alpha, R.steps[2] + 1.0f);
+            if (R.p && R.alpha_on) {
+                adam_one(o_p, g, o_m, o_v, R.lr_alpha, o_steps + 1.0f);
+                R.p[a] = o_p; R.m[a] = o_m; R.v[a] = o_v;
+            }
         }
     }
 }
@@ -981,13 +1150,7 @@ struct AdamArgs {
     int alpha_on; int n_params; float lr_alpha; float target_entropy; const float* actor_stat;
     float* target; int n_polyak; float tau;
 };
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float t) {
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    m = b1 * m + (1.0f - b1) * g;
-    v = b2 * v + (1.0f - b2) * g * g;
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    p -= lr / bc1 * m / (sqrtf(v) / sqrtf(bc2) + eps);
-}
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float t) { adam_element(p, g, m, v, lr, t); }
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs A) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;            // one element per thread: Adam (if in [lo, hi)), then its soft update
     if (i >= A.lo && i < A.hi) adam_one(A.p[i], A.g[i], A.m[i], A.v[i], A.lr, A.steps[A.step_slot] + 1.0f);
@@ -995,7 +1158,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs A) {
         const int k = A.n_params;                           // (gradient written by the actor's reduce_kernel)
         adam_one(A.p[k], A.g[k], A.m[k], A.v[k], A.lr_alpha, A.steps[2] + 1.0f);
     }
-    if (A.target && i < A.n_polyak) A.target[i] = (1.0f - A.tau) * A.target[i] + A.tau * A.p[i];
+    if (A.target && i < A.n_polyak) A.target[i] = polyak(A.target[i], A.p[i], A.tau);
 }
 
 struct FinishArgs {
@@ -1020,15 +1183,18 @@ __global__ void finish_kernel(const FinishArgs F) {
 
 // ------------------------------------------------------------------ host side
 struct Ws {      // workspace carve-up (floats)
-    size_t idx, eps, a_pi, logp, eps2, a_next, logp_next, qpi, dqda, qt, stat, la_before, partials, total;
+    size_t idx[2], eps, a_pi, logp, eps2, a_next, logp_next, qpi, dqda, qt, stat, la_before[2], head, ah1, ah2, qo, qh1, qh2, qrew, qmask, partials, total;
 };
 static Ws carve(int B, int n_part) {
     Ws w; size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) / 64 * 64; return at; };
-    w.idx = take(B); w.eps = take((size_t)B * NU); w.a_pi = take((size_t)B * NU); w.logp = take(B);
+    // (two copies of the minibatch rows and of the log_alpha snapshot: scg_sac_update_n draws step k + 1's while step k still reads its own)
+    w.idx[0] = take(B); w.idx[1] = take(B); w.eps = take((size_t)B * NU); w.a_pi = take((size_t)B * NU); w.logp = take(B);
     w.eps2 = take((size_t)B * NU); w.a_next = take((size_t)B * NU); w.logp_next = take(B);
     w.qpi = take(2 * (size_t)B); w.dqda = take(2 * (size_t)B * NU); w.qt = take(2 * (size_t)B);
-    w.stat = take(8); w.la_before = take(1);
+    w.stat = take(8); w.la_before[0] = take(1); w.la_before[1] = take(1);
+    w.head = take((size_t)wide::HEADW * B); w.ah1 = take((size_t)B * HID); w.ah2 = take((size_t)B * HID);
+    w.qo = take(2 * (size_t)B); w.qh1 = take(2 * (size_t)B * HID); w.qh2 = take(2 * (size_t)B * HID); w.qrew = take(B); w.qmask = take(B);
     w.partials = take(2 * (size_t)n_part * PSTRIDE);
     w.total = o;
     return w;
@@ -1049,6 +1215,9 @@ static int set_lds(K kernel, size_t bytes) {
 static size_t lds_actor_bytes() { return (MlpLds<NOBS, HID, NA>::END + WAVES * (32 * ((NOBS + 3) / 4 * 4) + NA * 32 + TR_WORDS)) * sizeof(float); }
 static size_t wide_lds_actor() { return (wide::Small<NA>::END + wide::Xch::END) * sizeof(float); }
 static size_t wide_lds_q() { return (wide::Small<1>::END + wide::Xch::END) * sizeof(float); }
+// forward-only launches need the small block, the h1 exchange and the output partials only: two workgroups per CU fit
+static size_t wide_lds_actor_fwd() { return (wide::Small<NA>::END + wide::Xch::FWD_END) * sizeof(float); }
+static size_t wide_lds_q_fwd() { return (wide::Small<1>::END + wide::Xch::FWD_END) * sizeof(float); }
 
 // One-time kernel attributes (dynamic LDS above 64 KB).  Call once before capturing scg_sac_update into a HIP graph: the
 // attribute calls are not stream operations.  scg_sac_update calls it itself otherwise.
@@ -1060,31 +1229,37 @@ extern "C" int scg_sac_prepare(void) {
     if (lds_a > 160 * 1024 || wide_lds_actor() > 160 * 1024 || wide_lds_q() > 160 * 1024)
         return fail(-1, "scg_sac: network image does not fit the LDS");
     if (set_lds(actor_act_kernel, lds_a) || set_lds(actor_sample_kernel, MlpLds<NOBS, HID, NA>::END * sizeof(float))) return -2;
-    if (set_lds(wide::actor_fwd_kernel, wide_lds_actor()) || set_lds(wide::actor_grad_kernel, wide_lds_actor()) ||
-        set_lds(wide::q_kernel<0>, wide_lds_q()) || set_lds(wide::q_kernel<1>, wide_lds_q()) || set_lds(wide::q_kernel<2>, wide_lds_q())) return -2;
+    if (set_lds(wide::actor_fwd_kernel, wide_lds_actor_fwd()) || set_lds(wide::actor_grad_kernel, wide_lds_actor()) ||
+        set_lds(wide::q_kernel<0>, wide_lds_q_fwd()) || set_lds(wide::q_kernel<1>, wide_lds_q()) || set_lds(wide::q_kernel<2>, wide_lds_q())) return -2;
     once.commit(dev);
     return 0;
 }
 
-extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
+static int check_args(const scg_sac_args* a, const char* who) {
     if (!a || !a->d_params || !a->d_target || !a->d_grad || !a->d_m || !a->d_v || !a->d_steps || !a->d_obs || !a->d_act || !a->d_rew ||
         !a->d_next_obs || !a->d_mask || !a->d_counter || !a->d_workspace || !a->d_stats || (!a->d_ring_size && !a->d_idx_in))
-        return fail(-1, "scg_sac_update: NULL argument");
-    if (a->batch <= 0 || a->batch % 32) return fail(-1, "scg_sac_update: the batch size must be a positive multiple of 32");
-    hipStream_t st = (hipStream_t)stream;
+        return fail(-1, std::string(who) + ": NULL argument");
+    if (a->batch <= 0 || a->batch % 32) return fail(-1, std::string(who) + ": the batch size must be a positive multiple of 32");
+    return 0;
+}
+
+// One gradient step (or the parts `phases` names).  parity: which copy of the minibatch rows / log_alpha snapshot the step uses;
+// have_first: the step's first launch (rows drawn, a, log pi at obs) already ran as the second job of the previous step's target-action
+// launch; with_next: this step's target-action launch carries that job for the NEXT step (scg_sac_update_n).
+static int enqueue_step(const scg_sac_args* a, hipStream_t st, int phases, int parity, bool have_first, bool with_next) {
     const int B = a->batch, n_part = n_part_of(B);
     const Ws w = carve(B, n_part);
     float* W = (float*)a->d_workspace;
-    int32_t* idx = (int32_t*)(W + w.idx);
-    const size_t wlds_a = wide_lds_actor(), wlds_q = wide_lds_q();
-    if (int rc = scg_sac_prepare()) return rc;
+    int32_t* idx = (int32_t*)(W + w.idx[parity]);
+    int32_t* idx_next = (int32_t*)(W + w.idx[parity ^ 1]);
+    float* la_before = W + w.la_before[parity];
+    const size_t wlds_a = wide_lds_actor(), wlds_q = wide_lds_q(), wlds_af = wide_lds_actor_fwd(), wlds_qf = wide_lds_q_fwd();
     Common Cm;
     Cm.idx = idx; Cm.batch = B; Cm.n_part = n_part; Cm.obs = a->d_obs; Cm.act = a->d_act; Cm.rew = a->d_rew; Cm.next_obs = a->d_next_obs;
     Cm.mask = a->d_mask; Cm.log_alpha = a->d_params + a->n_params; Cm.gamma = a->gamma;
     for (int j = 0; j < 4; ++j) { Cm.low[j] = a->act_low[j]; Cm.high[j] = a->act_high[j]; }
     Cm.k0 = (uint32_t)a->seed; Cm.k1 = (uint32_t)(a->seed >> 32); Cm.counter = a->d_counter;
     float* stat = W + w.stat;
-    const int phases = a->phases == 0 ? SCG_SAC_ALL : a->phases;
     // the whole step on one GPU: the optimiser steps ride in the reduction launches; data-parallel callers (phases given one
     // by one, an all-reduce of d_grad between them) get the gradient only and step in adam_kernel
     const bool fuse = phases == SCG_SAC_ALL;
@@ -1097,18 +1272,27 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
         if (step_slot == 0) R.bump_critic = 1;              // actor's launch: pre-increment the critics' count (read by their launch only)
         else {                                              // critics' launch: the count is already this step's; + the step's bookkeeping
             R.t_add = 0.0f;
-            R.fin = ReduceArgs::Fin{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
+            R.fin = ReduceArgs::Fin{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, la_before, a->use_entropy_tuning, a->target_entropy};
         }
     };
+    // the policy-loss job of a step: draws the minibatch rows (kept in idx), snapshots log_alpha as the policy loss sees it (entropy_loss
+    // is reported with that value), a, log pi at obs + what actor_grad_kernel reads back of the pass
+    auto policy_job = [&](int32_t* rows, float* la, uint32_t cnt_add) {
+        return wide::AfJob{a->d_obs, nullptr, rows, a->d_ring_size, a->d_idx_in, a->d_eps_in, 1u, cnt_add, W + w.eps, W + w.a_pi, W + w.logp, la,
+                           W + w.head, W + w.ah1, W + w.ah2};
+    };
+    const wide::QAct QA{W + w.qo, W + w.qh1, W + w.qh2, W + w.qrew, W + w.qmask};
     if (phases & SCG_SAC_ACTOR_GRAD) {
-    // 1. minibatch rows (kept in idx), log_alpha as the policy loss sees it (entropy_loss is reported with that value);
-    //    a, log pi at obs
-    wide::actor_fwd_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, 0, a->d_eps_in, 1u, W + w.eps, W + w.a_pi, W + w.logp,
-                                                                        idx, a->d_ring_size, a->d_idx_in, W + w.la_before);
+    // 1. minibatch rows, a, log pi at obs
+    if (!have_first) {
+        const wide::AfJob J = policy_job(idx, la_before, 0u);
+        wide::actor_fwd_kernel<<<dim3(n_part, 1), dim3(64 * NT), wlds_af, st>>>(a->d_params, a->actor, Cm, J, J);
+    }
     // 2. q1, q2 and dq/da at (obs, a)
-    wide::q_kernel<1><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_params, a->q1, a->q2, Cm, W + w.a_pi, nullptr, nullptr, W + w.qpi, W + w.dqda, nullptr);
+    wide::q_kernel<1><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_params, nullptr, a->q1, a->q2, Cm, W + w.a_pi, nullptr, nullptr, W + w.qpi, W + w.dqda, QA, nullptr);
     // 3. actor gradient
-    wide::actor_grad_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, W + w.eps, W + w.qpi, W + w.dqda, W + w.partials);
+    wide::actor_grad_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, W + w.eps, W + w.qpi, W + w.dqda, W + w.head, W + w.logp,
+                                                                         W + w.ah1, W + w.ah2, W + w.partials);
     // 4. its sum (+ the actor and temperature steps and the soft update of the actor's target copy when fused)
     {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->actor; R.lay[1] = a->actor; R.grad = a->d_grad; R.stat_out = stat;
@@ -1124,13 +1308,17 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
                    a->use_entropy_tuning, a->n_params, a->entropy_lr, a->target_entropy, stat, nullptr, 0, 0.0f};
         adam_kernel<<<dim3((a->n_actor + 255) / 256), dim3(256), 0, st>>>(A);
     }
-    // 5. a', log pi' at next_obs with the updated actor
-    wide::actor_fwd_kernel<<<dim3(n_part), dim3(64 * NT), wlds_a, st>>>(a->d_params, a->actor, Cm, 1, a->d_eps_next_in, 2u, W + w.eps2, W + w.a_next, W + w.logp_next,
-                                                                        nullptr, nullptr, nullptr, nullptr);
-    // 6. target networks
-    wide::q_kernel<0><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_target, a->q1, a->q2, Cm, W + w.a_next, nullptr, nullptr, W + w.qt, nullptr, nullptr);
+    // 5. a', log pi' at next_obs with the updated actor [+ the next step's launch 1: same actor, the counter word one ahead]
+    {
+        const wide::AfJob J{a->d_next_obs, idx, nullptr, nullptr, nullptr, a->d_eps_next_in, 2u, 0u, W + w.eps2, W + w.a_next, W + w.logp_next, nullptr,
+                            nullptr, nullptr, nullptr};
+        const wide::AfJob Jn = with_next ? policy_job(idx_next, W + w.la_before[parity ^ 1], 1u) : J;
+        wide::actor_fwd_kernel<<<dim3(n_part, with_next ? 2 : 1), dim3(64 * NT), wlds_af, st>>>(a->d_params, a->actor, Cm, J, Jn);
+    }
+    // 6. target networks at (next_obs, a'); next to them the online critics' forward pass at (obs, act) for 7
+    wide::q_kernel<0><<<dim3(n_part, 4), dim3(64 * NT), wlds_qf, st>>>(a->d_target, a->d_params, a->q1, a->q2, Cm, W + w.a_next, nullptr, nullptr, W + w.qt, nullptr, QA, nullptr);
     // 7. critic gradients
-    wide::q_kernel<2><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_params, a->q1, a->q2, Cm, nullptr, W + w.qt, W + w.logp_next, nullptr, nullptr, W + w.partials);
+    wide::q_kernel<2><<<dim3(n_part, 2), dim3(64 * NT), wlds_q, st>>>(a->d_params, nullptr, a->q1, a->q2, Cm, nullptr, W + w.qt, W + w.logp_next, nullptr, nullptr, QA, W + w.partials);
     // 8. their sums (+ the critic steps and the soft update of their target copies when fused)
     {
         ReduceArgs R; R.partials = W + w.partials; R.n_part = n_part; R.lay[0] = a->q1; R.lay[1] = a->q2; R.grad = a->d_grad; R.stat_out = stat + 2;
@@ -1148,11 +1336,30 @@ extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
     }
     // 9. step counters, loss statistics (data-parallel path; the fused single-GPU step did them inside the critics' reduction)
     if (!fuse) {
-        FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, W + w.la_before, a->use_entropy_tuning, a->target_entropy};
+        FinishArgs F{a->d_steps, a->d_counter, a->d_stats, a->d_stats_acc, stat, stat + 2, la_before, a->use_entropy_tuning, a->target_entropy};
         finish_kernel<<<dim3(1), dim3(64), 0, st>>>(F);
     }
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int scg_sac_update(const scg_sac_args* a, void* stream) {
+    if (int rc = check_args(a, "scg_sac_update")) return rc;
+    if (int rc = scg_sac_prepare()) return rc;
+    return enqueue_step(a, (hipStream_t)stream, a->phases == 0 ? SCG_SAC_ALL : a->phases, 0, false, false);
+}
+
+// n_steps whole gradient steps (a->phases must be 0 / SCG_SAC_ALL), results bit-identical to n_steps scg_sac_update calls, in
+// 7 n_steps + 1 launches instead of 8 n_steps: the target-action launch of step k also runs step k + 1's first launch (see
+// wide::actor_fwd_kernel) — nothing between the two touches the actor, the replay ring or the row draw's inputs.
+extern "C" int scg_sac_update_n(const scg_sac_args* a, int n_steps, void* stream) {
+    if (int rc = check_args(a, "scg_sac_update_n")) return rc;
+    if (n_steps <= 0) return fail(-1, "scg_sac_update_n: n_steps must be positive");
+    if (a->phases != 0 && a->phases != SCG_SAC_ALL) return fail(-1, "scg_sac_update_n: whole steps only (phases = 0)");
+    if (int rc = scg_sac_prepare()) return rc;
+    for (int k = 0; k < n_steps; ++k)
+        if (int rc = enqueue_step(a, (hipStream_t)stream, SCG_SAC_ALL, k & 1, k > 0, k + 1 < n_steps)) return rc;
     return 0;
 }
 

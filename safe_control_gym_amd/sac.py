@@ -350,12 +350,15 @@ class SACAgent:
                     self._fused_step_dp(F)
             return self._fused_stats(F, n_updates, lazy)
         g = F['graphs'].get(n_updates)
-        if g is None:                               # n_updates steps as one HIP graph (9 launches each: host-launch bound otherwise)
+        if g is None:                               # n_updates steps as one HIP graph (7 launches each + 1: host-launch bound otherwise)
+            from safe_control_gym_amd import _sac
             with torch.cuda.device(dev):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    for _ in range(n_updates):
-                        self._fused_step(F)
+                    # scg_sac_update_n: step k + 1's first launch rides in step k's target-action launch (bit-identical to n calls)
+                    F['args'].phases = 0
+                    st = F['C'].c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    _sac.check(F['D'], F['D'].scg_sac_update_n(F['C'].byref(F['args']), int(n_updates), st))
             F['graphs'][n_updates] = g
         g.replay()
         return self._fused_stats(F, n_updates, lazy)

@@ -193,6 +193,46 @@ def test_fused_update_samples_in_the_kernel_is_reproducible_and_learns():
     torch.testing.assert_close(out, a, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('nobs,nu,hidden,act,B', [(24, 4, 128, 'relu', 4096), (17, 2, 96, 'tanh', 640), (6, 2, 32, 'relu', 64)])
+def test_update_n_is_bit_identical_to_single_step_calls(nobs, nu, hidden, act, B):
+    """scg_sac_update_n (what SACAgent.update_from_buffer captures: step k + 1's first launch — rows drawn, a, log pi at obs, the tiles
+    actor_grad_kernel reads back — rides in step k's target-action launch, 7 n + 1 launches) against n scg_sac_update calls (8 launches
+    each) from the same state: parameters, target copy, Adam moments, step counts, Philox counter and the loss sums, bit for bit — with
+    entropy tuning on (log_alpha moves between the two jobs' reads) and an odd n (both copies of the row / log_alpha buffers in use)."""
+    from safe_control_gym_amd.sac import DeviceReplay, SACAgent, SACConfig
+    dev = torch.device('cuda', 0)
+    low, high = -torch.ones(nu, device=dev), torch.ones(nu, device=dev)
+    out = []
+    for mode in ('n', 'single'):
+        torch.manual_seed(4)
+        ag = SACAgent(nobs, nu, low, high, SACConfig(hidden_dim=hidden, activation=act, use_entropy_tuning=True), dev)
+        assert ag.use_fused
+        buf = DeviceReplay(20000, nobs, nu, dev)
+        g = torch.Generator(device=dev).manual_seed(7)
+        n = 9000
+        buf.push(torch.randn(n, nobs, device=dev, generator=g), torch.rand(n, nu, device=dev, generator=g) * 2 - 1, torch.randn(n, device=dev, generator=g),
+                 torch.randn(n, nobs, device=dev, generator=g), (torch.rand(n, device=dev, generator=g) < 0.8).float())
+        if mode == 'n':
+            stats = [ag.update_from_buffer(buf, B, 5) for _ in range(3)]           # three replays of the captured 5-step graph
+            acc = None
+        else:
+            F = ag._fused_args(buf, B)
+            stats = []
+            for _ in range(3):
+                F['acc'].zero_()
+                for _ in range(5):
+                    ag._fused_step(F)
+                stats.append(dict(zip(('policy_loss', 'critic_loss', 'entropy_loss'), (F['acc'] / 5).tolist()[:3])))
+        torch.cuda.synchronize()
+        fl = ag._flat
+        out.append(({k: fl[k].clone() for k in ('p', 'targ', 'm', 'v', 'steps', 'counter')}, stats))
+    (a, sa), (b, sb) = out
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int(a['counter']) == 15 and a['steps'].tolist() == [15.0, 15.0, 15.0]
+    assert sa == sb
+
+
 def _sac_variant_names():
     from tests.golden.learner_cases import SAC_CASES
     return sorted(SAC_CASES)

@@ -8,7 +8,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('SCG_SAC_FLAGS', '-DSCG_S_TIMING')
-NAMES = ['start', 'operands requested + small block filled + barrier', 'first tile: rows gathered, forward done', 'squash + loss derivatives',
+NAMES = ['start', 'data-gradient operand, stored tiles and row values requested + small block filled + barrier', 'first tile: rows arrived, sample cache',
+         'loss derivatives (from the stored head: no forward pass, no tanh-Gaussian algebra)',
          'db3 + dW3 (h2 transposed)', 'dz2, dz2^T, db2, h1^T (before the barrier)', 'barrier', 'data gradient (64 MFMA) x act\'', 'dW1 | db1 (16 MFMA) + store',
          'dW2 (64 MFMA) + 64 KB of partial stores', 'barrier', 'statistics, end']
 
@@ -42,7 +43,7 @@ def main():
     t = list(out)[:16]
     print('actor_grad_kernel, wave 0 of workgroup 0, batch 4096 (one tile per workgroup), shader clock / 2.4 GHz:')
     for k in range(1, 12):
-        print(f'  {NAMES[k]:70s} {(t[k] - t[k - 1]) / 2400.0:7.2f} us   (at {(t[k] - t[0]) / 2400.0:6.2f})')
+        print(f'  {NAMES[k]:100s} {(t[k] - t[k - 1]) / 2400.0:7.2f} us   (at {(t[k] - t[0]) / 2400.0:6.2f})')
     _sac.lib_path = orig
     os.remove(tagged)
 
