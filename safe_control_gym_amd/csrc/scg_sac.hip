@@ -76,7 +76,7 @@ struct Part {
     static constexpr int DW3 = DB2 + HID;                   // [NOUT][H]
     static constexpr int DB3 = DW3 + NOUT * HID;            // [8]
     static constexpr int STAT = DB3 + 8;                    // [4]
-    static constexpr int DW2 = STAT + 4;                    // [NT * NT tiles][64 lanes][16]
+    static constexpr int DW2 = STAT + 4;                    // [NT * NT tiles][4 g][64 lanes][4]: accumulator word q = 4 g + r of lane
     static constexpr int END = DW2 + HID * HID;
 };
 constexpr int PSTRIDE = (Part<NOBS, NA>::END > Part<NQ, 1>::END ? Part<NOBS, NA>::END : Part<NQ, 1>::END);
@@ -92,6 +92,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 16-byte store WRITTEN THROUGH (sc0 sc1, as scg_learn.hip's partial vectors): what a launch leaves for the NEXT launch — partial gradient
+// vectors, activation tiles — is read there from other XCDs, so it has to reach the memory side before this kernel may retire; written
+// back, that is one flush of megabytes behind the last workgroup's last store, written through it drains while the kernel still computes.
+// `base` must be wave-uniform (it becomes the buffer resource); `word` = this lane's float offset from it.
+#ifndef SCG_S_STORE_AUX
+#define SCG_S_STORE_AUX 17
+#endif
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+__device__ __forceinline__ void store_wt(float* base, uint32_t word, const f32x4 v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, 4u * word, 0, SCG_S_STORE_AUX);
 }
 
 // Sum over lanes 0..31 of v, valid in lane 0: through 32 words of the wave's LDS (one 4-byte write per lane, eight 16-byte reads in lane 0,
@@ -642,12 +655,12 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
 #pragma unroll
             for (int q = 0; q < 16; ++q) g1 = mfma32(acc[q], xb[q], g1);
             if (c <= NIN) {
-                float* const dst = P + G::DW1 + c * HID + 32 * wave + 4 * h;
+                const uint32_t dw = G::DW1 + c * HID + 32 * wave + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]};
-                    if (!first) v += *reinterpret_cast<const f32x4*>(dst + 8 * g);
-                    *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                    if (!first) v += *reinterpret_cast<const f32x4*>(P + dw + 8 * g);
+                    store_wt(P, dw + 8 * g, v);
                 }
             }
         }
@@ -662,12 +675,12 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
             for (int q = 0; q < 16; ++q) d2[q] = 0.0f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) d2 = mfma32(ta[q], zt[q], d2);
-            float* const p = P + G::DW2 + ((tau * NT + wave) * 64 + lane) * 16;
+            const uint32_t dw = G::DW2 + ((tau * NT + wave) * 4 * 64 + lane) * 4;        // [tile][g][lane][4]: 1 KB of consecutive addresses per store
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {d2[4 * g], d2[4 * g + 1], d2[4 * g + 2], d2[4 * g + 3]};
-                if (!first) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
-                *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                if (!first) v += *reinterpret_cast<const f32x4*>(P + dw + 256 * g);
+                store_wt(P, dw + 256 * g, v);
             }
         }
     }
@@ -679,9 +692,9 @@ __device__ __forceinline__ void backward(const float* sm, float* xch, const floa
 // The gradient kernels then START at the loss derivatives: no operand loads for the forward products, no forward pass, no tanh-Gaussian
 // algebra on their critical path (round 6's timeline of actor_grad_kernel: 4.8 + 1.5 of the 18.9 us a wave lived).
 __device__ __forceinline__ void act_store(float* __restrict__ base, int tile, int wave, int lane, const f32x16& t) {
-    float* const p = base + (((size_t)tile * NT + wave) * 4 * 64 + lane) * 4;
+    const uint32_t word = (uint32_t)((tile * NT + wave) * 4 * 64 + lane) * 4u;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(p + g * 256) = (f32x4){t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+    for (int g = 0; g < 4; ++g) store_wt(base, word + 256u * g, (f32x4){t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]});
 }
 __device__ __forceinline__ void act_load(const float* __restrict__ base, int tile, int wave, int lane, f32x16& t) {
     const float* const p = base + (((size_t)tile * NT + wave) * 4 * 64 + lane) * 4;
@@ -1014,8 +1027,8 @@ __device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay) {
     if (k < G::DB3) return lay.W3 + (k - G::DW3);
     if (k < G::STAT) return (k - G::DB3) < NOUT ? lay.b3 + (k - G::DB3) : -1;
     if (k < G::DW2) return -2 - (k - G::STAT);
-    const int p = k - G::DW2;
-    const int q = p & 15, lane = (p >> 4) & 63, tr = p >> 10;
+    const int p = k - G::DW2;                               // [tile][g][lane][4]
+    const int q = 4 * ((p >> 8) & 3) + (p & 3), lane = (p >> 2) & 63, tr = p >> 10;
     const int tau = tr / NT, rho = tr % NT;
     return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
 }

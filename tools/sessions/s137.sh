@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 6 (second session): SAC partial vectors and activation tiles written through (sc0 sc1; variant wb = written back), dW2 partial as [tile][g][lane][4]
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/s137; mkdir -p $O
+( time timeout 1500 python -m pytest tests/test_gpu_sac_fused.py tests/test_gpu_rl.py tests/test_gpu_multirank.py -x -q -m gpu ) > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+timeout 600 python tools/sac_step_ab.py shipped wb base > $O/sac_ab.txt 2>&1; tail -5 $O/sac_ab.txt
+timeout 300 python tools/sac_timeline.py > $O/sac_timeline.txt 2>&1; tail -13 $O/sac_timeline.txt
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+P=gpurun_out/prof6f; rm -rf $P; mkdir -p $P
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt_sac -o p -- python tools/learner_profile.py sac --iters 200 > $P/kt_sac.log 2>&1 < /dev/null
+timeout 300 python tools/learner_profile.py sac --iters 200 > $P/plain_sac.log 2>&1 < /dev/null
+python tools/learner_profile_post.py $P | cut -c1-400
+find $P -name '*kernel_trace.csv' -delete; find $P -name '*agent_info.csv' -delete; find $P -name '*.db' -delete
+python - <<'PY'
+import csv
+rows = list(csv.DictReader(open('gpurun_out/prof6f/r06_kernel_stats_sac_iteration.csv')))
+for r in rows[:9]:
+    print(f"  {r['Name'][:60]:60s} calls {r['Calls']:>6s} avg {float(r['AverageNs'])/1e3:8.2f} us  {r['Percentage']}%")
+PY
