@@ -910,10 +910,11 @@ def sac_leg(torch, seeds, budget_s, envs=2048, batch=4096, updates_per_step=16, 
     ok1, ok2 = [t for t in first if t is not None], [t for t in both if t is not None]
     # ---- the gradient step against the float32 matrix peak: algorithmic flops per minibatch row of one SACAgent.update
     # (sac_utils.py:143-170): actor forward on obs and on next_obs, both Q forward + d q / d a at (obs, a), the actor's backward
-    # (forward recomputed + data + weight gradients), both target Q forward, both Q forward + data + weight gradients
+    # (data + weight gradients; its forward pass is the first launch's, kept as activation tiles — counted once), both target Q
+    # forward, both Q forward + data + weight gradients
     nobs, nu, hd = spec.obs_dim, spec.nu, 128
     a_f, q_f = mlp_flops(nobs, hd, 2 * nu), mlp_flops(nobs + nu, hd, 1)
-    flops_step = batch * (2 * a_f + 2 * 2 * q_f + 3 * a_f + 2 * q_f + 2 * 3 * q_f)
+    flops_step = batch * (2 * a_f + 2 * 2 * q_f + 2 * a_f + 2 * q_f + 2 * 3 * q_f)
     ks, ks_src = learner_kernel_sum(f'sac/{batch}/{updates_per_step}')
     step_us = ks['gradient_step_us'] if ks else None
     vs_ms = statistics.median(vstep_ms) if vstep_ms else None

@@ -23,6 +23,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/scg_learn.h"
@@ -182,7 +183,14 @@ __device__ __forceinline__ void gl_add(float* p, float v) {
     else atomicAdd(p, v);
 }
 
-template <int NOUT, bool ACTOR>
+// ONE = at most one tile per wave (tiles <= 4 x workgroups: what the shipped minibatch sizes give — 16 256 rows = 508 tiles on 127
+// workgroups per network).  The dW2 "accumulators" then accumulate nothing: each of the NT^2 tile products is a single 16-MFMA chain, and
+// holding all of them in 256 AccVGPRs until the cross-wave sum (a) left everything else of the tile 256 registers — 35 spilled words per
+// lane, each reload a scratch round trip behind an s_waitcnt vmcnt(0) — and (b) made that sum a separate 5.6 us pass over 64 KB of LDS.
+// With ONE the products are formed INSIDE the cross-wave sum, behind the barrier that frees the weight image: in round r wave w forms
+// the tile row tau = (w + r) mod 4 (4 x 16 MFMAs) and adds it to the row's running sum in the staging area — the same products added in
+// the same order as before (bit-identical), the LDS traffic of one row under the matrix products of the next.
+template <int NOUT, bool ACTOR, bool ONE>
 __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     using L = MlpLds<NIN, HID, NOUT>;
     using G = GradLds<NOUT>;
@@ -226,13 +234,22 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     float st_loss = 0.0f, st_kl = 0.0f, dls[NOUT];
 #pragma unroll
     for (int a = 0; a < NOUT; ++a) dls[a] = 0.0f;
-    f32x16 dW2[NT][NT];                                                 // [tau (in tile)][rho (out tile)]
+    f32x16 dW2[ONE ? 1 : NT][ONE ? 1 : NT];                             // [tau (in tile)][rho (out tile)]
+    if constexpr (!ONE) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < NT; ++r)
+            for (int r = 0; r < NT; ++r)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) dW2[t][r][q] = 0.0f;
+                for (int q = 0; q < 16; ++q) dW2[t][r][q] = 0.0f;
+    }
+    f32x16 h1[NT], h2[NT];                      // (ONE: the tile's transposed h1 / dz2 tiles outlive the loop — operands of the products below)
+    if constexpr (ONE) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { h1[t][q] = 0.0f; h2[t][q] = 0.0f; }
+    }
 
     for (int tile = tile0; tile < n_tiles; tile += gridDim.x * WAVES) {
 #ifdef SCG_L_TIMING
@@ -261,7 +278,6 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
             else if (f < NIN) { if (h == 0) xs[f * 32 + c] = x[q]; }
         }
         SCG_L_TSTAMP(1);
-        f32x16 h1[NT], h2[NT];
         float out[NOUT], dout[NOUT];
 #ifdef SCG_L_TIMING
         mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, out, lane, tst + 8);
@@ -314,16 +330,20 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) dout_l[o * 32 + c] = dout[o];
         }
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {                                // db3: sum over the tile's 32 samples (both halves hold them)
-            float v = dout[o];
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0) gl_add(glw + G::DB3 + o, v);
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // db3: lane o sums row o of the LDS copy (eight 16-byte reads, a fixed order) — as a butterfly over the lanes it was five dependent
+        // ds_bpermute round trips per output, serialised further by the branches of the stores between the outputs
+        if (lane < NOUT) {
+            float v = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dout_l + lane * 32 + 4 * g);
+                v += d4.x; v += d4.y; v += d4.z; v += d4.w;
+            }
+            gl_add(glw + G::DB3 + lane, v);
+        }
         SCG_L_TSTAMP(3);
 #ifndef DBG_NO_DW3
         // ---- output layer backward: dW3 from the transposed h2 tiles, then dz2 = (W3^T dout) * act'(h2) in place
@@ -331,6 +351,7 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         for (int tau = 0; tau < NT; ++tau) {
             float t[16];
             tile_transpose(scr, h2[tau], t, lane);                      // t[q] = h2[feature 32 tau + c][sample row(q, h)]
+            float a3[NOUT], x3[NOUT];
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 float acc = 0.0f;
@@ -340,8 +361,13 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
                     acc = __builtin_fmaf(t[4 * g], dv.x, acc); acc = __builtin_fmaf(t[4 * g + 1], dv.y, acc);
                     acc = __builtin_fmaf(t[4 * g + 2], dv.z, acc); acc = __builtin_fmaf(t[4 * g + 3], dv.w, acc);
                 }
-                acc += __shfl_xor(acc, 32, 64);
-                if (h == 0) gl_add(glw + G::DW3 + o * HID + 32 * tau + c, acc);
+                a3[o] = acc;
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) x3[o] = __shfl_xor(a3[o], 32, 64);
+            if (h == 0) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) gl_add(glw + G::DW3 + o * HID + 32 * tau + c, a3[o] + x3[o]);
             }
         }
 #endif
@@ -442,22 +468,30 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 #ifndef DBG_NO_DW2
         // ---- dW2 += h1 dz2^T over this tile's 32 samples (MFMA over sample pairs), db2: dz2 goes through the scratch as h1 did
         //      (8 in-place transposes for this product; transposing h1[tau] inside the rho loop made it 20)
+        float sb[NT], xb2[NT];
 #pragma unroll
         for (int rho = 0; rho < NT; ++rho) {
             tile_transpose_inplace(scr, h2[rho], lane);                 // dz2[out 32 rho + c][sample row(q, h)]
-            float sb = 0.0f;
+            float v = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sb += h2[rho][q];
-            sb += __shfl_xor(sb, 32, 64);
-            if (h == 0) gl_add(glw + G::DB2 + 32 * rho + c, sb);
+            for (int q = 0; q < 16; ++q) v += h2[rho][q];
+            sb[rho] = v;
         }
 #pragma unroll
-        for (int tau = 0; tau < NT; ++tau) {
+        for (int rho = 0; rho < NT; ++rho) xb2[rho] = __shfl_xor(sb[rho], 32, 64);
+        if (h == 0) {
 #pragma unroll
-            for (int rho = 0; rho < NT; ++rho) {
+            for (int rho = 0; rho < NT; ++rho) gl_add(glw + G::DB2 + 32 * rho + c, sb[rho] + xb2[rho]);
+        }
+        if constexpr (!ONE) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) dW2[tau][rho] = mfma32(h1[tau][q], h2[rho][q], dW2[tau][rho]);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int tau = 0; tau < NT; ++tau) {
+#pragma unroll
+                for (int rho = 0; rho < NT; ++rho) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) dW2[tau][rho] = mfma32(h1[tau][q], h2[rho][q], dW2[tau][rho]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
 #endif
@@ -472,20 +506,28 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     }
     SCG_L_STAMP(2);
     // ---- workgroup reduction and the partial vector
-    if constexpr (ACTOR) {
-#pragma unroll
-        for (int a = 0; a < NOUT; ++a) {
-            float v = dls[a];
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0) gl_add(glw + G::DLS + a, v);
-        }
-    }
+    // per-lane running sums (lanes of half 0) -> the wave's totals: rows of the wave's transpose scratch, lane k sums row k (fixed order) —
+    // butterflies over the lanes were up to 4 x 5 dependent ds_bpermute round trips at the end of every call
     {
-        float v0 = st_loss, v1 = st_kl;
+        static_assert((NOUT + 2) * 32 <= TR_WORDS, "rows in the transpose scratch");
+        if (lane < 32) {
 #pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) { v0 += __shfl_xor(v0, m, 64); v1 += __shfl_xor(v1, m, 64); }
-        if (lane == 0) { gl_add(glw + G::STAT + 0, v0); gl_add(glw + G::STAT + 1, v1); }
+            for (int a = 0; a < NOUT; ++a) scr[a * 32 + lane] = ACTOR ? dls[a] : 0.0f;
+            scr[NOUT * 32 + lane] = st_loss; scr[(NOUT + 1) * 32 + lane] = st_kl;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < NOUT + 2) {
+            float v = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(scr + lane * 32 + 4 * g);
+                v += d4.x; v += d4.y; v += d4.z; v += d4.w;
+            }
+            if (lane < NOUT) { if (ACTOR) gl_add(glw + G::DLS + lane, v); }
+            else gl_add(glw + G::STAT + (lane - NOUT), v);
+        }
         // entropy_loss = -sum_a (0.5 + 0.5 log(2 pi) + logstd_a) of the parameters THIS launch read: slot STAT + 2 of one partial vector
         // (every other workgroup contributes 0), so that the reduction needs no look at the parameters — which the fused reduction + Adam
         // kernel updates while it sums
@@ -515,23 +557,53 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     // summed in arrival order.)  Word order: [tile][lane][q].
     float* const stg = lds + L::W2F;                                    // H * H words
     static_assert(NT <= WAVES, "round 0 must write every tile row");
+    if constexpr (ONE) {
 #pragma unroll
-    for (int r = 0; r < WAVES; ++r) {
+        for (int r = 0; r < WAVES; ++r) {
+            const int tau = (wave + r) % WAVES;                         // wave-uniform
+            if (tau < NT) {
+                f32x16 a = h1[0];                                       // h1^T[tau]: picked by uniform branches (register arrays have no index)
 #pragma unroll
-        for (int tau = 0; tau < NT; ++tau) {
-            if (tau != ((wave + r) % WAVES)) continue;
+                for (int t = 1; t < NT; ++t) {
+                    if (tau == t) a = h1[t];
+                }
 #pragma unroll
-            for (int rho = 0; rho < NT; ++rho) {
-                float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+                for (int rho = 0; rho < NT; ++rho) {
+                    f32x16 d2;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {dW2[tau][rho][4 * g], dW2[tau][rho][4 * g + 1], dW2[tau][rho][4 * g + 2], dW2[tau][rho][4 * g + 3]};
-                    if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
-                    *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                    for (int q = 0; q < 16; ++q) d2[q] = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) d2 = mfma32(a[q], h2[rho][q], d2);
+                    float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {d2[4 * g], d2[4 * g + 1], d2[4 * g + 2], d2[4 * g + 3]};
+                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
+                        *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+#pragma unroll
+        for (int r = 0; r < WAVES; ++r) {
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) {
+                if (tau != ((wave + r) % WAVES)) continue;
+#pragma unroll
+                for (int rho = 0; rho < NT; ++rho) {
+                    float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {dW2[tau][rho][4 * g], dW2[tau][rho][4 * g + 1], dW2[tau][rho][4 * g + 2], dW2[tau][rho][4 * g + 3]};
+                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
+                        *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
     SCG_L_STAMP(4);
     // The workgroup's partial vector (74 KB for H = 128; 254 workgroups: 19 MB per call) leaves as 16-byte stores WRITTEN THROUGH
@@ -552,10 +624,27 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
 
 constexpr size_t grad_lds_words() { return grad_lds_base_words() + (private_dw1() ? (WAVES - 1) * W1R : 0); }
 
+template <bool ONE>
 __global__ __launch_bounds__(64 * WAVES, 1) void ppo_grad_kernel(const GradArgs A) {
     extern __shared__ __align__(16) float lds[];
-    if (blockIdx.y == 0) grad_net<NU, true>(A, lds);
-    else grad_net<1, false>(A, lds);
+    if (blockIdx.y == 0) grad_net<NU, true, ONE>(A, lds);
+    else grad_net<1, false, ONE>(A, lds);
+}
+// enqueue the gradient kernel: the one-tile form when no wave has more than one tile
+static int launch_grad(const GradArgs& G, int n_workgroups, hipStream_t st) {
+    const size_t bytes = grad_lds_words() * sizeof(float);
+    static scg::PerDeviceOnce set_g;
+    int dev;
+    if (set_g.pending(&dev)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        set_g.commit(dev);
+    }
+    static const bool force_multi = getenv("SCG_LEARN_MULTI_TILE") != nullptr;          // (A/B: the accumulating form at any size)
+    if (G.batch / 32 <= n_workgroups * WAVES && !force_multi) ppo_grad_kernel<true><<<dim3(n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
+    else ppo_grad_kernel<false><<<dim3(n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // Sum of the workgroup partials -> flat gradient vector (torch parameter order) + approx-KL slot + loss statistics.
@@ -853,12 +942,7 @@ extern "C" int scg_ppo_grad(const scg_ppo_grad_args* a, void* stream) {
     G.obs = a->d_obs; G.act = a->d_act; G.logp_old = a->d_logp_old; G.adv = a->d_adv; G.ret = a->d_ret; G.v_old = a->d_v_old;
     G.idx = a->d_idx; G.batch = a->batch; G.clip_param = a->clip_param; G.use_clipped_value = a->use_clipped_value;
     G.partials = (float*)a->d_workspace;
-    const size_t bytes = grad_lds_words() * sizeof(float);
-    static scg::PerDeviceOnce set_g;
-    int dev;
-    if (set_g.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_g.commit(dev); }
-    ppo_grad_kernel<<<dim3(a->n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_grad(G, a->n_workgroups, st)) return rc;
     ReduceArgs R;
     R.partials = G.partials; R.n_wg = a->n_workgroups; R.actor = a->actor; R.critic = a->critic; R.logstd_off = a->logstd_off;
     R.n_params = a->n_params; R.entropy_coef = a->entropy_coef; R.params = a->d_params; R.grad = a->d_grad; R.stats = a->d_stats;
@@ -880,12 +964,7 @@ extern "C" int scg_ppo_step(const scg_ppo_grad_args* a, float* d_m, float* d_v, 
     G.obs = a->d_obs; G.act = a->d_act; G.logp_old = a->d_logp_old; G.adv = a->d_adv; G.ret = a->d_ret; G.v_old = a->d_v_old;
     G.idx = a->d_idx; G.batch = a->batch; G.clip_param = a->clip_param; G.use_clipped_value = a->use_clipped_value;
     G.partials = (float*)a->d_workspace;
-    const size_t bytes = grad_lds_words() * sizeof(float);
-    static scg::PerDeviceOnce set_g;
-    int dev;
-    if (set_g.pending(&dev)) { HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); set_g.commit(dev); }
-    ppo_grad_kernel<<<dim3(a->n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_grad(G, a->n_workgroups, st)) return rc;
     StepArgs S;
     S.R.partials = G.partials; S.R.n_wg = a->n_workgroups; S.R.actor = a->actor; S.R.critic = a->critic; S.R.logstd_off = a->logstd_off;
     S.R.n_params = a->n_params; S.R.entropy_coef = a->entropy_coef; S.R.params = a->d_params; S.R.grad = a->d_grad; S.R.stats = a->d_stats;

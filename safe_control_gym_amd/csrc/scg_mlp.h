@@ -101,13 +101,17 @@ __device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, in
     using L = MlpLds<NIN, H, NOUT, SS>;
     {                                                                   // W1F[rho][q][lane(i,h)] = W1[32 rho + i][row(q,h)]
         constexpr int N1 = L::NT * L::L1Q * 64, IT = (N1 + NTHR - 1) / NTHR;
+        // (every load unconditional on a clamped address, the zero applied afterwards: as `cond ? load : 0` each load sat in its own
+        //  exec-masked branch, and in a kernel that spills — ppo_grad_kernel at its 512 registers — a scratch reload + s_waitcnt vmcnt(0)
+        //  in every such branch made the IT loads IT dependent memory round trips at kernel entry: most of the 4.8 us "fill")
         float v[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int k = tid + it * NTHR;
-            const int lane = k & 63, q = (k >> 6) % L::L1Q, rho = (k >> 6) / L::L1Q;
+            const int k = tid + it * NTHR, kc = k < N1 ? k : N1 - 1;
+            const int lane = kc & 63, q = (kc >> 6) % L::L1Q, rho = (kc >> 6) / L::L1Q;
             const int in = d_row(q, lane >> 5);
-            v[it] = (k < N1 && in < NIN) ? w.W1[(32 * rho + (lane & 31)) * NIN + in] : 0.0f;
+            const float x = w.W1[(32 * rho + (lane & 31)) * NIN + (in < NIN ? in : 0)];
+            v[it] = (k < N1 && in < NIN) ? x : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {

@@ -91,7 +91,7 @@ def run_sac(args, torch):
     env.close()
     return {'mode': 'sac', 'key': f'sac/{batch}/{ups}', 'vector_steps_executed': n_warm + 4 + args.iters, 'learning_vector_steps_executed': 4 + args.iters,
             'gradient_steps_executed': ups * (4 + args.iters), 'wall_ms_per_vector_step': 1e3 * wall / args.iters,
-            'flops_per_gradient_step': batch * (2 * a_f + 4 * q_f + 3 * a_f + 2 * q_f + 6 * q_f)}
+            'flops_per_gradient_step': batch * (2 * a_f + 4 * q_f + 2 * a_f + 2 * q_f + 6 * q_f)}       # (bench.py: actor forward counted once)
 
 
 def main():
