@@ -404,6 +404,16 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
             const int ip = lane & 31;
             const int qi = 4 * (ip >> 3) + (ip & 3), hi2 = (ip >> 2) & 1;
             const float* const xrow = xs + (c < NIN + 1 ? c : NIN + 1) * 32 + 4 * h;   // [x | 1 | 0][column c][sample row(., h)]
+            // (the weight operand of block (tp, rp) — 16 gathered words — is read one block AHEAD, in front of the previous block's products:
+            //  read where it is used, every 16-MFMA chain began with an exposed LDS round trip.  ONE only: the accumulating form has no
+            //  registers for the second buffer.)
+            float a_nx[16];
+            auto gather = [&](int tp, int rp, float* a) {
+                const float* base = lds + L::W2F + (rp * NT + tp) * L::TILE2 + 32 * hi2 * L::S + qi;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = base[d_row(q, h) * L::S];
+            };
+            if constexpr (ONE) gather(0, 0, a_nx);
 #pragma unroll
             for (int tp = 0; tp < NT; ++tp) {
                 f32x16 acc;
@@ -411,10 +421,15 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
                 for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 #pragma unroll
                 for (int rp = 0; rp < NT; ++rp) {
-                    const float* base = lds + L::W2F + (rp * NT + tp) * L::TILE2 + 32 * hi2 * L::S + qi;
                     float a[16];
+                    if constexpr (ONE) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) a[q] = base[d_row(q, h) * L::S];
+                        for (int q = 0; q < 16; ++q) a[q] = a_nx[q];
+                        if (rp + 1 < NT) gather(tp, rp + 1, a_nx);
+                        else if (tp + 1 < NT) gather(tp + 1, 0, a_nx);
+                    } else {
+                        gather(tp, rp, a);
+                    }
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc = mfma32(h2[rp][q], a[q], acc);
                     __builtin_amdgcn_sched_barrier(0);
@@ -554,9 +569,14 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     // round: in round r wave w owns the tile rows tau = (w + r) mod WAVES — round 0 writes, the later rounds read-add-write,
     // 16-byte LDS accesses — so row tau is summed in the order wave tau, tau - 1, ...  (One wave at a time, wave 0 to 3, made four
     // passes over the 64 KB instead of one: 9.3 us; 256 ds_add_f32 per lane from four waves onto the same words took 86 us and
-    // summed in arrival order.)  Word order: [tile][lane][q].
+    // summed in arrival order.)  Word order: [tile][g][lane][4] (accumulator word q = 4 g + r): every 16-byte access of a wave, in the LDS and
+    // in the partial vector, covers 1 KB of consecutive addresses.
     float* const stg = lds + L::W2F;                                    // H * H words
     static_assert(NT <= WAVES, "round 0 must write every tile row");
+    static_assert(G::END % 4 == 0 && PARTIAL_STRIDE % 4 == 0 && (HID * HID) % 4 == 0, "16-byte partial stores");
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)A.partials, 0, 0xffffffff, 0x00020000);
+    const uint32_t pbase = (uint32_t)(((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE * sizeof(float));
+    typedef unsigned int u32x4 __attribute__((vector_size(16)));
     if constexpr (ONE) {
 #pragma unroll
         for (int r = 0; r < WAVES; ++r) {
@@ -574,16 +594,21 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
                     for (int q = 0; q < 16; ++q) d2[q] = 0.0f;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) d2 = mfma32(a[q], h2[rho][q], d2);
-                    float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+                    const int word = ((tau * NT + rho) * 4 * 64 + lane) * 4;          // [tile][g][lane][4]
+                    float* const p = stg + word;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {d2[4 * g], d2[4 * g + 1], d2[4 * g + 2], d2[4 * g + 3]};
-                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
-                        *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 256 * g);
+                        // the LAST round completes the row: it leaves for the partial vector at once (same word order as the staging area)
+                        // instead of one more pass through the LDS, a barrier and the cooperative copy
+                        if (r == WAVES - 1)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), pr, pbase + 4u * (uint32_t)(G::END + word + 256 * g), 0, SCG_L_PART_AUX);
+                        else *reinterpret_cast<f32x4*>(p + 256 * g) = v;
                     }
                 }
             }
-            __syncthreads();
+            if (r < WAVES - 1) __syncthreads();
         }
     } else {
 #pragma unroll
@@ -593,12 +618,12 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
                 if (tau != ((wave + r) % WAVES)) continue;
 #pragma unroll
                 for (int rho = 0; rho < NT; ++rho) {
-                    float* const p = stg + ((tau * NT + rho) * 64 + lane) * 16;
+                    float* const p = stg + ((tau * NT + rho) * 4 * 64 + lane) * 4;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {dW2[tau][rho][4 * g], dW2[tau][rho][4 * g + 1], dW2[tau][rho][4 * g + 2], dW2[tau][rho][4 * g + 3]};
-                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 4 * g);
-                        *reinterpret_cast<f32x4*>(p + 4 * g) = v;
+                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 256 * g);
+                        *reinterpret_cast<f32x4*>(p + 256 * g) = v;
                     }
                 }
             }
@@ -610,15 +635,13 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     // (sc0 sc1, SCG_L_PART_AUX): the reduction kernel that follows reads it from other XCDs, so it has to reach the memory side
     // before this kernel may retire — written back, that is one flush behind the LAST workgroup's last store; written through,
     // the partials of workgroups that finish early (the tile counts differ by one between waves) are out already.
-    static_assert(G::END % 4 == 0 && PARTIAL_STRIDE % 4 == 0 && (HID * HID) % 4 == 0, "16-byte partial stores");
-    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)A.partials, 0, 0xffffffff, 0x00020000);
-    const uint32_t pbase = (uint32_t)(((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE * sizeof(float));
-    typedef unsigned int u32x4 __attribute__((vector_size(16)));
     for (int k = 4 * tid; k < G::END; k += 4 * blockDim.x)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(gl + k)), pr, pbase + 4u * (uint32_t)k, 0, SCG_L_PART_AUX);
-    for (int k = 4 * tid; k < HID * HID; k += 4 * blockDim.x)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(stg + k)), pr, pbase + 4u * (uint32_t)(G::END + k), 0,
-                                               SCG_L_PART_AUX);
+    if constexpr (!ONE) {
+        for (int k = 4 * tid; k < HID * HID; k += 4 * blockDim.x)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(stg + k)), pr, pbase + 4u * (uint32_t)(G::END + k), 0,
+                                                   SCG_L_PART_AUX);
+    }
     SCG_L_STAMP(5);
 }
 
@@ -667,8 +690,8 @@ __device__ __forceinline__ int dest_of(int k, const scg_mlp_layout& lay, int log
     if (k < G::DLS) return (k - G::DB3) < NOUT ? lay.b3 + (k - G::DB3) : -1;
     if (k < G::STAT) return (actor && (k - G::DLS) < NOUT) ? logstd_off + (k - G::DLS) : -1;
     if (k < G::END) return -2 - (k - G::STAT);                          // statistics slots
-    const int p = k - G::END;                                           // dW2 staging order [tile][lane][q] -> W2[out][in]
-    const int q = p & 15, lane = (p >> 4) & 63, tr = p >> 10;
+    const int p = k - G::END;                                           // dW2 staging order -> W2[out][in]
+    const int q = 4 * ((p >> 8) & 3) + (p & 3), lane = (p >> 2) & 63, tr = p >> 10;       // word order [tile][g][lane][4], q = 4 g + r
     const int tau = tr / NT, rho = tr % NT;
     return lay.W2 + (32 * rho + (lane & 31)) * HID + 32 * tau + d_row(q, lane >> 5);
 }

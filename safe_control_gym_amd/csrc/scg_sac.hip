@@ -9,21 +9,29 @@
 // over the workgroup's waves (see "wide tiles" below); all matrix products on v_mfma_f32_32x32x2_f32 (exact float32).
 //   actor_fwd_kernel     batch rows ~ U[0, ring size) (SACBuffer.sample :399-413), then
 //                        a, log pi (tanh-Gaussian, reparameterised)                       MLPActor.forward  (:185-222)
+//                        + what the policy gradient needs of this pass: the waves' h1 / h2 tiles, tanh u, sigma, the clamp's pass flags
 //   q_kernel<1>          q_y(obs, a) and dq_y/da for y = 1, 2 (forward + data gradient)   compute_policy_loss (:110-127)
-//   actor_grad_kernel    d mean(alpha log pi - min q)/d(actor), forward recomputed, weight gradients
+//   actor_grad_kernel    d mean(alpha log pi - min q)/d(actor) from the stored pass: starts at the loss derivatives
 //   reduce_kernel        sum of the partials + Adam: actor (+ log_alpha), soft update of the actor's target copy
 //   actor_fwd_kernel     a', log pi' at next_obs with the UPDATED actor                   compute_q_loss    (:129-141)
-//   q_kernel<0>          target networks at (next_obs, a')
-//   q_kernel<2>          d[mean (q_y - target)^2]/d(q_y), y = 1, 2
-//   reduce_kernel        sum of the partials + Adam: critics, soft update of their target copies        (:163-168)
-//   finish_kernel        step counters, loss statistics
+//                        [scg_sac_update_n: + the NEXT step's first launch as a second job — same actor, 2 x 128 workgroups fill the chip]
+//   q_kernel<0>          target networks at (next_obs, a'); beside them (blockIdx.y = 2, 3) the online critics' forward pass at
+//                        (obs, act) — it does not depend on the targets — leaving q, the h1 / h2 tiles, reward and mask per batch row
+//   q_kernel<2>          d[mean (q_y - target)^2]/d(q_y), y = 1, 2, from the stored pass: starts at the loss derivatives
+//   reduce_kernel        sum of the partials + Adam: critics, soft update of their target copies + the step's bookkeeping  (:163-168)
+//   [finish_kernel       step counters, loss statistics: data-parallel path only]
 // (Data-parallel callers run the phases separately — include/scg_sac.h — with reduce_kernel writing the gradient only and
 //  adam_kernel stepping after the all-reduce.)
+// What a launch leaves for the next one (partial vectors, activation tiles) is stored write-through, 1 KB of consecutive addresses per
+// instruction: it is read on other XCDs, so it must reach the memory side before the kernel retires — written back that is one flush
+// of megabytes behind the last workgroup.  Requests at kernel entry are ordered by need, and nothing in front of the first barrier
+// waits for an index -> row gather (profiles/r06_sac_actor_grad_timeline.txt).
 // Gradient reduction: every WORKGROUP owns one partial gradient vector in global memory (a workgroup usually owns one tile: plain
 // stores), reduce_kernel sums the partials in a fixed order — no atomics, bitwise reproducible.
 // History: until late in round 3 a tile belonged to ONE wave behind a 100 KB LDS weight image (scg_learn.hip's scheme, right for
 // PPO's 2000-tile minibatches): 0.211 ms per step at batch 4096, where 128 tiles left 7/8 of the SIMDs idle behind 288-864
-// dependent MFMAs each; the wide tiles run the same step in 0.114 ms (profiles/r03_sac_update_cost.json).
+// dependent MFMAs each; the wide tiles run the same step in 0.114 ms (profiles/r03_sac_update_cost.json), round 6's in 0.078 ms
+// (profiles/r06_sac_step_ab.txt: stored passes, merged launches, write-through hand-over, ordered requests).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

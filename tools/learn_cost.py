@@ -41,17 +41,19 @@ for _ in range(50):
 ev[1].record(); torch.cuda.synchronize()
 print(f'adam_gated: {1e3 * ev[0].elapsed_time(ev[1]) / 50:.1f} us per call')
 
-if '--timeline' in sys.argv:            # needs a library built with SCG_LEARN_FLAGS=-DSCG_L_TIMING
-    F = ag._build_fused(data, 65536)
-    F['idx'].copy_(torch.randperm(M, device='cuda')[:65536].to(torch.int32))
+if '--timeline' in sys.argv:            # needs a library built with SCG_LEARN_FLAGS=-DSCG_L_TIMING; --mb 16256: the one-tile form (round 6)
+    mbt = int(sys.argv[sys.argv.index('--mb') + 1]) if '--mb' in sys.argv else 65536
+    F = ag._build_fused(data, mbt)
+    F['idx'].copy_(torch.randperm(M, device='cuda')[:mbt].to(torch.int32))
+    print(f'timeline at minibatch {mbt}: {F["args"].n_workgroups} workgroups per network, {mbt // 32 / (F["args"].n_workgroups * 4):.2f} tiles per wave')
     for _ in range(3):
         ag._fused_grad(F)
     torch.cuda.synchronize()
     T = F['ws'][-256:].view(torch.int64).cpu().tolist()
     t = T[:6]
-    names = ['fill + barrier', 'tile loop (4 tiles)', 'small-gradient sums + barrier', 'dW2 staging', 'partial vector write']
+    names = ['fill + barrier', 'tile loop', 'small-gradient sums + barrier', 'dW2 staging (one-tile form: products + cross-wave sum + row stores)', 'partial vector write']
     for n, a, b in zip(names, t, t[1:]):
-        print(f'  {n:40s} {(b - a) / 2400.0:8.2f} us')
+        print(f'  {n:75s} {(b - a) / 2400.0:8.2f} us')
     # one warm tile (the wave's last), phase boundaries; the two forward-pass stamps sit between 'inputs' and 'loss derivatives'
     tt = [T[8], T[9], T[24], T[25]] + T[10:16]
     names = ['index -> observation gather, sample cache', 'forward layer 1 (+ activations)', 'forward layer 2 (+ activations)', 'output layer',
