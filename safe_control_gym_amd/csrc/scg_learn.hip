@@ -87,7 +87,11 @@ __device__ __forceinline__ void load_x(const float* __restrict__ obs, int sample
 // A tile is 32 NT (NT + L1Q / 16) dependent MFMAs followed, layer by layer, by the activation of 16 NT values per lane on the vector
 // unit (tanh = v_exp + v_rcp at quarter rate: ~40 % of the tile's time with one wave per SIMD, during which the matrix pipe idles);
 // a second wave's products run under it.
-constexpr int FWD_WAVES = 8;
+#ifndef SCG_L_FWD_WAVES
+#define SCG_L_FWD_WAVES 8
+#endif
+constexpr int FWD_WAVES = SCG_L_FWD_WAVES;                  // (12 = three per SIMD, measured: see DESIGN 4.6)
+constexpr int FWD_FILL = FWD_WAVES > 8 ? 512 : 64 * FWD_WAVES;          // threads that fill the image (must divide H * H)
 template <int NOUT>
 __global__ __launch_bounds__(64 * FWD_WAVES) void mlp_forward_kernel(const float* __restrict__ params, const scg_mlp_layout lay,
                                                           const float* __restrict__ xin, int M, float* __restrict__ out,
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void mlp_forward_kernel(const float
     using L = MlpLds<NIN, HID, NOUT>;
     extern __shared__ __align__(16) float lds[];
     const MlpWeights w = weights_of(params, lay);
-    mlp_fill_lds<NIN, HID, NOUT, 20, 64 * FWD_WAVES>(lds, w, threadIdx.x);
+    if (FWD_FILL == 64 * FWD_WAVES || (int)threadIdx.x < FWD_FILL) mlp_fill_lds<NIN, HID, NOUT, 20, FWD_FILL>(lds, w, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -209,8 +213,26 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     // call paid it on its critical path).  (The rows themselves requested up here as well cost 40 more spilled registers: not kept.)
     const int n_tiles = A.batch / 32;
     const int tile0 = blockIdx.x * WAVES + wave;
-    const int s_pre = tile0 < n_tiles ? A.idx[tile0 * 32 + c] : 0;
-    mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid);
+    const int s_pre = A.idx[tile0 < n_tiles ? tile0 * 32 + c : c];      // (unconditional: a `cond ? load : 0` keeps its use in the load's branch)
+    // ONE: the first (only) tile's rows and per-sample scalars are requested INSIDE the fill, once its first batch of requests is out —
+    // they arrive under the rest of the fill instead of costing a round trip behind its barrier (the accumulating form has no registers
+    // for them: 40 spilled words when it was tried there)
+    float x_pre[L1Q], act_pre[NOUT], a_pre = 0.0f, b_pre = 0.0f;
+    if constexpr (ONE) {
+        mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid, [&]() {
+            load_x<L1Q>(A.obs, s_pre, h, x_pre);
+            if constexpr (ACTOR) {
+#pragma unroll
+                for (int a = 0; a < NOUT; ++a) act_pre[a] = A.act[(size_t)s_pre * NOUT + a];
+                a_pre = A.logp_old[s_pre]; b_pre = A.adv[s_pre];
+            } else {
+                a_pre = A.ret[s_pre];
+                if (A.use_clipped_value) b_pre = A.v_old[s_pre];
+            }
+        });
+    } else {
+        mlp_fill_lds<NIN, HID, NOUT>(lds, w, tid);
+    }
     for (int k = tid; k < G::END; k += blockDim.x) gl[k] = 0.0f;
     if constexpr (private_dw1()) {
         for (int k = tid; k < (WAVES - 1) * W1R; k += blockDim.x) w1_all[k] = 0.0f;
@@ -260,15 +282,23 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         // the per-sample scalars of the loss are requested here, a forward pass ahead of their use (asked for where they are
         // used, their round trip to memory was 2.3 us of a 37 us tile)
         float s_act[NOUT], s_a = 0.0f, s_b = 0.0f;
-        const int s = tile == tile0 ? s_pre : A.idx[tile * 32 + c];
-        load_x<L1Q>(A.obs, s, h, x);
-        if constexpr (ACTOR) {
+        if constexpr (ONE) {
 #pragma unroll
-            for (int a = 0; a < NOUT; ++a) s_act[a] = A.act[(size_t)s * NOUT + a];
-            s_a = A.logp_old[s]; s_b = A.adv[s];
+            for (int q = 0; q < L1Q; ++q) x[q] = x_pre[q];
+#pragma unroll
+            for (int a = 0; a < NOUT; ++a) s_act[a] = act_pre[a];
+            s_a = a_pre; s_b = b_pre;
         } else {
-            s_a = A.ret[s];
-            if (A.use_clipped_value) s_b = A.v_old[s];
+            const int s = tile == tile0 ? s_pre : A.idx[tile * 32 + c];
+            load_x<L1Q>(A.obs, s, h, x);
+            if constexpr (ACTOR) {
+#pragma unroll
+                for (int a = 0; a < NOUT; ++a) s_act[a] = A.act[(size_t)s * NOUT + a];
+                s_a = A.logp_old[s]; s_b = A.adv[s];
+            } else {
+                s_a = A.ret[s];
+                if (A.use_clipped_value) s_b = A.v_old[s];
+            }
         }
         // sample cache for dW1: xs[input column][sample c]
 #pragma unroll

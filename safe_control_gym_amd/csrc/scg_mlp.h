@@ -92,54 +92,74 @@ constexpr int fill_chunk(int it) {
 }
 
 // Cooperative fill of the LDS image from torch-layout parameters (all NTHR threads of the workgroup; caller barriers after).
-// Global reads run along the rows of W (coalesced), the permutation is applied on the LDS side.  Each phase issues ALL its
-// global loads before its first LDS store: written element by element (load, permute, store, next) the fill exposed one
-// memory round trip per element — with one wave per SIMD that was ~1 us x 64 iterations, a third of the gradient kernel's
-// time at four tiles per wave.
-template <int NIN, int H, int NOUT, int SS = 20, int NTHR = 256>
-__device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, int tid) {
+// Global reads run along the rows of W (coalesced), the permutation is applied on the LDS side.
+// Request schedule (round 6): the fill is memory round trips, so they are made to overlap — W1, W3, the biases and the FIRST chunk of W2
+// are all requested before the first LDS store; every later W2 chunk is requested before the previous one is stored.  (History: written
+// element by element — load, permute, store — the fill exposed one round trip per element, ~1 us x 64 at one wave per SIMD; with each
+// PHASE issuing its loads before its stores it was still five dependent round trips, 3.8 of the gradient kernel's 46 us per call.)
+// Every load is unconditional on a clamped address, the zero applied afterwards: as `cond ? load : 0` each load sat in its own
+// exec-masked branch, and in a kernel that spills a scratch reload + s_waitcnt vmcnt(0) in every branch serialised them.
+// `between()` runs once, after the first batch of requests has been issued and before the first LDS store: the caller's own early requests
+// (a first tile's rows, whose index load it issued before the call) go there and arrive under the rest of the fill.
+struct MlpFillNothing { __device__ __forceinline__ void operator()() const {} };
+template <int NIN, int H, int NOUT, int SS = 20, int NTHR = 256, typename Between = MlpFillNothing>
+__device__ __forceinline__ void mlp_fill_lds(float* lds, const MlpWeights& w, int tid, Between between = Between()) {
     using L = MlpLds<NIN, H, NOUT, SS>;
-    {                                                                   // W1F[rho][q][lane(i,h)] = W1[32 rho + i][row(q,h)]
-        constexpr int N1 = L::NT * L::L1Q * 64, IT = (N1 + NTHR - 1) / NTHR;
-        // (every load unconditional on a clamped address, the zero applied afterwards: as `cond ? load : 0` each load sat in its own
-        //  exec-masked branch, and in a kernel that spills — ppo_grad_kernel at its 512 registers — a scratch reload + s_waitcnt vmcnt(0)
-        //  in every such branch made the IT loads IT dependent memory round trips at kernel entry: most of the 4.8 us "fill")
-        float v[IT];
+    // ---- requests: W1F[rho][q][lane(i,h)] = W1[32 rho + i][row(q,h)]
+    constexpr int N1 = L::NT * L::L1Q * 64, IT1 = (N1 + NTHR - 1) / NTHR;
+    float v1[IT1];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int k = tid + it * NTHR, kc = k < N1 ? k : N1 - 1;
-            const int lane = kc & 63, q = (kc >> 6) % L::L1Q, rho = (kc >> 6) / L::L1Q;
-            const int in = d_row(q, lane >> 5);
-            const float x = w.W1[(32 * rho + (lane & 31)) * NIN + (in < NIN ? in : 0)];
-            v[it] = (k < N1 && in < NIN) ? x : 0.0f;
+    for (int it = 0; it < IT1; ++it) {
+        const int k = tid + it * NTHR, kc = k < N1 ? k : N1 - 1;
+        const int lane = kc & 63, q = (kc >> 6) % L::L1Q, rho = (kc >> 6) / L::L1Q;
+        const int in = d_row(q, lane >> 5);
+        const float x = w.W1[(32 * rho + (lane & 31)) * NIN + (in < NIN ? in : 0)];
+        v1[it] = (k < N1 && in < NIN) ? x : 0.0f;
+    }
+    // ---- W3, biases
+    constexpr int N3 = NOUT * H, IT3 = (N3 + NTHR - 1) / NTHR;
+    float v3[IT3];
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) { const int k = tid + it * NTHR; v3[it] = w.W3[k < N3 ? k : N3 - 1]; }
+    static_assert(H <= NTHR && NOUT <= NTHR, "one bias word per thread and layer");
+    const float vb1 = w.b1[tid < H ? tid : H - 1], vb2 = w.b2[tid < H ? tid : H - 1], vb3 = w.b3[tid < NOUT ? tid : NOUT - 1];
+    // ---- W2 in chunks (source order: W2[o][in], in fastest), one chunk in flight ahead of the stores
+    static_assert((H * H) % NTHR == 0, "workgroup size must divide H * H");
+    constexpr int IT = H * H / NTHR, CH = fill_chunk(IT);             // H = 96: 36 loads per thread in two chunks of 18
+    static_assert(IT % CH == 0, "chunking");
+    float cur[CH], nxt[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) cur[j] = w.W2[tid + j * NTHR];
+    between();
+    // ---- stores of the first batch
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int k = tid + it * NTHR;
+        if (k < N1) lds[L::W1F + k] = v1[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) { const int k = tid + it * NTHR; if (k < N3) lds[L::W3 + k] = v3[it]; }
+    if (tid < H) { lds[L::B1 + tid] = vb1; lds[L::B2 + tid] = vb2; }
+    if (tid < NOUT) lds[L::B3 + tid] = vb3;
+#pragma unroll
+    for (int base = 0; base < IT; base += CH) {
+        if (base + CH < IT) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) nxt[j] = w.W2[tid + (base + CH + j) * NTHR];
         }
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int k = tid + it * NTHR;
-            if (k < N1) lds[L::W1F + k] = v[it];
+        for (int j = 0; j < CH; ++j) {
+            const int k = tid + (base + j) * NTHR;
+            const int o = k / H, in = k % H;
+            const int rho = o >> 5, i = o & 31, tau = in >> 5, r = in & 31;
+            const int q = 4 * (r >> 3) + (r & 3), h = (r >> 2) & 1;
+            lds[L::W2F + (rho * L::NT + tau) * L::TILE2 + (i + 32 * h) * L::S + q] = cur[j];
+        }
+        if (base + CH < IT) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
         }
     }
-    {                                                                   // source order: W2[o][in], in fastest
-        static_assert((H * H) % NTHR == 0, "workgroup size must divide H * H");
-        constexpr int IT = H * H / NTHR, CH = fill_chunk(IT);         // H = 96: 36 loads per thread in two chunks of 18
-        static_assert(IT % CH == 0, "chunking");
-        for (int base = 0; base < IT; base += CH) {
-            float v[CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) v[j] = w.W2[tid + (base + j) * NTHR];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int k = tid + (base + j) * NTHR;
-                const int o = k / H, in = k % H;
-                const int rho = o >> 5, i = o & 31, tau = in >> 5, r = in & 31;
-                const int q = 4 * (r >> 3) + (r & 3), h = (r >> 2) & 1;
-                lds[L::W2F + (rho * L::NT + tau) * L::TILE2 + (i + 32 * h) * L::S + q] = v[j];
-            }
-        }
-    }
-    for (int k = tid; k < NOUT * H; k += NTHR) lds[L::W3 + k] = w.W3[k];
-    for (int k = tid; k < H; k += NTHR) { lds[L::B1 + k] = w.b1[k]; lds[L::B2 + k] = w.b2[k]; }
-    for (int k = tid; k < NOUT; k += NTHR) lds[L::B3 + k] = w.b3[k];
 }
 
 // The 16 A operands (q = 0..15) of lane `lane` for the layer-2 tile (rho, tau): four 16-byte LDS reads.

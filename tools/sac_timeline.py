@@ -8,9 +8,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('SCG_SAC_FLAGS', '-DSCG_S_TIMING')
-NAMES = ['start', 'data-gradient operand, stored tiles and row values requested + small block filled + barrier', 'first tile: rows arrived, sample cache',
+NAMES = ['start', 'data-gradient operand, stored tiles and row values requested + small block filled + barrier', 'first tile: stored tiles and row values arrived',
          'loss derivatives (from the stored head: no forward pass, no tanh-Gaussian algebra)',
-         'db3 + dW3 (h2 transposed)', 'dz2, dz2^T, db2, h1^T (before the barrier)', 'barrier', 'data gradient (64 MFMA) x act\'', 'dW1 | db1 (16 MFMA) + store',
+         'db3 + dW3 (h2 transposed)', 'dz2, dz2^T, db2, h1^T, sample cache (before the barrier)', 'barrier', 'data gradient (64 MFMA) x act\'', 'dW1 | db1 (16 MFMA) + store',
          'dW2 (64 MFMA) + 64 KB of partial stores', 'barrier', 'statistics, end']
 
 
