@@ -31,8 +31,8 @@ void scg_learn_shape(int32_t* obs_dim, int32_t* hidden, int32_t* act_dim, int32_
 
 /* MLP.forward on a batch (neural_networks.py:45-54): d_x [m][obs_dim] -> d_out [m][nout], nout = act_dim or 1.
  * d_row_mask (nullable, [m] bytes): sparse evaluation — rows are processed in tiles of 32; a tile without a non-zero mask
- * byte is skipped and its outputs are written as 0 (used for the critic's values of the few time-limit-truncated
- * terminal observations of a rollout, ppo.py:276-283). */
+ * byte is skipped, and every row whose mask byte is 0 is written as 0 (used for the critic's values of the few
+ * time-limit-truncated terminal observations of a rollout, ppo.py:276-283: the output IS the bootstrap term). */
 int scg_mlp_forward(const float* d_params, const scg_mlp_layout* layout, int nout, const float* d_x, int m, float* d_out,
                     const uint8_t* d_row_mask, void* stream);
 
@@ -93,6 +93,22 @@ int scg_adam_gated_scaled(float* d_p, const float* d_g, float* d_m, float* d_v, 
  * all-reduced between the two halves, keep scg_ppo_grad + scg_adam_gated. */
 int scg_ppo_step(const scg_ppo_grad_args* args, float* d_m, float* d_v, float lr_actor, float lr_critic, const float* d_steps_in,
                  float* d_steps_out, float target_kl, float* d_stats_acc, void* stream);
+
+/* The collector's post-processing between rollout and update (PPO.train_step, controllers/ppo/ppo.py:276-300) over the [T][N] rollout,
+ * four launches in place of ~30 elementwise / reduction kernels:
+ *   scg_ppo_returns_prepare    d_trunc = done & (flags & 1) (time truncation is not termination), d_mask = 1 - done, d_rew_out = rew
+ *                              (scg_gae adds gamma * terminal_v to it in place), d_v_out = d_v_all[:T]; run it in front of the masked
+ *                              critic pass over the terminal observations (scg_mlp_forward with d_row_mask = d_trunc)
+ *   scg_ppo_returns_moments    d_moments[3] = {sum adv, sum adv^2, T N} (fixed-order two-stage sum); d_episode_acc (nullable, [N][8]:
+ *                              scg_policy_rollout.d_episode_acc): columns 0..3 are added to d_episode_totals[4] and the array is zeroed
+ *   scg_ppo_returns_normalise  d_out = (adv - mean) / (std + 1e-6), population std (ppo.py:300), from d_moments — all-reduce (sum) the
+ *                              moments between the two calls on several ranks.  d_out may alias d_adv. */
+int scg_ppo_returns_prepare(const uint8_t* d_done, const uint8_t* d_flags, const float* d_rew, const float* d_v_all, int T, int N,
+                            uint8_t* d_trunc, float* d_mask, float* d_rew_out, float* d_v_out, void* stream);
+size_t scg_ppo_returns_scratch_bytes(void);
+int scg_ppo_returns_moments(const float* d_adv, int T, int N, float* d_episode_acc, float* d_scratch, float* d_moments,
+                            float* d_episode_totals, void* stream);
+int scg_ppo_returns_normalise(const float* d_adv, const float* d_moments, int T, int N, float* d_out, void* stream);
 
 /* d_out[i] = pi(i) for i < count, pi a keyed pseudo-random permutation of [0, n) (count <= n): the shuffled row indices of
  * one epoch's minibatches (SubsetRandomSampler + BatchSampler(drop_last=True), ppo_utils.py:358-371), one launch. */

@@ -89,6 +89,11 @@ def lib(obs_dim, hidden, act_dim, activation):
                                         C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     D.scg_random_permutation.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
     D.scg_random_permutation_keyed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    D.scg_ppo_returns_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+    D.scg_ppo_returns_scratch_bytes.restype = C.c_size_t
+    D.scg_ppo_returns_moments.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    D.scg_ppo_returns_normalise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     shape = [C.c_int32() for _ in range(4)]
     D.scg_learn_shape(*[C.byref(v) for v in shape])
     if tuple(v.value for v in shape) != (obs_dim, hidden, act_dim, ACTS[activation]):

@@ -21,6 +21,7 @@
 //     that the data-parallel all-reduce carries), deterministic: no global atomics anywhere.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -124,8 +125,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void mlp_forward_kernel(const float
         float o[NOUT];
         mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, o, lane);
         if (live && h == 0) {
+            const bool keep = !row_mask || row_mask[s] != 0;            // (a masked pass returns 0 on every row that is not flagged)
 #pragma unroll
-            for (int k = 0; k < NOUT; ++k) out[(size_t)s * NOUT + k] = o[k];
+            for (int k = 0; k < NOUT; ++k) out[(size_t)s * NOUT + k] = keep ? o[k] : 0.0f;
         }
     }
 }
@@ -310,9 +312,9 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
         SCG_L_TSTAMP(1);
         float out[NOUT], dout[NOUT];
 #ifdef SCG_L_TIMING
-        mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, out, lane, tst + 8);
+        mlp_forward_tile<NIN, HID, NOUT, ACT, 20, ACT, ONE>(lds, x, h1, h2, out, lane, tst + 8);
 #else
-        mlp_forward_tile<NIN, HID, NOUT, ACT>(lds, x, h1, h2, out, lane);
+        mlp_forward_tile<NIN, HID, NOUT, ACT, 20, ACT, ONE>(lds, x, h1, h2, out, lane);
 #endif
         SCG_L_TSTAMP(2);
         // ---- loss derivatives w.r.t. the network outputs (both lane halves compute the same numbers)
@@ -916,6 +918,108 @@ __global__ __launch_bounds__(256) void permutation_kernel(int32_t* __restrict__ 
         x = (l << half) | r;
     } while (x >= n);
     out[i] = (int32_t)x;
+}
+
+// ------------------------------------------------------------------ the collector's post-processing
+// Between the rollout and the update PPO.train_step (controllers/ppo/ppo.py:276-300) derives, elementwise over the [T][N] rollout, the
+// time-limit flags, masks, bootstrap terms, the advantage moments and the normalised advantages — ~30 PyTorch kernels of 4-11 us each
+// (5 % of an iteration at 65 536 envs).  Here: one kernel in front of the bootstrap critic pass, three behind scg_gae.
+//   prepare:    trunc = done & (flags & 1)  (time truncation is not termination, ppo.py:276-283), mask = 1 - done, rew_out = rew (scg_gae
+//               adds gamma * terminal_v to it in place, like the reference does to its buffer), v_out = v_all[:T]
+//   moments:    block partials of sum(adv), sum(adv^2) and of the first four columns of the per-env episode accumulators, which are zeroed
+//   finish:     fixed-order sum of the partials -> moments = {sum, sum of squares, count}; the episode totals are added to the running ones
+//   normalise:  adv <- (adv - mean) / (std + 1e-6), population std (ppo.py:300), from the moments (after the caller's all-reduce, if any)
+constexpr int RET_BLOCKS = 256;
+__global__ __launch_bounds__(256) void returns_prepare_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ flags,
+                                                               const float* __restrict__ rew, const float* __restrict__ v_all, int M,
+                                                               uint8_t* __restrict__ trunc, float* __restrict__ mask,
+                                                               float* __restrict__ rew_out, float* __restrict__ v_out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const uint8_t d = done[i];
+        trunc[i] = (uint8_t)((flags[i] & 1) & d);
+        mask[i] = 1.0f - (float)d;
+        rew_out[i] = rew[i];
+        v_out[i] = v_all[i];
+    }
+}
+__device__ __forceinline__ float block_sum256(float v, float* red) {       // fixed order: butterfly inside the wave, waves 0..3 in order
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
+__global__ __launch_bounds__(256) void returns_moments_kernel(const float* __restrict__ adv, int M, float* __restrict__ episode_acc, int N,
+                                                               float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s1 = 0.0f, s2 = 0.0f, e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) { const float a = adv[i]; s1 += a; s2 = __builtin_fmaf(a, a, s2); }
+    if (episode_acc) {
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+            f32x4* const row = reinterpret_cast<f32x4*>(episode_acc + (size_t)n * 8);
+            const f32x4 a = row[0];
+            e[0] += a.x; e[1] += a.y; e[2] += a.z; e[3] += a.w;
+            row[0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; row[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    float out[6] = {block_sum256(s1, red), block_sum256(s2, red), block_sum256(e[0], red), block_sum256(e[1], red), block_sum256(e[2], red),
+                    block_sum256(e[3], red)};
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) partials[blockIdx.x * 8 + k] = out[k];
+    }
+}
+__global__ __launch_bounds__(64) void returns_finish_kernel(const float* __restrict__ partials, int n_blocks, float count, float* __restrict__ moments,
+                                                             float* __restrict__ ep_totals) {
+    const int k = threadIdx.x;
+    if (k >= 6) return;
+    float s = 0.0f;
+    for (int b = 0; b < n_blocks; ++b) s += partials[b * 8 + k];
+    if (k < 2) moments[k] = s;
+    else if (ep_totals) ep_totals[k - 2] += s;
+    if (k == 0) moments[2] = count;
+}
+__global__ __launch_bounds__(256) void returns_normalise_kernel(const float* __restrict__ adv, const float* __restrict__ moments, int M,
+                                                                 float* __restrict__ out) {
+    const float mean = moments[0] / moments[2];
+    const float var = fmaxf(moments[1] / moments[2] - mean * mean, 0.0f);
+    const float den = sqrtf(var) + 1e-6f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) out[i] = (adv[i] - mean) / den;
+}
+
+extern "C" int scg_ppo_returns_prepare(const uint8_t* d_done, const uint8_t* d_flags, const float* d_rew, const float* d_v_all, int T, int N,
+                                       uint8_t* d_trunc, float* d_mask, float* d_rew_out, float* d_v_out, void* stream) {
+    if (!d_done || !d_flags || !d_rew || !d_v_all || !d_trunc || !d_mask || !d_rew_out || !d_v_out || T <= 0 || N <= 0)
+        return fail(-1, "scg_ppo_returns_prepare: bad argument");
+    const long long M = (long long)T * N;
+    if (M > 0x7fffffffLL) return fail(-1, "scg_ppo_returns_prepare: T x N too large");
+    const int grid = (int)std::min<long long>((M + 255) / 256, 4096);
+    returns_prepare_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(d_done, d_flags, d_rew, d_v_all, (int)M, d_trunc, d_mask, d_rew_out, d_v_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" size_t scg_ppo_returns_scratch_bytes(void) { return (size_t)RET_BLOCKS * 8 * sizeof(float); }
+extern "C" int scg_ppo_returns_moments(const float* d_adv, int T, int N, float* d_episode_acc, float* d_scratch, float* d_moments,
+                                       float* d_episode_totals, void* stream) {
+    if (!d_adv || !d_scratch || !d_moments || T <= 0 || N <= 0) return fail(-1, "scg_ppo_returns_moments: bad argument");
+    const long long M = (long long)T * N;
+    if (M > 0x7fffffffLL) return fail(-1, "scg_ppo_returns_moments: T x N too large");
+    const int grid = (int)std::min<long long>((M + 255) / 256, RET_BLOCKS);
+    returns_moments_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(d_adv, (int)M, d_episode_acc, N, d_scratch);
+    returns_finish_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(d_scratch, grid, (float)M, d_moments, d_episode_acc ? d_episode_totals : nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int scg_ppo_returns_normalise(const float* d_adv, const float* d_moments, int T, int N, float* d_out, void* stream) {
+    if (!d_adv || !d_moments || !d_out || T <= 0 || N <= 0) return fail(-1, "scg_ppo_returns_normalise: bad argument");
+    const long long M = (long long)T * N;
+    if (M > 0x7fffffffLL) return fail(-1, "scg_ppo_returns_normalise: T x N too large");
+    const int grid = (int)std::min<long long>((M + 255) / 256, 4096);
+    returns_normalise_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(d_adv, d_moments, (int)M, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------ C ABI

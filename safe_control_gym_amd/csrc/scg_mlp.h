@@ -183,7 +183,9 @@ __device__ __forceinline__ float mlp_dact<MLP_ACT_NONE>(float) { return 1.0f; }
 // Forward pass of one 32-sample column tile.  x[q] (q < L1Q): input feature row(q, h) of this lane's sample.
 // Leaves h1, h2 (activations, D layout: [tile][q]) and out[NOUT] (identical in both lane halves).  ACT2: activation of
 // the second hidden layer when it differs from the first's.
-template <int NIN, int H, int NOUT, int ACT, int SS = 20, int ACT2 = ACT>
+// PF: the weight operand of layer-2 block (rho, tau) is read one block AHEAD, in front of the previous block's products (16 more
+// registers) — for callers that run one wave per SIMD, where every 16-MFMA chain otherwise begins with an exposed LDS round trip.
+template <int NIN, int H, int NOUT, int ACT, int SS = 20, int ACT2 = ACT, bool PF = false>
 __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* x, f32x16* h1, f32x16* h2, float* out, int lane,
                                                  unsigned long long* ts = nullptr) {
     using L = MlpLds<NIN, H, NOUT, SS>;
@@ -207,6 +209,8 @@ __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* 
     }
     if (ts) ts[0] = __builtin_readcyclecounter();
     // ---- layer 2
+    float a_nx[16];
+    if constexpr (PF) load_w2_tile<L>(lds, 0, 0, lane, a_nx);
 #pragma unroll
     for (int rho = 0; rho < NT; ++rho) {
         f32x16 acc;
@@ -218,7 +222,14 @@ __device__ __forceinline__ void mlp_forward_tile(const float* lds, const float* 
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             float a[16];
-            load_w2_tile<L>(lds, rho, tau, lane, a);
+            if constexpr (PF) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = a_nx[q];
+                if (tau + 1 < NT) load_w2_tile<L>(lds, rho, tau + 1, lane, a_nx);
+                else if (rho + 1 < NT) load_w2_tile<L>(lds, rho + 1, 0, lane, a_nx);
+            } else {
+                load_w2_tile<L>(lds, rho, tau, lane, a);
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc = mfma32(a[q], h1[tau][q], acc);
             __builtin_amdgcn_sched_barrier(0);                  // keep the scheduler from hoisting every tile's operand loads

@@ -660,12 +660,19 @@ class PPO:
             self._episode_acc = torch.zeros(N, 8, **f)
             self._v_all = torch.zeros(T + 1, N, **f)
             self._tv = torch.zeros(T, N, **f)
+            # the collector's post-processing as library launches (scg_learn.h: scg_ppo_returns_*): persistent outputs
+            from safe_control_gym_amd import _learn
+            D = _learn.lib(self.obs_dim, cfg.hidden_dim, self.act_dim, cfg.activation)
+            self._trunc = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+            self._mask = torch.zeros(T, N, **f)
+            self._rew_c = torch.zeros(T, N, **f)
+            self._adv_n = torch.zeros(T, N, **f)
+            self._moments = torch.zeros(3, **f)
+            self._ret_scratch = torch.zeros(int(D.scg_ppo_returns_scratch_bytes()) // 4, **f)
         self.obs[0].copy_(self.obs_normalizer(env.reset_tensors()))
-        # finished-episode statistics (VecRecordEpisodeStatistics), accumulated on device
-        self.ep_count = torch.zeros((), device=self.device)
-        self.ep_return_sum = torch.zeros((), device=self.device)
-        self.ep_length_sum = torch.zeros((), device=self.device)
-        self.ep_violation_sum = torch.zeros((), device=self.device)
+        # finished-episode statistics (VecRecordEpisodeStatistics), accumulated on device (four adjacent words: views of one vector)
+        self._ep_tot = torch.zeros(4, device=self.device)
+        self.ep_count, self.ep_return_sum, self.ep_length_sum, self.ep_violation_sum = (self._ep_tot[k] for k in range(4))
 
     # ---- rollout (ppo.py:266-284)
     def _collect_body(self):
@@ -737,29 +744,32 @@ class PPO:
 
     @torch.no_grad()
     def _collect_fused(self, count_steps=True):
-        """One launch for the T control steps (policy inside), two batched critic passes, scg_gae."""
+        """One launch for the T control steps (policy inside), two batched critic passes, scg_gae; the elementwise work between them
+        (time-limit flags, masks, advantage moments, episode totals) as three library launches (round 6: ~25 PyTorch kernels before)."""
+        import ctypes as C
+        from safe_control_gym_amd import _learn
         cfg, T, N = self.cfg, self.T, self.N
+        D = _learn.lib(self.obs_dim, cfg.hidden_dim, self.act_dim, cfg.activation)
+        p = lambda t: C.c_void_p(t.data_ptr())                          # noqa: E731
         self.env.rollout_policy(self._policy_struct(), T, self.obs, self.act, self.logp, self.rew, self.done, self.flags,
                                 terminal_obs=self.term_obs, episode_acc=self._episode_acc)
         self._critic_batch(self.obs.view((T + 1) * N, self.obs_dim), self._v_all.view(-1))
-        # time truncation is not termination (ppo.py:276-283): bootstrap with the critic's value of the terminal observation
-        # — evaluated only on the 32-row tiles that hold a truncated row
-        trunc_u8 = (self.flags & 1) & self.done
-        self._critic_batch(self.term_obs.view(T * N, self.obs_dim), self._tv.view(-1), row_mask=trunc_u8.view(-1))
-        self.v.copy_(self._v_all[:T])
-        mask = 1.0 - self.done.to(torch.float32)
-        terminal_v = torch.where(trunc_u8.bool(), self._tv, torch.zeros_like(self._tv))
-        rew = self.rew.clone()
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            # time truncation is not termination (ppo.py:276-283): trunc = done & (flags & 1); mask = 1 - done; working copies of rew, v
+            _learn.check(D, D.scg_ppo_returns_prepare(p(self.done), p(self.flags), p(self.rew), p(self._v_all), T, N, p(self._trunc), p(self._mask),
+                                                      p(self._rew_c), p(self.v), st))
+        # bootstrap with the critic's value of the terminal observation — evaluated only on the 32-row tiles that hold a truncated row,
+        # 0 on every row that is not truncated: the pass's output IS the terminal_v of ppo_utils.py:389
+        self._critic_batch(self.term_obs.view(T * N, self.obs_dim), self._tv.view(-1), row_mask=self._trunc.view(-1))
         if self._ret_adv is None:
-            self._ret_adv = (torch.empty_like(rew), torch.empty_like(rew))
-        ret, adv = self._gae(rew, self.v, mask, terminal_v, self._v_all[T], cfg.gamma, cfg.gae_lambda, cfg.use_gae, out=self._ret_adv)
-        moments = torch.stack([adv.sum(), (adv * adv).sum(), torch.full((), float(adv.numel()), device=adv.device)])
-        tot = self._episode_acc.sum(0)
-        self.ep_count += tot[0]; self.ep_return_sum += tot[1]; self.ep_length_sum += tot[2]; self.ep_violation_sum += tot[3]
-        self._episode_acc.zero_()
+            self._ret_adv = (torch.empty_like(self._rew_c), torch.empty_like(self._rew_c))
+        ret, adv = self._gae(self._rew_c, self.v, self._mask, self._tv, self._v_all[T], cfg.gamma, cfg.gae_lambda, cfg.use_gae, out=self._ret_adv)
+        with torch.cuda.device(self.device):
+            _learn.check(D, D.scg_ppo_returns_moments(p(adv), T, N, p(self._episode_acc), p(self._ret_scratch), p(self._moments), p(self._ep_tot), st))
         if count_steps:
             self.total_steps += T * N * parallel.world_size()
-        return ret, adv, moments
+        return ret, adv, self._moments
 
     def _build_rollout_graph(self):
         """One HIP graph for the whole iteration front end: T x (policy forward, sampling, value, log-prob, env step
@@ -783,6 +793,15 @@ class PPO:
         """Global advantage normalisation (ppo.py:300): population std, +1e-6; the moments are summed over the ranks."""
         with torch.no_grad():
             parallel.all_reduce_sum_(moments)
+            if self._fused_rollout and moments is self._moments:         # one library launch on the collector's own moments vector
+                import ctypes as C
+                from safe_control_gym_amd import _learn
+                D = _learn.lib(self.obs_dim, self.cfg.hidden_dim, self.act_dim, self.cfg.activation)
+                with torch.cuda.device(self.device):
+                    _learn.check(D, D.scg_ppo_returns_normalise(C.c_void_p(adv.data_ptr()), C.c_void_p(moments.data_ptr()), self.T, self.N,
+                                                                C.c_void_p(self._adv_n.data_ptr()),
+                                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+                return self._adv_n
             mean = moments[0] / moments[2]
             std = torch.sqrt(torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0))
             return (adv - mean) / (std + 1e-6)

@@ -56,14 +56,50 @@ def test_mfma_forward_equals_torch(shape):
         _learn.check(D, D.scg_mlp_forward(ag._flat['p'].data_ptr(), C.byref(lay), nout, x.data_ptr(), M, out.data_ptr(), None, st))
         ref = net(x)
         torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
-        # sparse evaluation: flagged rows get their value, tiles without a flagged row are zero
+        # sparse evaluation: flagged rows get their value, every other row is zero (tiles without a flagged row are skipped)
         mask = torch.zeros(M, dtype=torch.uint8, device='cuda')
         mask[[5, 40, 700, 999]] = 1
         out2 = torch.full((M, nout), float('nan'), device='cuda')
         _learn.check(D, D.scg_mlp_forward(ag._flat['p'].data_ptr(), C.byref(lay), nout, x.data_ptr(), M, out2.data_ptr(),
                                           mask.data_ptr(), st))
         torch.testing.assert_close(out2[mask.bool()], ref[mask.bool()], rtol=2e-5, atol=2e-5)
-        assert torch.isfinite(out2).all() and (out2[64:640] == 0).all()
+        assert torch.isfinite(out2).all() and (out2[~mask.bool()] == 0).all()       # every row that is not flagged returns 0
+
+
+def test_returns_post_processing_launches_equal_the_torch_ops():
+    """scg_ppo_returns_prepare / _moments / _normalise (the collector's work between rollout and update, ppo.py:276-300) against the
+    PyTorch expressions they replace: flags and copies exactly, sums to float32 accumulation-order noise, the episode accumulators added to
+    the running totals and zeroed."""
+    from safe_control_gym_amd import _learn
+    D = _learn.lib(12, 128, 2, 'tanh')
+    T, N = 7, 1000
+    g = torch.Generator(device='cuda').manual_seed(3)
+    done = (torch.rand(T, N, device='cuda', generator=g) < 0.2).to(torch.uint8)
+    flags = torch.randint(0, 8, (T, N), device='cuda', generator=g, dtype=torch.uint8)
+    rew, v_all = torch.randn(T, N, device='cuda', generator=g), torch.randn(T + 1, N, device='cuda', generator=g)
+    trunc, mask = torch.empty(T, N, dtype=torch.uint8, device='cuda'), torch.empty(T, N, device='cuda')
+    rew_c, v = torch.empty(T, N, device='cuda'), torch.empty(T, N, device='cuda')
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())                              # noqa: E731
+    _learn.check(D, D.scg_ppo_returns_prepare(p(done), p(flags), p(rew), p(v_all), T, N, p(trunc), p(mask), p(rew_c), p(v), st))
+    assert torch.equal(trunc, (flags & 1) & done) and torch.equal(mask, 1.0 - done.float()) and torch.equal(rew_c, rew) and torch.equal(v, v_all[:T])
+    adv = torch.randn(T, N, device='cuda', generator=g) * 3 + 0.5
+    acc = torch.rand(N, 8, device='cuda', generator=g)
+    acc0, totals = acc.clone(), torch.tensor([1.0, 2.0, 3.0, 4.0], device='cuda')
+    scratch = torch.zeros(int(D.scg_ppo_returns_scratch_bytes()) // 4, device='cuda')
+    mom, out = torch.zeros(3, device='cuda'), torch.empty(T, N, device='cuda')
+    _learn.check(D, D.scg_ppo_returns_moments(p(adv), T, N, p(acc), p(scratch), p(mom), p(totals), st))
+    _learn.check(D, D.scg_ppo_returns_normalise(p(adv), p(mom), T, N, p(out), st))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(mom, torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(T * N), device='cuda')]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(totals, torch.tensor([1.0, 2.0, 3.0, 4.0], device='cuda') + acc0.sum(0)[:4], rtol=1e-5, atol=1e-4)
+    assert (acc == 0).all()
+    torch.testing.assert_close(out, (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-6), rtol=1e-4, atol=1e-5)
+    # without episode accumulators: the totals are left alone; in place
+    _learn.check(D, D.scg_ppo_returns_moments(p(adv), T, N, None, p(scratch), p(mom), p(totals), st))
+    _learn.check(D, D.scg_ppo_returns_normalise(p(adv), p(mom), T, N, p(adv), st))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(adv, out, rtol=0, atol=0)
 
 
 @pytest.mark.parametrize('clipped_value', [False, True])
