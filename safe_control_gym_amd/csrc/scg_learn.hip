@@ -971,15 +971,22 @@ __global__ __launch_bounds__(256) void returns_moments_kernel(const float* __res
         for (int k = 0; k < 6; ++k) partials[blockIdx.x * 8 + k] = out[k];
     }
 }
-__global__ __launch_bounds__(64) void returns_finish_kernel(const float* __restrict__ partials, int n_blocks, float count, float* __restrict__ moments,
-                                                             float* __restrict__ ep_totals) {
-    const int k = threadIdx.x;
-    if (k >= 6) return;
-    float s = 0.0f;
-    for (int b = 0; b < n_blocks; ++b) s += partials[b * 8 + k];
-    if (k < 2) moments[k] = s;
-    else if (ep_totals) ep_totals[k - 2] += s;
-    if (k == 0) moments[2] = count;
+__global__ __launch_bounds__(256) void returns_finish_kernel(const float* __restrict__ partials, int n_blocks, float count, float* __restrict__ moments,
+                                                              float* __restrict__ ep_totals) {
+    // thread b holds block b's six partial sums; six fixed-order block sums (one thread walking the 256 partials of a column was 256
+    // dependent loads: 32 us)
+    __shared__ float red[4];
+    const int b = threadIdx.x;
+    float v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = b < n_blocks ? partials[b * 8 + k] : 0.0f;
+    float s[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = block_sum256(v[k], red);
+    if (b == 0) {
+        moments[0] = s[0]; moments[1] = s[1]; moments[2] = count;
+        if (ep_totals) { ep_totals[0] += s[2]; ep_totals[1] += s[3]; ep_totals[2] += s[4]; ep_totals[3] += s[5]; }
+    }
 }
 __global__ __launch_bounds__(256) void returns_normalise_kernel(const float* __restrict__ adv, const float* __restrict__ moments, int M,
                                                                  float* __restrict__ out) {
@@ -1008,7 +1015,8 @@ extern "C" int scg_ppo_returns_moments(const float* d_adv, int T, int N, float* 
     if (M > 0x7fffffffLL) return fail(-1, "scg_ppo_returns_moments: T x N too large");
     const int grid = (int)std::min<long long>((M + 255) / 256, RET_BLOCKS);
     returns_moments_kernel<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(d_adv, (int)M, d_episode_acc, N, d_scratch);
-    returns_finish_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(d_scratch, grid, (float)M, d_moments, d_episode_acc ? d_episode_totals : nullptr);
+    static_assert(RET_BLOCKS <= 256, "one partial row per thread of the finishing block");
+    returns_finish_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream>>>(d_scratch, grid, (float)M, d_moments, d_episode_acc ? d_episode_totals : nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
