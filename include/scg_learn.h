@@ -94,6 +94,11 @@ int scg_adam_gated_scaled(float* d_p, const float* d_g, float* d_m, float* d_v, 
 int scg_ppo_step(const scg_ppo_grad_args* args, float* d_m, float* d_v, float lr_actor, float lr_critic, const float* d_steps_in,
                  float* d_steps_out, float target_kl, float* d_stats_acc, void* stream);
 
+/* The gradient kernel has two forms: when no wave of the launch has more than one 32-row tile (batch / 32 <= 4 n_workgroups — the shipped
+ * minibatch sizes) the dW2 tile products are formed inside the cross-wave sum, otherwise they are accumulated over the wave's tiles first.
+ * The results are bit-identical; this hook forces the accumulating form at any size (A/B runs, tests/test_gpu_learn.py). */
+void scg_learn_force_accumulating_form(int on);
+
 /* The collector's post-processing between rollout and update (PPO.train_step, controllers/ppo/ppo.py:276-300) over the [T][N] rollout,
  * four launches in place of ~30 elementwise / reduction kernels:
  *   scg_ppo_returns_prepare    d_trunc = done & (flags & 1) (time truncation is not termination), d_mask = 1 - done, d_rew_out = rew

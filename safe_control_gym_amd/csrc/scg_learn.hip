@@ -685,6 +685,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ppo_grad_kernel(const GradArgs 
     if (blockIdx.y == 0) grad_net<NU, true, ONE>(A, lds);
     else grad_net<1, false, ONE>(A, lds);
 }
+// A/B and test hook: the accumulating form at any size (initially: $SCG_LEARN_MULTI_TILE set).  The two forms are bit-identical.
+static int g_force_accumulating = getenv("SCG_LEARN_MULTI_TILE") != nullptr;
+extern "C" void scg_learn_force_accumulating_form(int on) { g_force_accumulating = on != 0; }
 // enqueue the gradient kernel: the one-tile form when no wave has more than one tile
 static int launch_grad(const GradArgs& G, int n_workgroups, hipStream_t st) {
     const size_t bytes = grad_lds_words() * sizeof(float);
@@ -695,8 +698,7 @@ static int launch_grad(const GradArgs& G, int n_workgroups, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void*)ppo_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         set_g.commit(dev);
     }
-    static const bool force_multi = getenv("SCG_LEARN_MULTI_TILE") != nullptr;          // (A/B: the accumulating form at any size)
-    if (G.batch / 32 <= n_workgroups * WAVES && !force_multi) ppo_grad_kernel<true><<<dim3(n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
+    if (G.batch / 32 <= n_workgroups * WAVES && !g_force_accumulating) ppo_grad_kernel<true><<<dim3(n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
     else ppo_grad_kernel<false><<<dim3(n_workgroups, 2), dim3(64 * WAVES), bytes, st>>>(G);
     HIP_TRY(hipGetLastError());
     return 0;

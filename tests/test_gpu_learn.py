@@ -66,6 +66,35 @@ def test_mfma_forward_equals_torch(shape):
         assert torch.isfinite(out2).all() and (out2[~mask.bool()] == 0).all()       # every row that is not flagged returns 0
 
 
+@pytest.mark.parametrize('shape', [(12, 128, 2, 'tanh'), (17, 96, 2, 'tanh'), (4, 64, 1, 'relu')])
+def test_one_tile_form_equals_the_accumulating_form_bit_for_bit(shape):
+    """scg_ppo_grad at one tile per wave: the dW2 tile products formed inside the cross-wave sum (ppo_grad_kernel<true>) against the form
+    that accumulates them over the wave's tiles first and sums afterwards (forced through scg_learn_force_accumulating_form) — the same
+    products added in the same order: gradients and statistics bit for bit, full and partial last workgroups."""
+    from safe_control_gym_amd import _learn
+    obs_dim, hidden, act_dim, act = shape
+    ag = _agent(obs_dim, hidden, act_dim, act)
+    D = _learn.lib(obs_dim, hidden, act_dim, act)
+    D.scg_learn_force_accumulating_form.argtypes = [C.c_int]
+    data = _data(obs_dim, act_dim, 40000, ag)
+    try:
+        for mb in (16256, 2048, 96):
+            F = ag._build_fused(data, mb)
+            assert mb // 32 <= F['args'].n_workgroups * 4                  # one tile per wave at most
+            F['idx'].copy_(torch.randperm(40000, device='cuda')[:mb].to(torch.int32))
+            outs = []
+            for on in (0, 1):
+                D.scg_learn_force_accumulating_form(on)
+                ag._flat['g'].zero_()
+                ag._fused_grad(F)
+                torch.cuda.synchronize()
+                outs.append((ag._flat['g'].clone(), F['stats'].clone()))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), mb
+            assert float(outs[0][0].abs().sum()) > 0
+    finally:
+        D.scg_learn_force_accumulating_form(0)
+
+
 def test_returns_post_processing_launches_equal_the_torch_ops():
     """scg_ppo_returns_prepare / _moments / _normalise (the collector's work between rollout and update, ppo.py:276-300) against the
     PyTorch expressions they replace: flags and copies exactly, sums to float32 accumulation-order noise, the episode accumulators added to

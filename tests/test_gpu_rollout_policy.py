@@ -32,9 +32,12 @@ def _setup(task, n, hidden, act, seed=5, override=None):
                                                       ('quadrotor_3D_track', 128, 'relu', None),
                                                       ('quadrotor_2D_track', 96, 'tanh', None),       # three feature tiles per hidden layer
                                                       ('quadrotor_2D_track', 64, 'tanh', STAB6)])     # rows of 24 bytes: no LDS transpose
-@pytest.mark.parametrize('epw', ['64', '32'])         # envs per wave: lane = env / lane pair = env (shards <= 32 768 envs by default)
-def test_fused_rollout_equals_step_by_step(task, hidden, act, override, epw, monkeypatch):
+# launch geometry: envs per wave (lane = env / lane pair = env) x waves per workgroup behind one weight image (8 = two waves per SIMD: what shards
+# above 32 768 envs get by default — forced here on a small batch)
+@pytest.mark.parametrize('epw,wpw', [('64', '4'), ('32', '4'), ('32', '8'), ('64', '8')])
+def test_fused_rollout_equals_step_by_step(task, hidden, act, override, epw, wpw, monkeypatch):
     monkeypatch.setenv('SCG_ROLLOUT_EPW', epw)
+    monkeypatch.setenv('SCG_ROLLOUT_WPW', wpw)
     n, K = 320, 12                                 # 5 / 10 waves: a partial workgroup as well
     env, ref, ppo = _setup(task, n, hidden, act, override=override)
     assert env.spec.obs_dim == (6 if override else env.spec.obs_dim)
@@ -86,11 +89,12 @@ def test_fused_rollout_equals_step_by_step(task, hidden, act, override, epw, mon
 
 
 def test_rollout_does_not_depend_on_the_launch_geometry(monkeypatch):
-    """Stochastic rollouts with 64 and with 32 envs per wave are the same rollouts: the noise is a per-env Philox stream, the
-    actor's arithmetic per env is the same MFMA sequence."""
+    """Stochastic rollouts with 64 and with 32 envs per wave, 4 and 8 waves per workgroup are the same rollouts: the noise is a per-env
+    Philox stream, the actor's arithmetic per env is the same MFMA sequence."""
     outs = []
-    for epw in ('64', '32'):
+    for epw, wpw in (('64', '4'), ('32', '4'), ('32', '8'), ('64', '8')):
         monkeypatch.setenv('SCG_ROLLOUT_EPW', epw)
+        monkeypatch.setenv('SCG_ROLLOUT_WPW', wpw)
         env, ref, ppo = _setup('quadrotor_2D_track', 1000, 128, 'tanh')
         n, K, nobs, nu = 1000, 40, 12, 2
         f = dict(device=env.device, dtype=torch.float32)
@@ -101,8 +105,9 @@ def test_rollout_does_not_depend_on_the_launch_geometry(monkeypatch):
         torch.cuda.synchronize()
         outs.append((obs.clone(), actb.clone(), logp.clone(), rew.clone(), done.clone(), env.get_raw_state() if hasattr(env, 'get_raw_state') else None))
         env.close(); ref.close()
-    for a, b in zip(outs[0][:5], outs[1][:5]):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:5], other[:5]):
+            assert torch.equal(a, b)
     assert int(outs[0][4].sum()) > 0                # episodes ended and were reset inside the launch
 
 
