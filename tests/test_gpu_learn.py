@@ -131,14 +131,18 @@ def test_returns_post_processing_launches_equal_the_torch_ops():
     torch.testing.assert_close(adv, out, rtol=0, atol=0)
 
 
+def test_fused_minibatch_gradients_equal_autograd_with_several_tiles_per_wave():
+    """The accumulating form of the gradient kernel (more than one 32-row tile per wave: minibatches above 127 x 128 rows) against autograd."""
+    test_fused_minibatch_gradients_equal_autograd((12, 128, 2, 'tanh'), True, M=40000, mb=32768)
+
+
 @pytest.mark.parametrize('clipped_value', [False, True])
 @pytest.mark.parametrize('shape', SHAPES)
-def test_fused_minibatch_gradients_equal_autograd(shape, clipped_value):
+def test_fused_minibatch_gradients_equal_autograd(shape, clipped_value, M=8192, mb=4096):
     from safe_control_gym_amd.ppo import policy_loss_terms, value_loss_term
     obs_dim, hidden, act_dim, act = shape
     ag = _agent(obs_dim, hidden, act_dim, act)
     ag.cfg.use_clipped_value = clipped_value
-    M, mb = 8192, 4096
     data = _data(obs_dim, act_dim, M, ag)
     F = ag._build_fused(data, mb)
     idx = torch.randperm(M, device='cuda')[:mb]

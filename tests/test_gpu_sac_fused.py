@@ -94,9 +94,10 @@ def test_fused_update_equals_the_eager_update_at_the_production_shape(tuning):
 
 
 # shapes no shipped task has: three feature tiles (hidden 96), input widths that are not multiples of 4 / 8, obs + act = 31 (the
-# widest Q input the library serves), one-float observations, three actions; batches of 1 to 20 tiles
+# widest Q input the library serves), one-float observations, three actions; batches of 1 to 20 tiles, and one above the 512-workgroup cap
 @pytest.mark.parametrize('obs_dim,act_dim,hidden,act,B', [(7, 1, 96, 'relu', 256), (17, 2, 96, 'tanh', 640), (27, 4, 64, 'leaky_relu', 32),
-                                                         (1, 1, 32, 'tanh', 96), (29, 2, 128, 'relu', 512), (3, 3, 32, 'relu', 224)])
+                                                         (1, 1, 32, 'tanh', 96), (29, 2, 128, 'relu', 512), (3, 3, 32, 'relu', 224),
+                                                         (12, 2, 64, 'relu', 20480)])       # 640 tiles on 512 workgroups: the multi-tile loops
 def test_fused_update_equals_the_eager_update_on_other_shapes(obs_dim, act_dim, hidden, act, B):
     _fused_vs_eager(obs_dim, act_dim, hidden, act, bool(obs_dim % 2), B)
 
@@ -193,7 +194,7 @@ def test_fused_update_samples_in_the_kernel_is_reproducible_and_learns():
     torch.testing.assert_close(out, a, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('nobs,nu,hidden,act,B', [(24, 4, 128, 'relu', 4096), (17, 2, 96, 'tanh', 640), (6, 2, 32, 'relu', 64)])
+@pytest.mark.parametrize('nobs,nu,hidden,act,B', [(24, 4, 128, 'relu', 4096), (17, 2, 96, 'tanh', 640), (6, 2, 32, 'relu', 64), (12, 2, 64, 'relu', 20480)])
 def test_update_n_is_bit_identical_to_single_step_calls(nobs, nu, hidden, act, B):
     """scg_sac_update_n (what SACAgent.update_from_buffer captures: step k + 1's first launch — rows drawn, a, log pi at obs, the tiles
     actor_grad_kernel reads back — rides in step k's target-action launch, 7 n + 1 launches) against n scg_sac_update calls (8 launches
