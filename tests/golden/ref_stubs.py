@@ -40,8 +40,8 @@ if sys.pycache_prefix is None:
 
 def reference_root():
     """Where the reference checkout is on THIS machine: $SCG_REFERENCE_ROOT, the build container's /root/reference, or the
-    untracked scratch copy tools/stage_reference.py makes under oracle/_ref/reference (travels to the gpurun box, never in
-    git).  None when there is none."""
+    untracked scratch copy tools/stage_reference.py makes under oracle/_ref/reference (local checker runs only: never in git,
+    never on the gpurun box — .gpurunignore).  None when there is none."""
     here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     for cand in (os.environ.get('SCG_REFERENCE_ROOT'), '/root/reference', os.path.join(here, 'oracle', '_ref', 'reference')):
         if cand and os.path.isdir(os.path.join(cand, 'safe_control_gym')):

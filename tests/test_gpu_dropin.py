@@ -134,9 +134,9 @@ def test_grouped_envs_never_share_a_random_stream():
 @pytest.mark.gpu
 @pytest.mark.parametrize('algo', ['ppo', 'sac'])
 def test_reference_controllers_run_on_hipvecenv(algo):
-    """The reference's own PPO / SAC classes through the binding (tools/run_reference_ppo_on_hip.py).  The reference's Python
-    reaches the GPU box as untracked scratch (tools/stage_reference.py -> oracle/_ref/reference, staged by build()); the test
-    only skips on a machine that has neither that copy nor a checkout."""
+    """The reference's own PPO / SAC classes through the binding (tools/run_reference_ppo_on_hip.py).  Needs the reference checkout
+    on the machine that has the GPU: the reference's Python does not travel to the gpurun box (.gpurunignore), so there the test
+    skips; rounds 3-5 ran it on the box from a staged scratch copy (profiles/r03_reference_controllers_on_hip.txt keeps the log)."""
     from tests.golden.ref_stubs import reference_root
     ref = reference_root()
     if ref is None:

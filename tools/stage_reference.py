@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Stage the reference's Python package as UNTRACKED scratch so that it travels to the gpurun box.
+"""Stage the reference's Python package as UNTRACKED scratch for LOCAL checker runs (rounds 3-5 let it travel to the gpurun box; since
+round 6 it does not: `.gpurunignore` lists oracle/_ref/reference/ — the reference's Python stays in this container).
 
     python tools/stage_reference.py [--reference /root/reference] [--dest oracle/_ref/reference]
 
-`oracle/_ref/` is git-ignored (never in history) but not gpurun-ignored, like the built oracle library: the snapshot carries
-it.  Only the checker side reads it — tests/test_gpu_dropin.py (the reference's own PPO / SAC classes on HipVecEnv),
+`oracle/_ref/` is git-ignored (never in history); the built oracle library in it travels with the snapshot, this copy does not.
+Only the checker side reads it — tests/test_gpu_dropin.py (the reference's own PPO / SAC classes on HipVecEnv),
 tools/run_reference_ppo_on_hip.py, tests/golden/pybullet_probe.py — through tests/golden/ref_stubs.py::reference_root()
 ($SCG_REFERENCE_ROOT, /root/reference, oracle/_ref/reference in that order).  Nothing under safe_control_gym_amd/ or in
 bench.py's timed region imports it (tests/test_capi_cpu.py::test_product_never_imports_the_oracle).
