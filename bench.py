@@ -713,8 +713,13 @@ def ppo_leg(torch, dist, world, rank, seeds, budget_s, envs=65536, minibatch=Non
     iteration_ms = {'wall_per_iteration': wall_ms, 'device_steady_state': dev_ms, 'kernel_sum': ks_ms,
                     'gap': (wall_ms - ks_ms) if (wall_ms and ks_ms) else None, 'wall_over_kernel_sum': (wall_ms / ks_ms) if (wall_ms and ks_ms) else None,
                     'kernel_sum_source': ks_src, 'host_path': paths[0] if paths else None,
+                    # the same iterations as a plain loop (no evaluation beside them, capture outside the clock): what the host path itself costs
+                    'plain_loop_wall': ks.get('wall_ms_per_iteration') if ks else None,
+                    'plain_loop_wall_over_kernel_sum': ks.get('wall_over_kernel_sum') if ks else None,
                     'what': 'wall = (clock start .. queue drained) / iterations, median over seeds (includes the capture iteration and the evaluator '
-                            'beside it); device_steady_state = median distance between consecutive iterations\' end events; kernel_sum = rocprofv3'}
+                            'beside it: +0.13 ms device / +0.33 ms wall per iteration, profiles/r06_eval_interference.txt); device_steady_state = median '
+                            'distance between consecutive iterations\' end events; kernel_sum = rocprofv3; plain_loop_wall = tools/learner_profile.py, '
+                            'the same replays without the asynchronous evaluation (same profile file)'}
     learner_roofline = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': F32_MFMA_PEAK_TFLOPS, 'flops_per_iteration': flops_it,
                         'kernel_sum_ms': ks_ms, 'wall_ms': wall_ms, 'achieved': (flops_it / (wall_ms * 1e-3) / 1e12) if wall_ms else None,
                         'frac_of_f32_mfma_peak': frac(wall_ms), 'frac_on_kernel_time': frac(ks_ms),
@@ -1165,7 +1170,9 @@ def main():
         rf['learners'] = {'peak_TFLOPs_f32_mfma': F32_MFMA_PEAK_TFLOPS,
                           'ppo_flops_per_iteration': pr.get('flops_per_iteration'), 'ppo_wall_ms_per_iteration': pi.get('wall_per_iteration'),
                           'ppo_device_ms_per_iteration': pi.get('device_steady_state'), 'ppo_kernel_sum_ms_per_iteration': pi.get('kernel_sum'),
-                          'ppo_wall_over_kernel_sum': pi.get('wall_over_kernel_sum'), 'ppo_frac_of_peak_on_wall': pr.get('frac_of_f32_mfma_peak'),
+                          'ppo_wall_over_kernel_sum': pi.get('wall_over_kernel_sum'), 'ppo_plain_loop_wall_ms_per_iteration': pi.get('plain_loop_wall'),
+                          'ppo_plain_loop_wall_over_kernel_sum': pi.get('plain_loop_wall_over_kernel_sum'),
+                          'ppo_frac_of_peak_on_wall': pr.get('frac_of_f32_mfma_peak'),
                           'ppo_frac_of_peak_on_kernel_time': pr.get('frac_on_kernel_time'),
                           'ppo_median_s_partial_epochs': (out.get('ppo') or {}).get('median_s_partial_epochs'),
                           'ppo_median_s_full_epochs': (out.get('ppo') or {}).get('median_s'),

@@ -989,10 +989,12 @@ class PPO:
 
 
 @torch.no_grad()
-def _evaluate_fused_device(env, policy, episodes_per_env=1):
+def _evaluate_fused_device(env, policy, episodes_per_env=1, chunk=None):
     """ONE launch on the current stream: deterministic actor inside the env kernel (scg_rollout_policy), per-env episode
     totals accumulated in the kernel.  Returns (device tensor [episodes, mean return, length, violations, mse], per-env
-    accumulator [N, 8]) without touching the host."""
+    accumulator [N, 8]) without touching the host.
+    chunk (control steps per launch; None = all in one): the same rollout as a sequence of shorter launches — identical results (the
+    simulator state lives in the env handle, the episode accumulators in `acc`, the noise is keyed by (env, episode, step))."""
     N, dev = env.num_envs, env.device
     steps = env.spec.max_episode_steps * episodes_per_env
     buf = getattr(env, '_eval_fused', None)
@@ -1006,8 +1008,11 @@ def _evaluate_fused_device(env, policy, episodes_per_env=1):
         env._eval_fused = buf
     env.reset_tensors()
     buf['acc'].zero_()
-    env.rollout_policy(policy, steps, buf['obs'], buf['act'], buf['logp'], buf['rew'], buf['done'], buf['flags'],
-                       episode_acc=buf['acc'], max_episodes=episodes_per_env)
+    chunk = steps if not chunk else max(1, min(int(chunk), steps))
+    for t0 in range(0, steps, chunk):
+        k = min(chunk, steps - t0)
+        env.rollout_policy(policy, k, buf['obs'][t0:t0 + k + 1], buf['act'][t0:t0 + k], buf['logp'][t0:t0 + k], buf['rew'][t0:t0 + k],
+                           buf['done'][t0:t0 + k], buf['flags'][t0:t0 + k], episode_acc=buf['acc'], max_episodes=episodes_per_env)
     a = buf['acc']
     n = a[:, 0].sum().clamp(min=1.0)
     return torch.stack([a[:, 0].sum(), a[:, 1].sum() / n, a[:, 2].sum() / n, a[:, 3].sum() / n, a[:, 4].sum() / n]), a
@@ -1040,6 +1045,11 @@ class AsyncEvaluator:
         self.policy.d_params = self.params.data_ptr()
         self.host = torch.zeros(5, dtype=torch.float32).pin_memory()
         self.event, self.tag = None, None
+        # Control steps per evaluation launch (None = the whole evaluation in one).  What the evaluation costs the training stream was
+        # measured in round 6 (profiles/r06_eval_interference.txt): +0.13 ms of device time and +0.33 ms of wall clock per 4.2 ms iteration,
+        # the SAME as one launch, as 25- or 5-step launches, as one captured graph per evaluation, and enqueued behind train_step or behind
+        # the collector's launch — i.e. neither a collector workgroup waiting for "its" CU nor host time in launch(); not removed.
+        self.chunk = ppo.cfg.extra.get('eval_chunk_steps')
 
     def launch(self, tag=None):
         """Snapshot the current weights and start evaluating them; False if the previous evaluation is still running."""
@@ -1049,7 +1059,7 @@ class AsyncEvaluator:
         self.params.copy_(self.ppo.agent._flat['p'])
         self.stream.wait_stream(main)
         with torch.cuda.stream(self.stream):
-            res, _ = _evaluate_fused_device(self.env, self.policy, 1)
+            res, _ = _evaluate_fused_device(self.env, self.policy, 1, chunk=self.chunk)
             self.host.copy_(res, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(self.stream)

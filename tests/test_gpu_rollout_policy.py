@@ -130,5 +130,12 @@ def test_ppo_iteration_and_evaluation_on_the_fused_rollout():
     assert a['episodes'] == b['episodes'] == 128
     for k in ('ep_return', 'ep_length', 'ep_constraint_violation', 'ep_mse'):
         assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    # the evaluation as a sequence of short launches (what AsyncEvaluator enqueues beside the training stream) == the one launch, bit for bit
+    from safe_control_gym_amd.ppo import _evaluate_fused_device
+    r1, a1 = _evaluate_fused_device(e1, ppo._policy_struct(True), 1)
+    r1, a1 = r1.clone(), a1.clone()
+    for chunk in (25, 64, 250, 1000):
+        r2, a2 = _evaluate_fused_device(e1, ppo._policy_struct(True), 1, chunk=chunk)
+        assert torch.equal(r1, r2) and torch.equal(a1, a2), chunk
     for e in (env, ref, e1, e2):
         e.close()

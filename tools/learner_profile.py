@@ -33,13 +33,27 @@ def run_ppo(args, torch):
                      opt_epochs=args.epochs, mini_batch_size=args.minibatch, actor_lr=2e-3, critic_lr=2e-3, rollout_batch_size=args.envs,
                      rollout_steps=32, extra=extra)
     ppo = PPO(env, pcfg, seed=1)
+    aev = None
+    if args.eval_chunk is not None:                     # bench.py's asynchronous evaluation beside the loop (--eval-chunk 0 = one launch)
+        from safe_control_gym_amd.ppo import AsyncEvaluator
+        ev_cfg = bench.eval_task_config(cfg, bench.EVAL_INIT_RAND_Q2)
+        eval_env = HipVecEnv(env_id, bench.EVAL_ENVS, seed=111, return_numpy=False, policy=(128, 'tanh'), **ev_cfg)
+        aev = AsyncEvaluator(ppo, eval_env)
+        aev.chunk = args.eval_chunk or None
     for _ in range(3):                                  # eager, captured (+ replayed), replayed
         ppo.train_step(lazy=True)
+        if aev:
+            aev.launch()
     torch.cuda.synchronize()
+    if aev:
+        aev.poll(wait=True)
     pending, ends = [], []
     t0 = time.perf_counter()
     for _ in range(args.iters):
         res = ppo.train_step(lazy=True)
+        if aev:
+            aev.launch()
+            aev.poll()
         ends.append(res['events'])
         pending.append(res['events'][2])
         while len(pending) > 2:
@@ -102,6 +116,7 @@ def main():
     ap.add_argument('--epochs', type=int, default=3)
     ap.add_argument('--minibatch', type=int, default=16256)
     ap.add_argument('--mb-per-epoch', type=int, default=16)
+    ap.add_argument('--eval-chunk', type=int, default=None, help='run bench.py\'s asynchronous evaluation beside the loop, this many control steps per launch (0 = one launch)')
     ap.add_argument('--no-graph', action='store_true', help='per-launch enqueue instead of the iteration graph (same launches)')
     args = ap.parse_args()
     import torch
