@@ -95,8 +95,9 @@ int scg_ppo_step(const scg_ppo_grad_args* args, float* d_m, float* d_v, float lr
                  float* d_steps_out, float target_kl, float* d_stats_acc, void* stream);
 
 /* The gradient kernel has two forms: when no wave of the launch has more than one 32-row tile (batch / 32 <= 4 n_workgroups — the shipped
- * minibatch sizes) the dW2 tile products are formed inside the cross-wave sum, otherwise they are accumulated over the wave's tiles first.
- * The results are bit-identical; this hook forces the accumulating form at any size (A/B runs, tests/test_gpu_learn.py). */
+ * minibatch sizes) the waves exchange their transposed tiles and each forms one tile row of dW2 over all the workgroup's samples, otherwise
+ * every wave accumulates its own products over its tiles and the waves are summed afterwards.  Same results up to the summation order inside
+ * dW2 (everything else bit for bit); this hook forces the accumulating form at any size (A/B runs, tests/test_gpu_learn.py). */
 void scg_learn_force_accumulating_form(int on);
 
 /* The collector's post-processing between rollout and update (PPO.train_step, controllers/ppo/ppo.py:276-300) over the [T][N] rollout,

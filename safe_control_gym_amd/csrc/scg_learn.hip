@@ -161,6 +161,16 @@ constexpr size_t grad_lds_base_words() {
 // accumulation is then a plain read-add-write by the owning wave, the copies are summed in wave order at the end, and the
 // kernel's result is bitwise reproducible — used when they fit next to the weight image, LDS atomics otherwise.
 constexpr bool private_dw1() { return (grad_lds_base_words() + (WAVES - 1) * W1R) * sizeof(float) <= 160 * 1024; }
+// The one-tile form's operand exchange (end of grad_net): every wave publishes 2 NT tiles of 1024 words; they go over the dead weight image
+// (whole tiles) and, behind the small-gradient block, over the dead per-wave scratch — which is made large enough for the rest here.
+constexpr int PUB_TILE = 1024;
+constexpr size_t scratch_words() { return WAVES * XS_WORDS + WAVES * 4 * 32 + WAVES * TR_WORDS + (private_dw1() ? (WAVES - 1) * W1R : 0); }
+template <int NOUT>
+constexpr size_t region_b_words() {
+    constexpr size_t in_image = MlpLds<NIN, HID, NOUT>::END / PUB_TILE, need = 2 * WAVES * (HID / 32);
+    constexpr size_t rest = need > in_image ? (need - in_image) * PUB_TILE : 0;
+    return rest > scratch_words() ? rest : scratch_words();
+}
 static_assert(NIN < 32, "the dW1 product appends a column of ones: NIN + 1 <= 32");
 
 struct GradArgs {
@@ -193,9 +203,10 @@ __device__ __forceinline__ void gl_add(float* p, float v) {
 // workgroups per network).  The dW2 "accumulators" then accumulate nothing: each of the NT^2 tile products is a single 16-MFMA chain, and
 // holding all of them in 256 AccVGPRs until the cross-wave sum (a) left everything else of the tile 256 registers — 35 spilled words per
 // lane, each reload a scratch round trip behind an s_waitcnt vmcnt(0) — and (b) made that sum a separate 5.6 us pass over 64 KB of LDS.
-// With ONE the products are formed INSIDE the cross-wave sum, behind the barrier that frees the weight image: in round r wave w forms
-// the tile row tau = (w + r) mod 4 (4 x 16 MFMAs) and adds it to the row's running sum in the staging area — the same products added in
-// the same order as before (bit-identical), the LDS traffic of one row under the matrix products of the next.
+// With ONE the products are formed behind the barrier that frees the weight image, by OPERAND exchange: every wave publishes its tile's
+// transposed h1 / dz2 tiles in the LDS, and wave w forms tile row tau = w of dW2 over all the workgroup's samples in its MFMA accumulators
+// (publishers in a fixed order) and stores it straight to the partial vector.  (First cut of the round: running sums through a staging
+// area in four rounds — the accumulating form's own sum with the products moved into it, bit-identical to it: 11.2 us for 6.8 of MFMA.)
 template <int NOUT, bool ACTOR, bool ONE>
 __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     using L = MlpLds<NIN, HID, NOUT>;
@@ -610,37 +621,87 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     const uint32_t pbase = (uint32_t)(((size_t)blockIdx.x * 2 + (ACTOR ? 0 : 1)) * PARTIAL_STRIDE * sizeof(float));
     typedef unsigned int u32x4 __attribute__((vector_size(16)));
     if constexpr (ONE) {
+        // ONE: operand exchange instead of partial-sum exchange.  Every wave publishes its tile's transposed h1 / dz2 tiles (2 NT x 4 KB) in
+        // the LDS — the weight image and the per-wave scratch are dead by now — and wave w then forms tile row tau = w of dW2 over ALL the
+        // workgroup's samples: for each publisher t, A = h1^T_t[tau], B = dz2^T_t[rho], accumulated in the MFMA accumulators (publishers in
+        // the order 0..3: a fixed order) and stored straight to the partial vector.  One barrier where the running-sum form (rounds of
+        // read-add-write through a staging area) had three, and no LDS round trip per product on the accumulators' path: 11.2 -> ~8 us.
+        // (Not bit-identical to the accumulating form any more: the sum over a wave's tile partners happens inside the accumulator.)
+        constexpr int TW = 1024;                                        // words of a published tile: [g][lane][4]
+        constexpr int A_TILES = (int)(L::END / TW);                     // tiles that fit the dead weight image ...
+        float* const reg_b = xs_all;                                    // ... the rest goes over the dead per-wave scratch (xs, dout, scr, private copies)
+        static_assert(TW == PUB_TILE && (2 * WAVES * NT <= A_TILES || (size_t)(2 * WAVES * NT - A_TILES) * TW <= region_b_words<NOUT>()),
+                      "published tiles do not fit the LDS");
+        auto slot = [&](int wv, int kind, int t) -> float* {
+            const int sidx = (wv * 2 + kind) * NT + t;
+            return sidx < A_TILES ? lds + sidx * TW : reg_b + (sidx - A_TILES) * TW;
+        };
+        __syncthreads();                                                // the private small-gradient copies have been summed: the scratch is dead
 #pragma unroll
-        for (int r = 0; r < WAVES; ++r) {
-            const int tau = (wave + r) % WAVES;                         // wave-uniform
-            if (tau < NT) {
-                f32x16 a = h1[0];                                       // h1^T[tau]: picked by uniform branches (register arrays have no index)
+        for (int t = 0; t < NT; ++t) {
+            float* const pa = slot(wave, 0, t) + lane * 4;
+            float* const pb = slot(wave, 1, t) + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(pa + 256 * g) = (f32x4){h1[t][4 * g], h1[t][4 * g + 1], h1[t][4 * g + 2], h1[t][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(pb + 256 * g) = (f32x4){h2[t][4 * g], h2[t][4 * g + 1], h2[t][4 * g + 2], h2[t][4 * g + 3]};
+            }
+        }
+        __syncthreads();
+        if (wave < NT) {
+            const int tau = wave;
+            f32x16 d2[NT];
+#pragma unroll
+            for (int rho = 0; rho < NT; ++rho)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d2[rho][q] = 0.0f;
+            // (the operands of block (publisher, rho) are read one block AHEAD of their 16 products: 4 + 4 16-byte LDS reads under the
+            //  previous block's chain instead of in front of their own)
+            auto rd = [&](const float* base, float* o) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(base + 256 * g);
+                    o[4 * g] = v.x; o[4 * g + 1] = v.y; o[4 * g + 2] = v.z; o[4 * g + 3] = v.w;
+                }
+            };
+            auto a_of = [&](int pw) -> const float* {
+                const float* pa = slot(pw, 0, 0) + lane * 4;
 #pragma unroll
                 for (int t = 1; t < NT; ++t) {
-                    if (tau == t) a = h1[t];
+                    if (tau == t) pa = slot(pw, 0, t) + lane * 4;       // wave-uniform selection
                 }
+                return pa;
+            };
+            float a_nx[16], b_nx[16];
+            rd(a_of(0), a_nx);
+            rd(slot(0, 1, 0) + lane * 4, b_nx);
+#pragma unroll
+            for (int pw = 0; pw < WAVES; ++pw) {                        // publishers in a fixed order
+                float a[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = a_nx[q];
+                if (pw + 1 < WAVES) rd(a_of(pw + 1), a_nx);
 #pragma unroll
                 for (int rho = 0; rho < NT; ++rho) {
-                    f32x16 d2;
+                    float bq[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) d2[q] = 0.0f;
+                    for (int q = 0; q < 16; ++q) bq[q] = b_nx[q];
+                    if (rho + 1 < NT) rd(slot(pw, 1, rho + 1) + lane * 4, b_nx);
+                    else if (pw + 1 < WAVES) rd(slot(pw + 1, 1, 0) + lane * 4, b_nx);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) d2 = mfma32(a[q], h2[rho][q], d2);
-                    const int word = ((tau * NT + rho) * 4 * 64 + lane) * 4;          // [tile][g][lane][4]
-                    float* const p = stg + word;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {d2[4 * g], d2[4 * g + 1], d2[4 * g + 2], d2[4 * g + 3]};
-                        if (r > 0) v += *reinterpret_cast<const f32x4*>(p + 256 * g);
-                        // the LAST round completes the row: it leaves for the partial vector at once (same word order as the staging area)
-                        // instead of one more pass through the LDS, a barrier and the cooperative copy
-                        if (r == WAVES - 1)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), pr, pbase + 4u * (uint32_t)(G::END + word + 256 * g), 0, SCG_L_PART_AUX);
-                        else *reinterpret_cast<f32x4*>(p + 256 * g) = v;
-                    }
+                    for (int q = 0; q < 16; ++q) d2[rho] = mfma32(a[q], bq[q], d2[rho]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (r < WAVES - 1) __syncthreads();
+#pragma unroll
+            for (int rho = 0; rho < NT; ++rho) {
+                const int word = ((tau * NT + rho) * 4 * 64 + lane) * 4;              // [tile][g][lane][4]
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {d2[rho][4 * g], d2[rho][4 * g + 1], d2[rho][4 * g + 2], d2[rho][4 * g + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), pr, pbase + 4u * (uint32_t)(G::END + word + 256 * g), 0, SCG_L_PART_AUX);
+                }
+            }
         }
     } else {
 #pragma unroll
@@ -677,7 +738,12 @@ __device__ __forceinline__ void grad_net(const GradArgs& A, float* lds) {
     SCG_L_STAMP(5);
 }
 
-constexpr size_t grad_lds_words() { return grad_lds_base_words() + (private_dw1() ? (WAVES - 1) * W1R : 0); }
+constexpr size_t grad_lds_words() {
+    size_t a = MlpLds<NIN, HID, NU>::END + GradLds<NU>::END + region_b_words<NU>();
+    size_t c = MlpLds<NIN, HID, 1>::END + GradLds<1>::END + region_b_words<1>();
+    return a > c ? a : c;
+}
+static_assert(grad_lds_words() * sizeof(float) <= 160 * 1024, "the gradient kernel's LDS does not fit");
 
 template <bool ONE>
 __global__ __launch_bounds__(64 * WAVES, 1) void ppo_grad_kernel(const GradArgs A) {
@@ -685,7 +751,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void ppo_grad_kernel(const GradArgs 
     if (blockIdx.y == 0) grad_net<NU, true, ONE>(A, lds);
     else grad_net<1, false, ONE>(A, lds);
 }
-// A/B and test hook: the accumulating form at any size (initially: $SCG_LEARN_MULTI_TILE set).  The two forms are bit-identical.
+// A/B and test hook: the accumulating form at any size (initially: $SCG_LEARN_MULTI_TILE set).  The forms agree up to dW2's summation order.
 static int g_force_accumulating = getenv("SCG_LEARN_MULTI_TILE") != nullptr;
 extern "C" void scg_learn_force_accumulating_form(int on) { g_force_accumulating = on != 0; }
 // enqueue the gradient kernel: the one-tile form when no wave has more than one tile
